@@ -1,0 +1,227 @@
+""".vxa writer and results-XML reader: the file formats on either side of the simulator.
+
+Drop-in for the reference module evosoro/tools/read_write_voxelyze.py:
+  read_voxlyze_results(population, print_log, filename)          reference :7-37
+  write_voxelyze_file(sim, env, individual, run_directory, name) reference :40-407
+
+The writer emits, byte for byte, the text the reference writer emits for the same inputs (pinned by
+tests/golden/vxa/*.vxa, which were produced by importing the reference module in the build container,
+see tests/golden/make_golden.py).  The text is assembled from tables (simulator tags, the 7-material
+palette) instead of one literal; the odd indentation of the reference output (continuation lines carry
+8 or 12 leading blanks) is part of the format and therefore reproduced.
+"""
+import hashlib
+import os
+import random
+import time
+
+from evosoro_amd.tools.utils import py2_str as _s
+
+_IND = " " * 8      # leading blanks of continuation lines in the reference output
+_IND_MAT = " " * 12  # ... inside <Material>
+
+# (id, name, (r, g, b, a), stiffness source, CTE sign or None, blanks before the opening <Material> tag)
+# reference palette: read_write_voxelyze.py:175-344
+_PALETTE = (
+    (1, "Passive_Soft", ("0", "1", "1", "1"), "fat_stiffness", None, 8),
+    (2, "Passive_Hard", ("0", "0", "1", "1"), "bone_stiffness", None, 8),
+    (3, "Active_+", ("1", "0", "0", "1"), "muscle_stiffness", +0.01, 12),
+    (4, "Active_-", ("0", "1", "0", "1"), "muscle_stiffness", -0.01, 8),
+    (5, "Obstacle", ("1", "0.784", "0", "1"), "5e+007", None, 8),
+    (6, "Head_Active_+", ("1", "1", "0", "1"), "fat_stiffness", +0.01, 8),
+    (7, "Food", ("1", "1", "0", "1"), "muscle_stiffness", None, 8),
+)
+
+
+def read_voxlyze_results(population, print_log, filename="softbotsOutput.xml"):
+    """Parse objective values out of a results XML: {rank: float or None}.
+
+    Same contract as the reference (read_write_voxelyze.py:7-37): wait (up to 60 x 1 s) for a non-empty
+    file, then for every objective with a tag take the number between <tag> and </tag> on the last line
+    that contains the tag.  Objectives without a tag map to None.
+    """
+    attempts, max_attempts, size = 0, 60, 0
+    while attempts < max_attempts and size == 0:
+        try:
+            size = os.stat(filename).st_size
+        except OSError:
+            size = 0
+        attempts += 1
+        if size == 0:
+            time.sleep(1)
+    if size == 0:
+        print_log.message("ERROR: Cannot find a non-empty fitness file in %d attempts: abort" % max_attempts)
+        raise SystemExit(1)
+
+    with open(filename) as handle:
+        lines = handle.readlines()
+    results = {rank: None for rank in range(len(population.objective_dict))}
+    for rank, details in population.objective_dict.items():
+        tag = details["tag"]
+        if tag is None:
+            continue
+        closing = "</" + tag[1:]
+        for line in lines:
+            if tag in line:
+                results[rank] = float(line[line.find(tag) + len(tag):line.find(closing)])
+    return results
+
+
+def _simulator_lines(sim, run_directory, ident):
+    """Fixed part of <Simulator> (reference :62-123); first line flush left, the rest indented."""
+    fit = run_directory + "/fitnessFiles/softbotsOutput--id_%05i.xml" % ident
+    qhull = run_directory + "/tempFiles/qhullInput--id_%05i.txt" % ident
+    curv = run_directory + "/tempFiles/curvatures--id_%05i.txt" % ident
+    body = [
+        "<Integration>", "<Integrator>0</Integrator>", "<DtFrac>" + _s(sim.dt_frac) + "</DtFrac>", "</Integration>",
+        "<Damping>", "<BondDampingZ>1</BondDampingZ>", "<ColDampingZ>0.8</ColDampingZ>",
+        "<SlowDampingZ>0.01</SlowDampingZ>", "</Damping>",
+        "<Collisions>", "<SelfColEnabled>" + str(int(sim.self_collisions_enabled)) + "</SelfColEnabled>",
+        "<ColSystem>3</ColSystem>", "<CollisionHorizon>2</CollisionHorizon>", "</Collisions>",
+        "<Features>", "<FluidDampEnabled>0</FluidDampEnabled>", "<PoissonKickBackEnabled>0</PoissonKickBackEnabled>",
+        "<EnforceLatticeEnabled>0</EnforceLatticeEnabled>", "</Features>",
+        "<SurfMesh>", "<CMesh>", "<DrawSmooth>1</DrawSmooth>", "<Vertices/>", "<Facets/>", "<Lines/>", "</CMesh>",
+        "</SurfMesh>",
+        "<StopCondition>", "<StopConditionType>" + str(int(sim.stop_condition)) + "</StopConditionType>",
+        "<StopConditionValue>" + _s(sim.simulation_time) + "</StopConditionValue>",
+        "<AfterlifeTime>" + _s(sim.afterlife_time) + "</AfterlifeTime>",
+        "<MidLifeFreezeTime>" + _s(sim.mid_life_freeze_time) + "</MidLifeFreezeTime>",
+        "<InitCmTime>" + _s(sim.fitness_eval_init_time) + "</InitCmTime>", "</StopCondition>",
+        "<EquilibriumMode>", "<EquilibriumModeEnabled>" + _s(sim.equilibrium_mode) + "</EquilibriumModeEnabled>",
+        "</EquilibriumMode>",
+        "<GA>", "<WriteFitnessFile>1</WriteFitnessFile>", "<FitnessFileName>" + fit + "</FitnessFileName>",
+        "<QhullTmpFile>" + qhull + "</QhullTmpFile>", "<CurvaturesTmpFile>" + curv + "</CurvaturesTmpFile>", "</GA>",
+        "<MinTempFact>" + _s(sim.min_temp_fact) + "</MinTempFact>",
+        "<MaxTempFactChange>" + _s(sim.max_temp_fact_change) + "</MaxTempFactChange>",
+        "<MaxStiffnessChange>" + _s(sim.max_stiffness_change) + "</MaxStiffnessChange>",
+        "<MinElasticMod>" + _s(sim.min_elastic_mod) + "</MinElasticMod>",
+        "<MaxElasticMod>" + _s(sim.max_elastic_mod) + "</MaxElasticMod>",
+        "<ErrorThreshold>0</ErrorThreshold>", "<ThresholdTime>0</ThresholdTime>", "<MaxKP>0</MaxKP>",
+        "<MaxKI>0</MaxKI>", "<MaxANTIWINDUP>0</MaxANTIWINDUP>",
+    ]
+    return body[0] + "\n" + "".join(_IND + line + "\n" for line in body[1:])
+
+
+def _environment_lines(env):
+    """Fixed part of <Environment> (reference :133-156)."""
+    body = [
+        "<Fixed_Regions>", "<NumFixed>0</NumFixed>", "</Fixed_Regions>",
+        "<Forced_Regions>", "<NumForced>0</NumForced>", "</Forced_Regions>",
+        "<Gravity>", "<GravEnabled>" + _s(env.gravity_enabled) + "</GravEnabled>", "<GravAcc>-9.81</GravAcc>",
+        "<FloorEnabled>" + _s(env.floor_enabled) + "</FloorEnabled>",
+        "<FloorSlope>" + _s(env.floor_slope) + "</FloorSlope>", "</Gravity>",
+        "<Thermal>", "<TempEnabled>" + _s(env.temp_enabled) + "</TempEnabled>",
+        "<TempAmp>" + _s(env.temp_amp) + "</TempAmp>", "<TempBase>25</TempBase>",
+        "<VaryTempEnabled>1</VaryTempEnabled>", "<TempPeriod>" + _s(1.0 / env.frequency) + "</TempPeriod>",
+        "</Thermal>",
+        "<TimeBetweenTraces>" + _s(env.time_between_traces) + "</TimeBetweenTraces>",
+        "<StickyFloor>" + _s(env.sticky_floor) + "</StickyFloor>", "</Environment>",
+    ]
+    return body[0] + "\n" + "".join(_IND + line + "\n" for line in body[1:])
+
+
+def _material_lines(env, entry):
+    ident, name, rgba, stiff, cte_sign, open_blanks = entry
+    stiffness = _s(getattr(env, stiff)) if hasattr(env, stiff) else stiff
+    if cte_sign is None:
+        cte = "0"
+    else:  # one draw from the global `random` stream per active material, as the reference does (:251,:275,:323)
+        cte = _s(cte_sign * (1 + random.uniform(0, env.actuation_variance)))
+    inner = [
+        "<MatType>0</MatType>", "<Name>" + name + "</Name>", "<Display>", "<Red>" + rgba[0] + "</Red>",
+        "<Green>" + rgba[1] + "</Green>", "<Blue>" + rgba[2] + "</Blue>", "<Alpha>" + rgba[3] + "</Alpha>",
+        "</Display>", "<Mechanical>", "<MatModel>0</MatModel>", "<Elastic_Mod>" + stiffness + "</Elastic_Mod>",
+        "<Plastic_Mod>0</Plastic_Mod>", "<Yield_Stress>0</Yield_Stress>", "<FailModel>0</FailModel>",
+        "<Fail_Stress>0</Fail_Stress>", "<Fail_Strain>0</Fail_Strain>", "<Density>1e+006</Density>",
+        "<Poissons_Ratio>0.35</Poissons_Ratio>", "<CTE>" + cte + "</CTE>", "<uStatic>1</uStatic>",
+        "<uDynamic>0.5</uDynamic>", "</Mechanical>",
+    ]
+    text = " " * open_blanks + "<Material ID=\"%d\">\n" % ident
+    text += "".join(_IND_MAT + line + "\n" for line in inner)
+    return text + _IND + "</Material>\n"
+
+
+def _vxc_header_lines(env, size_xyz):
+    """<VXC> up to and including the <Z_Voxels> line (reference :158-359)."""
+    head = [
+        "<Lattice>", "<Lattice_Dim>" + _s(env.lattice_dimension) + "</Lattice_Dim>", "<X_Dim_Adj>1</X_Dim_Adj>",
+        "<Y_Dim_Adj>1</Y_Dim_Adj>", "<Z_Dim_Adj>1</Z_Dim_Adj>", "<X_Line_Offset>0</X_Line_Offset>",
+        "<Y_Line_Offset>0</Y_Line_Offset>", "<X_Layer_Offset>0</X_Layer_Offset>",
+        "<Y_Layer_Offset>0</Y_Layer_Offset>", "</Lattice>",
+        "<Voxel>", "<Vox_Name>BOX</Vox_Name>", "<X_Squeeze>1</X_Squeeze>", "<Y_Squeeze>1</Y_Squeeze>",
+        "<Z_Squeeze>1</Z_Squeeze>", "</Voxel>", "<Palette>",
+    ]
+    text = "<VXC Version=\"0.93\">\n" + "".join(_IND + line + "\n" for line in head)
+    for entry in _PALETTE:
+        text += _material_lines(env, entry)
+    tail = ["</Palette>", "<Structure Compression=\"ASCII_READABLE\">",
+            "<X_Voxels>" + str(size_xyz[0]) + "</X_Voxels>", "<Y_Voxels>" + str(size_xyz[1]) + "</Y_Voxels>",
+            "<Z_Voxels>" + str(size_xyz[2]) + "</Z_Voxels>"]
+    return text + "".join(_IND + line + "\n" for line in tail)
+
+
+def write_voxelyze_file(sim, env, individual, run_directory, run_name):
+    """Serialise one individual to `<run_directory>/voxelyzeFiles/<run_name>--id_%05i.vxa`.
+
+    Returns the md5 hex digest of the concatenated per-voxel output strings, which evaluate_all uses as
+    its evaluation-cache key (reference :362,390,404-407).
+    """
+    mapping = individual.genotype.to_phenotype_mapping
+    size = individual.genotype.orig_size_xyz
+
+    # outputs that drive environment attributes rather than voxel data (reference :45-49)
+    for _, details in mapping.items():
+        if details["env_kws"] is not None:
+            for env_key, env_func in details["env_kws"].items():
+                setattr(env, env_key, env_func(details["state"]))
+
+    out = ["<?xml version=\"1.0\" encoding=\"ISO-8859-1\"?>\n" + _IND + "<VXA Version=\"1.0\">\n" + _IND +
+           "<Simulator>\n"]
+    for name, tag in sim.new_param_tag_dict.items():
+        out.append(tag + _s(getattr(sim, name)) + "</" + tag[1:] + "\n")
+    out.append(_simulator_lines(sim, run_directory, individual.id))
+    if hasattr(individual, "parent_lifetime"):
+        if individual.parent_lifetime > 0:
+            out.append("<ParentLifetime>" + _s(individual.parent_lifetime) + "</ParentLifetime>\n")
+        elif individual.lifetime > 0:
+            out.append("<ParentLifetime>" + _s(individual.lifetime) + "</ParentLifetime>\n")
+    out.append("</Simulator>\n")
+
+    out.append("<Environment>\n")
+    for name, tag in env.new_param_tag_dict.items():
+        out.append(tag + _s(getattr(env, name)) + "</" + tag[1:] + "\n")
+    out.append(_environment_lines(env))
+    out.append(_vxc_header_lines(env, size))
+
+    if "<Data>" not in [details["tag"] for _, details in mapping.items()]:
+        # morphology not evolved: a full box of material 3 (reference :361-370)
+        out.append("<Data>\n")
+        for _ in range(size[2]):
+            out.append("<Layer><![CDATA[" + "3" * (size[0] * size[1]) + "]]></Layer>\n")
+        out.append("</Data>\n")
+
+    md5_text = []
+    for _, details in mapping.items():
+        voxel_data = details["env_kws"] is None
+        if voxel_data:
+            out.append(details["tag"] + "\n")
+        if details["params"] is not None:
+            for param_tag, param in zip(details["param_tags"], details["params"]):
+                out.append(param_tag + _s(param) + "</" + param_tag[1:] + "\n")
+        if voxel_data:
+            separator = "" if details["tag"] == "<Data>" else ", "
+            for z in range(size[2]):
+                cells = []
+                for y in range(size[1]):
+                    for x in range(size[0]):
+                        cells.append(_s(details["output_type"](details["state"][x, y, z])))
+                md5_text.extend(cells)
+                out.append("<Layer><![CDATA[" + "".join(cell + separator for cell in cells) + "]]></Layer>\n")
+            out.append("</" + details["tag"][1:] + "\n")
+
+    out.append("</Structure>\n" + _IND + "</VXC>\n" + _IND + "</VXA>")
+
+    path = run_directory + "/voxelyzeFiles/" + run_name + "--id_%05i.vxa" % individual.id
+    with open(path, "w") as handle:
+        handle.write("".join(out))
+    return hashlib.md5("".join(md5_text).encode()).hexdigest()

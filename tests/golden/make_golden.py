@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the REFERENCE itself.  Runs only in the build container (it needs
+/root/reference and oracle/_ref/*, built by `make -C oracle ref`); the fixtures it writes are data
+(inputs + expected outputs) and are what travels to the GPU box.
+
+ 1. .vxa text pinned by IMPORTING the reference writer (evosoro/tools/read_write_voxelyze.py runs under
+    python3 up to its final md5 line, which raises TypeError after the file is complete) on duck-typed
+    inputs; our writer must produce identical bytes (asserted here and again in tests/test_vxa_io.py).
+ 2. Expected physics from the reference C++ built from its own sources: the result XML written by
+    oracle/_ref/voxelyze_ref, and binary state traces written by oracle/_ref/vxprobe (first 200 steps,
+    every 25th step, full voxel state; plus initial/final state of the whole run).
+ 3. read_voxlyze_results pinned by running the reference reader on those result XMLs.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import random
+from collections import OrderedDict
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REF, "evosoro", "tools"))
+
+import read_write_voxelyze as ref_rw  # noqa: E402  (the reference module)
+from evosoro_amd.base import Sim, Env, ObjectiveDict  # noqa: E402
+from evosoro_amd.tools import read_write_voxelyze as our_rw  # noqa: E402
+from evosoro_amd import workloads  # noqa: E402
+
+RUN_DIR = "golden_run"   # relative on purpose: it is embedded in <FitnessFileName>
+RUN_NAME = "golden"
+
+
+def cases():
+    out = OrderedDict()
+    # config 1 "plumbing": SURVEY App. C probe robot
+    out["probe6"] = dict(variant="land", sim=Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1),
+                         env=Env(), ind=workloads.make_individual(0, workloads.probe_material()))
+    out["rand6_nocol"] = dict(variant="land",
+                              sim=Sim(self_collisions_enabled=False, dt_frac=0.9, simulation_time=0.2,
+                                      fitness_eval_init_time=0.05),
+                              env=Env(), ind=workloads.random_robot(1, (6, 6, 6), 3))
+    out["rand6_col"] = dict(variant="land", sim=Sim(dt_frac=0.9, simulation_time=0.25, fitness_eval_init_time=0.1),
+                            env=Env(), ind=workloads.random_robot(2, (6, 6, 6), 7))
+    # soft-only robot (no bone): 10x larger dt, big deformations, sticky floor off, InitCmTime = 0 quirk
+    soft = workloads.random_material((5, 5, 5), 11)
+    soft[soft == 2] = 1
+    out["soft5_init0"] = dict(variant="land", sim=Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0),
+                              env=Env(), ind=workloads.make_individual(3, soft))
+    # per-voxel phase offsets + extra env tag through add_param
+    env4 = Env(frequency=5.0, temp_amp=35)
+    env4.add_param("growth_amplitude", 0.3, "<GrowthAmplitude>")
+    # (phases rounded to 3 decimals: python2 str() prints 12 significant digits, python3 the shortest repr; the
+    #  reference is python2 code but can only be imported under python3 here, so pin on values where both agree)
+    phase = np.round(np.random.RandomState(99).uniform(-1, 1, size=(4, 4, 4)), 3)
+    out["phase4"] = dict(variant="land", sim=Sim(dt_frac=0.8, simulation_time=0.3, fitness_eval_init_time=0.05),
+                         env=env4, ind=workloads.make_individual(4, workloads.random_material((4, 4, 4), 5, 0.1),
+                                                                OrderedDict([("<PhaseOffset>", phase)])))
+    return out
+
+
+class _Pop(object):
+    pass
+
+
+def main():
+    work = os.path.join("/tmp", "vx_golden_work")
+    shutil.rmtree(work, ignore_errors=True)
+    for sub in ("ref", "ours"):
+        for d in ("voxelyzeFiles", "fitnessFiles", "tempFiles"):
+            os.makedirs(os.path.join(work, sub, RUN_DIR, d))
+    vxa_dir = os.path.join(HERE, "vxa")
+    exp_dir = os.path.join(HERE, "expected")
+    shutil.rmtree(vxa_dir, ignore_errors=True)
+    shutil.rmtree(exp_dir, ignore_errors=True)
+    os.makedirs(vxa_dir)
+    os.makedirs(exp_dir)
+    manifest = OrderedDict()
+    probe = {"land": os.path.join(REPO, "oracle/_ref/vxprobe"), "lw": os.path.join(REPO, "oracle/_ref/vxprobe_lw")}
+    refbin = {"land": os.path.join(REPO, "oracle/_ref/voxelyze_ref"),
+              "lw": os.path.join(REPO, "oracle/_ref/voxelyze_lw_ref")}
+
+    for name, case in cases().items():
+        ind = case["ind"]
+        fname = RUN_NAME + "--id_%05i.vxa" % ind.id
+        # reference writer (py3: file complete, then TypeError at the md5 update)
+        os.chdir(os.path.join(work, "ref"))
+        random.seed(12345)
+        try:
+            ref_rw.write_voxelyze_file(case["sim"], case["env"], ind, RUN_DIR, RUN_NAME)
+        except TypeError:
+            pass
+        ref_text = open(os.path.join(RUN_DIR, "voxelyzeFiles", fname)).read()
+        state_after_ref = random.getstate()
+        # ours
+        os.chdir(os.path.join(work, "ours"))
+        random.seed(12345)
+        md5 = our_rw.write_voxelyze_file(case["sim"], case["env"], ind, RUN_DIR, RUN_NAME)
+        our_text = open(os.path.join(RUN_DIR, "voxelyzeFiles", fname)).read()
+        assert our_text == ref_text, "writer mismatch for %s" % name
+        assert random.getstate() == state_after_ref, "random stream consumption differs for %s" % name
+        with open(os.path.join(vxa_dir, name + ".vxa"), "w") as f:
+            f.write(ref_text)
+
+        # reference physics
+        os.chdir(os.path.join(work, "ref"))
+        vxa = os.path.join(RUN_DIR, "voxelyzeFiles", fname)
+        subprocess.run(["timeout", "900", refbin[case["variant"]], "-f", vxa], check=False)
+        xml = os.path.join(RUN_DIR, "fitnessFiles", "softbotsOutput--id_%05i.xml" % ind.id)
+        shutil.copy(xml, os.path.join(exp_dir, name + ".xml"))
+        subprocess.run(["timeout", "900", probe[case["variant"]], "-f", vxa, "-o",
+                        os.path.join(exp_dir, name + ".early.bin"), "-max", "200", "-every", "25", "-noresult"],
+                       check=True)
+        subprocess.run(["timeout", "900", probe[case["variant"]], "-f", vxa, "-o",
+                        os.path.join(exp_dir, name + ".final.bin"), "-every", "100000000", "-noresult"], check=True)
+
+        # reference reader on the reference XML
+        pop = _Pop()
+        pop.objective_dict = ObjectiveDict()
+        pop.objective_dict.add_objective(name="fitness", maximize=True, tag="<NormFinalDist>")
+        pop.objective_dict.add_objective(name="age", maximize=False, tag=None)
+        pop.objective_dict.add_objective(name="y", maximize=True, tag="<finalDistY>")
+        pop.objective_dict.add_objective(name="touch", maximize=True, tag="<NumTouchingFloor>")
+        values = ref_rw.read_voxlyze_results(pop, None, xml)
+        manifest[name] = {"variant": case["variant"], "id": ind.id, "md5": md5,
+                          "read_results": {str(k): v for k, v in values.items()},
+                          "nvox": int((ind.genotype.to_phenotype_mapping["material"]["state"] > 0).sum())}
+        print(name, manifest[name])
+
+    # input files the reference ships next to its simulator (data, not code); expected values from the reference
+    shipped = [("land", "evosoro/_voxcad/voxelyzeMain/Example_withPhaseOffset.vxa", "example_phaseoffset"),
+               ("land", "evosoro/_voxcad/voxelyzeMain/Example_1.vxa", "example_1")]
+    for variant, rel, name in shipped:
+        wd = os.path.join(work, "shipped_" + name)
+        os.makedirs(os.path.join(wd, "fitnessFiles"))
+        shutil.copy(os.path.join(REF, rel), os.path.join(wd, name + ".vxa"))
+        os.chdir(wd)
+        subprocess.run(["timeout", "900", refbin[variant], "-f", name + ".vxa"], check=False)
+        outs = [p for p in os.listdir(wd) + [os.path.join("fitnessFiles", q) for q in os.listdir("fitnessFiles")]
+                if p.endswith(".xml")]
+        assert len(outs) == 1, outs
+        shutil.copy(os.path.join(wd, name + ".vxa"), os.path.join(vxa_dir, name + ".vxa"))
+        shutil.copy(outs[0], os.path.join(exp_dir, name + ".xml"))
+        subprocess.run(["timeout", "900", probe[variant], "-f", name + ".vxa", "-o",
+                        os.path.join(exp_dir, name + ".early.bin"), "-max", "200", "-every", "50", "-noresult"],
+                       check=True)
+        manifest[name] = {"variant": variant, "shipped": rel, "result_path": outs[0]}
+
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
