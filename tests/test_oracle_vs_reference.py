@@ -1,0 +1,91 @@
+"""Pins the CPU restatement (oracle/vx_oracle.c) on the reference itself.
+
+Expected values are outputs of the UNMODIFIED reference C++ (built from /root/reference by oracle/Makefile)
+captured by tests/golden/make_golden.py: full-state traces of the first 200 steps, the final state of the
+whole run, and the result XML.  The restatement follows the reference's operation order, and both sides use
+the same glibc libm without FMA contraction, so the bar is BIT-EXACT state (not a tolerance) and
+identical 6-significant-digit result fields.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vxoracle as vo
+
+LAND_CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4"]
+SHIPPED = ["example_1", "example_phaseoffset"]
+
+RESULT_TAGS = [("NormFinalDist", "norm_final_dist"), ("NormRegimeDist", "norm_regime_dist"),
+               ("NormFrozenDist", "norm_frozen_dist"), ("FinalDist", "final_dist"), ("finalDistY", "final_dist_y"),
+               ("AnteriorDist", "anterior_dist"), ("PosteriorDist", "posterior_dist"), ("AnteriorY", "anterior_y"),
+               ("PosteriorY", "posterior_y"), ("EndOfLifePosteriorY", "end_of_life_posterior_y"),
+               ("FallAdjPostY", "fall_adj_post_y"), ("NumNonFeetTouchingFloor", "num_non_feet_touching_floor"),
+               ("NumTouchingFloor", "num_touching_floor"), ("Lifetime", "lifetime")]
+
+
+def _sim(golden_dir, name):
+    return vo.OracleSim.from_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"))
+
+
+@pytest.mark.parametrize("name", LAND_CASES + SHIPPED)
+def test_early_trace_bit_exact(golden_dir, name):
+    trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".early.bin"))
+    sim = _sim(golden_dir, name)
+    info = sim.info()
+    assert (info.nvox, info.nbond) == (trace["nvox"], trace["nbond"])
+    assert info.opt_dt == trace["opt_dt"]          # CalcMaxDt, bitwise
+    for rec in trace["records"]:
+        todo = rec["step"] - sim.info().steps
+        if todo > 0:
+            assert sim.step(todo) == todo
+        got = sim.info()
+        assert got.ncol == rec["ncol"], "collision bond count at step %d" % rec["step"]
+        assert got.cur_time == rec["time"]
+        assert np.array_equal(sim.state(), rec["state"]), "state differs at step %d" % rec["step"]
+
+
+@pytest.mark.parametrize("name", LAND_CASES)
+def test_full_run_final_state_and_result(golden_dir, name):
+    trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".final.bin"))
+    sim = _sim(golden_dir, name)
+    sim.step(-1)
+    info = sim.info()
+    assert info.status == 1
+    assert info.steps == trace["total_steps"]
+    assert np.array_equal(sim.state(), trace["records"][-1]["state"])
+    assert np.array_equal(np.array(info.ini_cm), trace["ini_cm"])    # IniCM latch (one step late, App. A.9)
+    assert np.array_equal(np.array(info.cur_cm), trace["cur_cm"])
+    expected = vo.read_result_xml(os.path.join(golden_dir, "expected", name + ".xml"))
+    result = sim.result()
+    for tag, field in RESULT_TAGS:
+        assert "%.6g" % getattr(result, field) == "%.6g" % expected[tag], tag
+
+
+def test_shipped_example_result(golden_dir):
+    # input file shipped with the reference simulator (5x5x5, per-voxel <PhaseOffset>, 3.24 s, collisions on)
+    name = "example_phaseoffset"
+    sim = _sim(golden_dir, name)
+    sim.step(-1)
+    expected = vo.read_result_xml(os.path.join(golden_dir, "expected", name + ".xml"))
+    result = sim.result()
+    for tag, field in RESULT_TAGS:
+        assert "%.6g" % getattr(result, field) == "%.6g" % expected[tag], tag
+
+
+def test_empty_and_single_voxel():
+    base = vo.parse_vxa(os.path.join(os.path.dirname(__file__), "golden", "vxa", "phase4.vxa"))
+    empty = dict(base)
+    empty["structure"] = np.zeros_like(base["structure"])
+    empty["phase_offset"] = None
+    sim = vo.OracleSim(empty)
+    assert sim.info().status == 3 and sim.step(-1) == 0       # the reference would loop forever
+    single = dict(empty)
+    cells = np.zeros_like(base["structure"])
+    cells[0] = 3
+    single["structure"] = cells
+    sim = vo.OracleSim(single)
+    info = sim.info()
+    assert (info.nvox, info.nbond) == (1, 0)
+    sim.step(-1)
+    assert sim.info().status == 1 and np.isfinite(sim.state()).all()
