@@ -1,0 +1,179 @@
+// C ABI of libvxhip (include/vxhip.h): exception -> status code translation around vxh::Engine.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+
+#include "engine.hpp"
+
+struct vxh_engine {
+    vxh::Engine* impl = nullptr;
+    std::string last_error;
+};
+
+namespace {
+
+template <class F>
+int guarded(vxh_engine* e, F&& body)
+{
+    if (!e || !e->impl) return VXH_ERR_ARG;
+    try {
+        body();
+        return VXH_OK;
+    } catch (const std::invalid_argument& ex) {
+        e->last_error = ex.what();
+        return std::strstr(ex.what(), "unsupported") ? VXH_ERR_UNSUPPORTED : VXH_ERR_ARG;
+    } catch (const std::logic_error& ex) {
+        e->last_error = ex.what();
+        return VXH_ERR_STATE;
+    } catch (const std::runtime_error& ex) {
+        e->last_error = ex.what();
+        if (std::strncmp(ex.what(), "HIP:", 4) == 0) return VXH_ERR_HIP;
+        if (std::strncmp(ex.what(), "xml:", 4) == 0 || std::strncmp(ex.what(), "vxa:", 4) == 0) return VXH_ERR_PARSE;
+        return VXH_ERR_PARSE;
+    } catch (const std::exception& ex) {
+        e->last_error = ex.what();
+        return VXH_ERR_ARG;
+    }
+}
+
+bool bad_robot(const vxh_engine* e, int robot) { return !e || !e->impl || robot < 0 || robot >= e->impl->num_robots(); }
+
+}  // namespace
+
+extern "C" {
+
+int vxh_create(vxh_engine** out, int variant, int device_id)
+{
+    if (!out || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;
+    *out = nullptr;
+    vxh_engine* e = new vxh_engine;
+    try {
+        e->impl = new vxh::Engine(variant, device_id);
+    } catch (const std::exception& ex) {
+        std::fprintf(stderr, "libvxhip: %s\n", ex.what());
+        delete e;
+        return std::strncmp(ex.what(), "HIP:", 4) == 0 ? VXH_ERR_HIP : VXH_ERR_NO_DEVICE;
+    }
+    *out = e;
+    return VXH_OK;
+}
+
+void vxh_destroy(vxh_engine* e)
+{
+    if (!e) return;
+    delete e->impl;
+    delete e;
+}
+
+int vxh_add_vxa_buffer(vxh_engine* e, const char* xml, size_t len, int* robot_index_out)
+{
+    if (!xml) return VXH_ERR_ARG;
+    return guarded(e, [&] { int idx = e->impl->add_vxa(xml, len); if (robot_index_out) *robot_index_out = idx; });
+}
+
+int vxh_add_vxa_file(vxh_engine* e, const char* path, int* robot_index_out)
+{
+    if (!e || !e->impl || !path) return VXH_ERR_ARG;
+    std::ifstream in(path, std::ios::binary);
+    if (!in) { e->last_error = std::string("cannot open ") + path; return VXH_ERR_IO; }
+    std::stringstream ss;
+    ss << in.rdbuf();
+    const std::string text = ss.str();
+    return vxh_add_vxa_buffer(e, text.data(), text.size(), robot_index_out);
+}
+
+int vxh_num_robots(const vxh_engine* e) { return (e && e->impl) ? e->impl->num_robots() : VXH_ERR_ARG; }
+
+int vxh_robot_dims(const vxh_engine* e, int robot, int* nvox, int* nbond, double* dt, long long* planned_steps)
+{
+    if (bad_robot(e, robot)) return VXH_ERR_ARG;
+    const vxh::RobotModel& m = e->impl->robot(robot);
+    if (nvox) *nvox = m.nvox;
+    if (nbond) *nbond = m.nbond;
+    if (dt) *dt = m.dt;
+    if (planned_steps) *planned_steps = m.planned_steps;
+    return VXH_OK;
+}
+
+int vxh_run(vxh_engine* e) { return guarded(e, [&] { e->impl->run(); }); }
+int vxh_step(vxh_engine* e, long long nsteps) { return guarded(e, [&] { e->impl->step(nsteps); }); }
+int vxh_reset(vxh_engine* e) { return guarded(e, [&] { e->impl->reset(); }); }
+int vxh_clear(vxh_engine* e) { return guarded(e, [&] { e->impl->clear(); }); }
+
+int vxh_get_result(const vxh_engine* ce, int robot, vxh_result* out)
+{
+    vxh_engine* e = const_cast<vxh_engine*>(ce);
+    if (bad_robot(e, robot) || !out) return VXH_ERR_ARG;
+    return guarded(e, [&] { e->impl->result(robot, out); });
+}
+
+int vxh_fitness_file_name(const vxh_engine* e, int robot, char* buf, size_t cap)
+{
+    if (bad_robot(e, robot) || !buf || cap == 0) return VXH_ERR_ARG;
+    const std::string& name = e->impl->robot(robot).vxa.fitness_file_name;
+    if (name.size() + 1 > cap) return VXH_ERR_ARG;
+    std::memcpy(buf, name.c_str(), name.size() + 1);
+    return VXH_OK;
+}
+
+int vxh_write_result_xml(const vxh_engine* ce, int robot, const char* path_or_null)
+{
+    vxh_engine* e = const_cast<vxh_engine*>(ce);
+    if (bad_robot(e, robot)) return VXH_ERR_ARG;
+    vxh_result res;
+    int rc = vxh_get_result(e, robot, &res);
+    if (rc != VXH_OK) return rc;
+    const vxh::RobotModel& m = e->impl->robot(robot);
+    std::string path = path_or_null ? path_or_null : m.vxa.fitness_file_name;
+    if (path.empty()) { e->last_error = "no FitnessFileName in the .vxa and no path given"; return VXH_ERR_IO; }
+    const std::string text = vxh::result_xml(m, res);
+    std::FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { e->last_error = "cannot write " + path; return VXH_ERR_IO; }
+    const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
+    std::fclose(f);
+    if (!ok) { e->last_error = "short write to " + path; return VXH_ERR_IO; }
+    return VXH_OK;
+}
+
+int vxh_get_state(const vxh_engine* ce, int robot, double* out14n, int capacity)
+{
+    vxh_engine* e = const_cast<vxh_engine*>(ce);
+    if (bad_robot(e, robot) || !out14n) return VXH_ERR_ARG;
+    return guarded(e, [&] { e->impl->state14(robot, out14n, capacity); });
+}
+
+int vxh_get_counters(const vxh_engine* e, vxh_counters* out)
+{
+    if (!e || !e->impl || !out) return VXH_ERR_ARG;
+    e->impl->counters(out);
+    return VXH_OK;
+}
+
+int vxh_set_option(vxh_engine* e, const char* key, double value)
+{
+    if (!key) return VXH_ERR_ARG;
+    return guarded(e, [&] { e->impl->set_option(key, value); });
+}
+
+const char* vxh_strerror(int status)
+{
+    switch (status) {
+    case VXH_OK: return "ok";
+    case VXH_ERR_ARG: return "bad argument";
+    case VXH_ERR_NO_DEVICE: return "no usable HIP device (libvxhip has no CPU path)";
+    case VXH_ERR_PARSE: return "malformed .vxa";
+    case VXH_ERR_IO: return "file I/O error";
+    case VXH_ERR_HIP: return "HIP runtime error";
+    case VXH_ERR_STATE: return "call order error";
+    case VXH_ERR_UNSUPPORTED: return "unsupported .vxa feature";
+    default: return "unknown status";
+    }
+}
+
+const char* vxh_last_error(const vxh_engine* e) { return e ? e->last_error.c_str() : ""; }
+const char* vxh_version(void) { return "vxhip 0.1.0 (gfx950)"; }
+
+}  // extern "C"

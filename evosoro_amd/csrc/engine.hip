@@ -1,0 +1,398 @@
+// Engine implementation: batch assembly, HBM upload, step-round launches (hipGraph), download.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+#include "engine.hpp"
+#include "kernels.hpp"
+
+namespace vxh {
+
+namespace {
+
+void hip_check(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string("HIP: ") + what + ": " + hipGetErrorString(e));
+}
+#define HIP_OK(call) hip_check((call), #call)
+
+template <class T>
+int intern_bytes(std::vector<T>& table, const T& value)
+{
+    for (size_t i = 0; i < table.size(); ++i)
+        if (std::memcmp(&table[i], &value, sizeof(T)) == 0) return (int)i;
+    table.push_back(value);
+    return (int)table.size() - 1;
+}
+
+}  // namespace
+
+struct Engine::Device {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<void*> allocs;
+    DBatch B{};
+    std::vector<DRobot> h_robot;
+    std::vector<int> vox_begin;           // per robot, global slot of voxel 0
+    std::vector<int> surf_begin;
+    int total_surf = 0;
+    long long max_planned = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_rounds = 0;
+
+    template <class T>
+    T* upload(const std::vector<T>& h, size_t min_count = 1)
+    {
+        size_t n = std::max(h.size(), min_count);
+        void* p = nullptr;
+        HIP_OK(hipMalloc(&p, n * sizeof(T)));
+        allocs.push_back(p);
+        if (!h.empty()) HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        return (T*)p;
+    }
+    template <class T>
+    T* alloc_zero(size_t n)
+    {
+        void* p = nullptr;
+        if (n == 0) n = 1;
+        HIP_OK(hipMalloc(&p, n * sizeof(T)));
+        allocs.push_back(p);
+        HIP_OK(hipMemset(p, 0, n * sizeof(T)));
+        return (T*)p;
+    }
+    void free_all()
+    {
+        if (graph_exec) { hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        if (graph) { hipGraphDestroy(graph); graph = nullptr; }
+        for (void* p : allocs) hipFree(p);
+        allocs.clear();
+        B = DBatch{};
+    }
+};
+
+Engine::Engine(int variant, int device_id) : variant_(variant), device_id_(device_id), dev_(new Device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        throw std::runtime_error("no HIP device available (libvxhip has no CPU path)");
+    if (device_id < 0 || device_id >= count) throw std::runtime_error("device id out of range");
+    HIP_OK(hipSetDevice(device_id));
+    HIP_OK(hipStreamCreateWithFlags(&dev_->stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreate(&dev_->ev0));
+    HIP_OK(hipEventCreate(&dev_->ev1));
+}
+
+Engine::~Engine()
+{
+    if (dev_) {
+        hipSetDevice(device_id_);
+        dev_->free_all();
+        if (dev_->ev0) hipEventDestroy(dev_->ev0);
+        if (dev_->ev1) hipEventDestroy(dev_->ev1);
+        if (dev_->stream) hipStreamDestroy(dev_->stream);
+    }
+}
+
+int Engine::add_vxa(const char* data, size_t len)
+{
+    VxaModel vxa = read_vxa(data, len, variant_);
+    if (!vxa.unsupported.empty()) {
+        std::string msg = "unsupported .vxa feature(s):";
+        for (const auto& u : vxa.unsupported) msg += " [" + u + "]";
+        throw std::invalid_argument(msg);
+    }
+    robots_.push_back(build_robot(vxa));
+    prepared_ = false;
+    downloaded_ = false;
+    return (int)robots_.size() - 1;
+}
+
+void Engine::clear()
+{
+    HIP_OK(hipSetDevice(device_id_));
+    dev_->free_all();
+    robots_.clear();
+    host_.clear();
+    prepared_ = downloaded_ = false;
+    rounds_done_ = 0;
+}
+
+void Engine::set_option(const std::string& key, double value)
+{
+    if (key == "graph_steps") { graph_steps_ = (int)value; if (dev_->graph_exec) { hipGraphExecDestroy(dev_->graph_exec); dev_->graph_exec = nullptr; } }
+    else throw std::invalid_argument("unknown option " + key);
+}
+
+void Engine::prepare()
+{
+    HIP_OK(hipSetDevice(device_id_));
+    Device& D = *dev_;
+    D.free_all();
+    const int nr = (int)robots_.size();
+    std::vector<DVoxClass> vtab;
+    std::vector<DBondClass> btab;
+    D.h_robot.assign(nr, DRobot{});
+    D.vox_begin.assign(nr, 0);
+    D.surf_begin.assign(nr, 0);
+    int nv = 0, ns = 0;
+    D.max_planned = 0;
+    for (int r = 0; r < nr; ++r) {
+        D.vox_begin[r] = nv;
+        D.surf_begin[r] = ns;
+        nv += (robots_[r].nvox + 63) / 64 * 64;
+        ns += robots_[r].vxa.self_col_enabled ? robots_[r].nsurf : 0;
+        if (robots_[r].nvox > 0) D.max_planned = std::max(D.max_planned, robots_[r].planned_steps);
+    }
+    if (nv == 0) nv = 64;
+    D.total_surf = ns;
+
+    std::vector<int> wave_robot(nv / 64, -1), nbr((size_t)6 * nv, -1), surf(std::max(ns, 1), 0), surf_ord(nv, -1), near_off((size_t)nv + 1, 0), near_idx;
+    std::vector<unsigned short> vclass(nv, 0);
+    std::vector<short> bclass((size_t)3 * nv, -1);
+    std::vector<float> phase(nv, 0.f), amp_damp(nv, 1.f);
+    std::vector<double> px(nv, 0), py(nv, 0), pz(nv, 0), sc(nv, 0), qw(nv, 1.0);
+    std::vector<unsigned char> small((size_t)3 * nv, 1);
+    std::vector<DRobotState> rstate(nr);
+
+    for (int r = 0; r < nr; ++r) {
+        const RobotModel& M = robots_[r];
+        const VxaModel& X = M.vxa;
+        const int base = D.vox_begin[r];
+        std::vector<int> vmap(M.vox_classes.size()), bmap(M.bond_classes.size());
+        for (size_t i = 0; i < M.vox_classes.size(); ++i) {
+            const VoxClass& c = M.vox_classes[i];
+            DVoxClass d;
+            std::memset(&d, 0, sizeof(d));
+            d.mass = c.mass; d.mass_inv = c.mass_inv; d.inertia_inv = c.inertia_inv; d.c_lin = c.c_lin; d.c_ang = c.c_ang;
+            d.E = c.E; d.k_floor = c.k_floor; d.u_static = c.u_static; d.u_dynamic = c.u_dynamic; d.cte = c.cte;
+            d.nom_size = c.nom_size; d.mat = c.mat;
+            vmap[i] = intern_bytes(vtab, d);
+        }
+        for (size_t i = 0; i < M.bond_classes.size(); ++i) {
+            const BondClass& c = M.bond_classes[i];
+            DBondClass d;
+            std::memset(&d, 0, sizeof(d));
+            d.L = c.L; d.a1 = c.a1; d.a2 = c.a2; d.b1 = c.b1; d.b2 = c.b2; d.b3 = c.b3;
+            d.sq_a1m1 = c.sq_a1m1; d.sq_a1m2 = c.sq_a1m2; d.sq_a2i1 = c.sq_a2i1; d.sq_a2i2 = c.sq_a2i2;
+            d.sq_b1m1 = c.sq_b1m1; d.sq_b1m2 = c.sq_b1m2; d.sq_b2fm1 = c.sq_b2fm1; d.sq_b2fm2 = c.sq_b2fm2;
+            d.sq_b3i1 = c.sq_b3i1; d.sq_b3i2 = c.sq_b3i2;
+            d.stress_E1 = c.stress_E1; d.stress_E2 = c.stress_E2; d.area_sum = c.area_sum; d.homogeneous = c.homogeneous;
+            bmap[i] = intern_bytes(btab, d);
+        }
+        if (vtab.size() > 65535 || btab.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one batch");
+        for (int w = base / 64; w < (base + (M.nvox + 63) / 64 * 64) / 64; ++w) wave_robot[w] = r;
+        for (int v = 0; v < M.nvox; ++v) {
+            const int g = base + v;
+            vclass[g] = (unsigned short)vmap[M.vox_class[v]];
+            phase[g] = M.phase_offset[v];
+            amp_damp[g] = M.temp_amp_damp[v];
+            px[g] = M.nom_pos[3 * v]; py[g] = M.nom_pos[3 * v + 1]; pz[g] = M.nom_pos[3 * v + 2];
+            sc[g] = M.vox_classes[M.vox_class[v]].nom_size;
+            for (int d = 0; d < 6; ++d) { int o = M.nbr[(size_t)v * 6 + d]; nbr[(size_t)d * nv + g] = o < 0 ? -1 : base + o; }
+            for (int a = 0; a < 3; ++a) { int c = M.bond_class[(size_t)v * 3 + a]; bclass[(size_t)a * nv + g] = c < 0 ? (short)-1 : (short)bmap[c]; }
+        }
+        if (X.self_col_enabled)
+            for (int i = 0; i < M.nsurf; ++i) { surf[D.surf_begin[r] + i] = base + M.surf[i]; surf_ord[base + M.surf[i]] = i; }
+        // CSR of the CalcNearby exclusion rows over every slot (empty rows for padding / non-colliding robots)
+        for (int v = 0; v < (M.nvox + 63) / 64 * 64; ++v) {
+            near_off[base + v] = (int)near_idx.size();
+            if (v < M.nvox && X.self_col_enabled)
+                for (int k = M.near_off[v]; k < M.near_off[v + 1]; ++k) near_idx.push_back(base + M.near_idx[k]);
+        }
+        DRobot& R = D.h_robot[r];
+        R.vox_begin = base; R.nvox = M.nvox; R.surf_begin = D.surf_begin[r]; R.nsurf = X.self_col_enabled ? M.nsurf : 0;
+        R.flags = (X.self_col_enabled ? RF_SELF_COL : 0) | (X.grav_enabled ? RF_GRAV : 0) | (X.floor_enabled ? RF_FLOOR : 0) |
+                  (X.temp_enabled ? RF_TEMP : 0) | ((X.sticky_floor && variant_ == 0) ? RF_STICKY : 0) |
+                  ((variant_ == 1 && X.fluid_env) ? RF_FLUID : 0) | (variant_ == 1 ? RF_LW : 0) |
+                  ((X.col_system == 2 || X.col_system == 3) ? RF_HORIZON_COL : 0);
+        R.stop_type = X.stop_type;
+        R.dt = M.dt; R.lat = X.lattice_dim; R.bond_z_half = 0.5 * X.bond_damping_z; R.slow_z = X.slow_damping_z; R.col_z = X.col_damping_z;
+        R.grav_acc = X.grav_acc; R.init_cm_time = X.init_cm_time; R.stop_value = X.stop_value;
+        R.afterlife = variant_ == 0 ? X.afterlife_time : 0.0;
+        R.temp_period_d = X.temp_period; R.min_temp_fact = X.min_temp_fact; R.growth_amplitude = X.growth_amplitude;
+        R.col_horizon = X.collision_horizon;
+        { double fd = X.collision_horizon * 1.5 * X.lattice_dim; R.filter_dist2 = fd * fd; }
+        R.drag_coef = X.aggregate_drag_coef;
+        R.temp_amplitude = (float)X.temp_amplitude; R.temp_period = (float)X.temp_period;
+        DRobotState& S = rstate[r];
+        std::memset(&S, 0, sizeof(S));
+        S.max_disp = (double)FLT_MAX;      // ClearAll, VX_Sim.cpp:369: forces a collision-list build on the first step
+        S.status = M.nvox == 0 ? 3 : 0;
+    }
+    near_off[nv] = (int)near_idx.size();
+
+    DBatch& B = D.B;
+    B.n_robots = nr; B.nv = nv;
+    B.robot = D.upload(D.h_robot);
+    B.rstate = D.upload(rstate);
+    B.wave_robot = D.upload(wave_robot);
+    B.vclass_tab = D.upload(vtab);
+    B.bclass_tab = D.upload(btab);
+    B.vclass = D.upload(vclass);
+    B.bclass = D.upload(bclass);
+    B.nbr = D.upload(nbr);
+    B.phase = D.upload(phase);
+    B.amp_damp = D.upload(amp_damp);
+    B.pos[0][0] = D.upload(px); B.pos[0][1] = D.upload(py); B.pos[0][2] = D.upload(pz);
+    B.pos[1][0] = D.upload(px); B.pos[1][1] = D.upload(py); B.pos[1][2] = D.upload(pz);
+    B.scale[0] = D.upload(sc); B.scale[1] = D.upload(sc);
+    B.quat[0] = D.upload(qw);
+    for (int k = 1; k < 4; ++k) B.quat[k] = D.alloc_zero<double>(nv);
+    for (int k = 0; k < 3; ++k) { B.lin_mom[k] = D.alloc_zero<double>(nv); B.ang_mom[k] = D.alloc_zero<double>(nv); }
+    for (int k = 0; k < 9; ++k) B.hist[k] = D.alloc_zero<double>((size_t)3 * nv);
+    B.small_angle = D.upload(small);
+    for (int k = 0; k < 12; ++k) B.bout[k] = D.alloc_zero<double>((size_t)3 * nv);
+    B.surf = D.upload(surf);
+    B.surf_ord = D.upload(surf_ord);
+    B.near_off = D.upload(near_off);
+    B.near_idx = D.upload(near_idx);
+    B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
+    B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
+    B.small_angle_w = std::cos(VXH_SMALL_ANGLE_RAD * 0.5);                    // Vec3D.h:55-59
+    B.smallish_angle_w = std::cos(VXH_HYST * VXH_SMALL_ANGLE_RAD * 0.5);
+    B.slthresh_acos2sqrt = 1.0 - 0.9988 * 0.9988;
+    prepared_ = true;
+    downloaded_ = false;
+    rounds_done_ = 0;
+    counters_ = vxh_counters{};
+}
+
+void Engine::reset() { if (!robots_.empty()) prepare(); }
+
+static void launch_round(const DBatch& B, hipStream_t s, long long cap)
+{
+    const int nb_b = (3 * B.nv + 255) / 256, nb_v = (B.nv + 255) / 256;
+    hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, s, B, cap, 1);
+    hipLaunchKernelGGL(k_bonds, dim3(nb_b), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_voxels, dim3(nb_v), dim3(256), 0, s, B);
+}
+
+void Engine::advance(long long max_rounds)
+{
+    HIP_OK(hipSetDevice(device_id_));
+    Device& D = *dev_;
+    const DBatch& B = D.B;
+    const long long cap_all = 0x7fffffffffffffffLL;
+    long long todo = std::min(max_rounds, std::max(0LL, D.max_planned - rounds_done_));
+    const long long cap = (max_rounds >= D.max_planned - rounds_done_) ? cap_all : rounds_done_ + max_rounds;
+    HIP_OK(hipEventRecord(D.ev0, D.stream));
+    long long launched = 0;
+    if (graph_steps_ > 1 && cap == cap_all && todo >= graph_steps_) {
+        if (!D.graph_exec || D.graph_rounds != graph_steps_) {
+            if (D.graph_exec) { hipGraphExecDestroy(D.graph_exec); D.graph_exec = nullptr; }
+            if (D.graph) { hipGraphDestroy(D.graph); D.graph = nullptr; }
+            HIP_OK(hipStreamBeginCapture(D.stream, hipStreamCaptureModeThreadLocal));
+            for (int k = 0; k < graph_steps_; ++k) launch_round(B, D.stream, cap_all);
+            HIP_OK(hipStreamEndCapture(D.stream, &D.graph));
+            HIP_OK(hipGraphInstantiate(&D.graph_exec, D.graph, nullptr, nullptr, 0));
+            D.graph_rounds = graph_steps_;
+        }
+        while (todo - launched >= graph_steps_) { HIP_OK(hipGraphLaunch(D.graph_exec, D.stream)); launched += graph_steps_; }
+    }
+    for (; launched < todo; ++launched) launch_round(B, D.stream, cap);
+    hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, cap, 0);   // finish the last step
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(D.ev1, D.stream));
+    HIP_OK(hipStreamSynchronize(D.stream));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, D.ev0, D.ev1));
+    counters_.kernel_seconds += ms * 1e-3;
+    counters_.launches += 3 * todo + 1;
+    rounds_done_ += todo;
+    downloaded_ = false;
+}
+
+void Engine::run()
+{
+    auto t0 = std::chrono::steady_clock::now();
+    if (robots_.empty()) return;
+    if (!prepared_) prepare();
+    advance(0x7fffffffffffffffLL / 4);
+    download();
+    counters_.run_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void Engine::step(long long n)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    if (robots_.empty() || n <= 0) return;
+    if (!prepared_) prepare();
+    advance(n);
+    download();
+    counters_.run_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void Engine::download()
+{
+    HIP_OK(hipSetDevice(device_id_));
+    Device& D = *dev_;
+    const DBatch& B = D.B;
+    const int nr = (int)robots_.size(), nv = B.nv;
+    std::vector<DRobotState> rstate(nr);
+    HIP_OK(hipMemcpy(rstate.data(), B.rstate, sizeof(DRobotState) * nr, hipMemcpyDeviceToHost));
+    std::vector<double> tmp[2][4], q[4], lm[3], am[3];
+    for (int b = 0; b < 2; ++b) {
+        for (int k = 0; k < 3; ++k) { tmp[b][k].resize(nv); HIP_OK(hipMemcpy(tmp[b][k].data(), B.pos[b][k], sizeof(double) * nv, hipMemcpyDeviceToHost)); }
+        tmp[b][3].resize(nv); HIP_OK(hipMemcpy(tmp[b][3].data(), B.scale[b], sizeof(double) * nv, hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < 4; ++k) { q[k].resize(nv); HIP_OK(hipMemcpy(q[k].data(), B.quat[k], sizeof(double) * nv, hipMemcpyDeviceToHost)); }
+    for (int k = 0; k < 3; ++k) {
+        lm[k].resize(nv); HIP_OK(hipMemcpy(lm[k].data(), B.lin_mom[k], sizeof(double) * nv, hipMemcpyDeviceToHost));
+        am[k].resize(nv); HIP_OK(hipMemcpy(am[k].data(), B.ang_mom[k], sizeof(double) * nv, hipMemcpyDeviceToHost));
+    }
+    host_.assign(nr, HostState());
+    double vs = 0, bs = 0, ab = 0; long long mx = 0;
+    for (int r = 0; r < nr; ++r) {
+        const RobotModel& M = robots_[r];
+        HostState& H = host_[r];
+        const DRobotState& S = rstate[r];
+        H.cur_time = S.cur_time; H.steps = S.steps; H.status = S.status; H.cm_init = S.cm_init; H.rebuilds = S.rebuilds;
+        H.eol_post_y = S.eol_post_y;
+        for (int k = 0; k < 3; ++k) H.ini_cm[k] = S.ini_cm[k];
+        if (S.status == 0 && S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
+        else if (S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
+        const int n = M.nvox, base = D.vox_begin[r], b = S.steps & 1;
+        H.pos.resize((size_t)3 * n); H.quat.resize((size_t)4 * n); H.scale.resize(n); H.lin_mom.resize((size_t)3 * n); H.ang_mom.resize((size_t)3 * n);
+        for (int v = 0; v < n; ++v) {
+            for (int k = 0; k < 3; ++k) { H.pos[3 * v + k] = tmp[b][k][base + v]; H.lin_mom[3 * v + k] = lm[k][base + v]; H.ang_mom[3 * v + k] = am[k][base + v]; }
+            for (int k = 0; k < 4; ++k) H.quat[4 * v + k] = q[k][base + v];
+            H.scale[v] = tmp[b][3][base + v];
+        }
+        vs += (double)n * S.steps; bs += (double)M.nbond * S.steps; ab += (224.0 * n + 144.0 * M.nbond) * S.steps;
+        mx = std::max(mx, (long long)S.steps);
+    }
+    counters_.voxel_steps = vs; counters_.bond_steps = bs; counters_.algorithmic_bytes = ab; counters_.max_steps = mx;
+    downloaded_ = true;
+}
+
+void Engine::result(int robot, vxh_result* out)
+{
+    if (!downloaded_) throw std::logic_error("results requested before vxh_run/vxh_step");
+    compute_result(robots_[robot], host_[robot], out);
+}
+
+void Engine::state14(int robot, double* out, int capacity)
+{
+    const RobotModel& M = robots_[robot];
+    if (capacity < M.nvox) throw std::invalid_argument("state buffer too small");
+    if (!prepared_) prepare();
+    if (!downloaded_) download();
+    const HostState& H = host_[robot];
+    for (int v = 0; v < M.nvox; ++v) {
+        const VoxClass& C = M.vox_classes[M.vox_class[v]];
+        double* o = out + (size_t)14 * v;
+        for (int k = 0; k < 3; ++k) o[k] = H.pos[3 * v + k];
+        for (int k = 0; k < 4; ++k) o[3 + k] = H.quat[4 * v + k];
+        o[7] = H.scale[v];
+        for (int k = 0; k < 3; ++k) { o[8 + k] = H.lin_mom[3 * v + k] * C.mass_inv; o[11 + k] = H.ang_mom[3 * v + k] * C.inertia_inv; }
+    }
+}
+
+}  // namespace vxh

@@ -1,0 +1,54 @@
+// Batched engine: owns the robots of one population shard and their SoA state on ONE HIP device.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/vxhip.h"
+#include "model.hpp"
+
+namespace vxh {
+
+struct HostState {                      // final/current state of one robot, downloaded from the device
+    std::vector<double> pos, quat, scale, lin_mom, ang_mom;   // pos [3*n] xyz-interleaved, quat [4*n] wxyz
+    double cur_time = 0, ini_cm[3] = {0, 0, 0}, eol_post_y = 0;
+    int steps = 0, status = 0, cm_init = 0, rebuilds = 0;
+};
+
+class Engine {
+public:
+    Engine(int variant, int device_id);       // throws std::runtime_error when no HIP device is usable
+    ~Engine();
+    int add_vxa(const char* data, size_t len);              // returns robot index; throws
+    int num_robots() const { return (int)robots_.size(); }
+    const RobotModel& robot(int i) const { return robots_[i]; }
+    void run();                                // to completion
+    void step(long long n);                    // at most n more steps per robot
+    void reset();
+    void clear();
+    void result(int robot, vxh_result* out);
+    void state14(int robot, double* out, int capacity);
+    void counters(vxh_counters* out) const { *out = counters_; }
+    void set_option(const std::string& key, double value);
+    int variant() const { return variant_; }
+
+private:
+    struct Device;                             // HIP-side members (engine.hip)
+    void prepare();                            // build + upload the batch
+    void advance(long long max_rounds);        // launch step rounds
+    void download();
+    int variant_, device_id_;
+    std::vector<RobotModel> robots_;
+    std::vector<HostState> host_;
+    std::unique_ptr<Device> dev_;
+    bool prepared_ = false, downloaded_ = false;
+    long long rounds_done_ = 0;
+    int graph_steps_ = 32;                     // step rounds captured per hipGraph launch (0 = plain launches)
+    vxh_counters counters_{};
+};
+
+// results.cpp: the numbers of CVX_SimGA::WriteResultFile from a final state, and the XML text
+void compute_result(const RobotModel& model, const HostState& st, vxh_result* out);
+std::string result_xml(const RobotModel& model, const vxh_result& res);
+
+}  // namespace vxh

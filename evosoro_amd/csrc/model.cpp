@@ -1,0 +1,223 @@
+#include "model.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace vxh {
+
+namespace {
+
+bool same_bits(double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0; }
+
+// CVX_Voxel::SetMaterial (VX_Voxel.cpp:94-128); Vox_E may be an evolved per-voxel value (App. A.8 of SURVEY.md)
+VoxClass make_vox_class(const VxaModel& m, int mat, double size, bool evolved, double evolved_E)
+{
+    const Material& pm = m.palette[mat];
+    VoxClass c;
+    std::memset(&c, 0, sizeof(c));   // classes are interned bytewise: keep padding deterministic
+    c.mat = mat;
+    c.nom_size = size;
+    double volume = size * size * size;
+    c.mass = volume * pm.rho;
+    c.inertia = c.mass * (size * size) / 6;
+    c.first_moment = c.mass * size / 2;
+    c.mat_E = pm.E;
+    c.E = pm.E;
+    c.u_static = pm.u_static;
+    c.u_dynamic = pm.u_dynamic;
+    c.cte = pm.cte;
+    c.mass_inv = 1 / c.mass;
+    c.inertia_inv = 1 / c.inertia;
+    c.c_lin = 2 * std::sqrt(c.mass * c.E * size);
+    c.c_ang = 2 * std::sqrt(c.inertia * c.E * size * size * size);
+    if (evolved) {
+        c.E = evolved_E;
+        if (m.variant == 1) {  // LW SetEMod refreshes the damping terms (LW/VX_Voxel.h:61); _voxcad does not (VX_Voxel.h:61)
+            c.c_lin = 2 * std::sqrt(c.mass * c.E * size);
+            c.c_ang = 2 * std::sqrt(c.inertia * c.E * size * size * size);
+        }
+    }
+    if (m.variant == 1) {  // LW/VX_Object.cpp:1474: float true_Elastic_Mod = (voxelEmod > 0) ? voxelEmod : Elastic_Mod
+        float e = (float)c.E;
+        float t = (e > 0) ? e : (float)c.mat_E;
+        c.stress_E = (double)t;
+    } else {
+        c.stress_E = c.mat_E;
+    }
+    c.k_floor = 2 * c.E * size;
+    return c;
+}
+
+// CVX_Bond::LinkVoxels + UpdateConstants (VX_Bond.cpp:65-173).  E1/E2 are the moduli the voxels carry at
+// bond-creation time: the material's in _voxcad (evolved stiffness is applied later), the evolved one in LW.
+BondClass make_bond_class(const VxaModel& m, const VoxClass& c1, double E1, const VoxClass& c2, double E2)
+{
+    BondClass b;
+    std::memset(&b, 0, sizeof(b));
+    b.homogeneous = (c1.mat == c2.mat);
+    if (m.variant == 1) b.homogeneous = b.homogeneous && (E1 == E2);
+    double u1 = m.palette[c1.mat].nu, u2 = m.palette[c2.mat].nu;
+    double E = (E1 * E2 / (E1 + E2)) * 2;
+    double u = (u1 == 0 && u2 == 0) ? 0 : (u1 * u2 / (u1 + u2)) * 2;
+    double size = (c1.nom_size + c2.nom_size) * 0.5;
+    double Lx = size, Ly = size, Lz = size;
+    b.L = Lx;
+    double G = E / (2 * (1 + u));
+    double A = Ly * Lz;
+    double Iy = Lz * Ly * Ly * Ly / 12;
+    double J = Ly * Lz * (Ly * Ly + Lz * Lz) / 12;
+    b.a1 = E * A / Lx;
+    b.a2 = G * J / Lx;
+    b.b1 = 12 * E * Iy / (Lx * Lx * Lx);   // b1y == b1z, b2y == b2z, b3y == b3z for cubic voxels
+    b.b2 = 6 * E * Iy / (Lx * Lx);
+    b.b3 = 2 * E * Iy / Lx;
+    b.sq_a1m1 = 2.0 * std::sqrt(b.a1 * c1.mass);          b.sq_a1m2 = 2.0 * std::sqrt(b.a1 * c2.mass);
+    b.sq_a2i1 = 2.0 * std::sqrt(b.a2 * c1.inertia);       b.sq_a2i2 = 2.0 * std::sqrt(b.a2 * c2.inertia);
+    b.sq_b1m1 = 2.0 * std::sqrt(b.b1 * c1.mass);          b.sq_b1m2 = 2.0 * std::sqrt(b.b1 * c2.mass);
+    b.sq_b2fm1 = 2.0 * std::sqrt(b.b2 * c1.first_moment); b.sq_b2fm2 = 2.0 * std::sqrt(b.b2 * c2.first_moment);
+    b.sq_b3i1 = 2.0 * std::sqrt(b.b3 * c1.inertia);       b.sq_b3i2 = 2.0 * std::sqrt(b.b3 * c2.inertia);
+    b.stress_E1 = c1.stress_E;
+    b.stress_E2 = c2.stress_E;
+    b.area_sum = Ly * Lz + Ly * Lz;   // CSArea1 + CSArea2 (VXS_Bond.cpp:75, VXS_Voxel.cpp:625-631)
+    return b;
+}
+
+template <class T>
+int intern(std::vector<T>& table, const T& value)
+{
+    for (size_t i = 0; i < table.size(); ++i)
+        if (std::memcmp(&table[i], &value, sizeof(T)) == 0) return (int)i;
+    table.push_back(value);
+    return (int)table.size() - 1;
+}
+
+bool stop_met(const VxaModel& m, double t, long long steps)
+{
+    if (m.variant == 0 && t <= m.init_cm_time) return false;           // VX_Sim.cpp:1402
+    switch (m.stop_type) {
+    case 1: return steps > (long long)(int)(m.stop_value + 0.5);
+    case 2: return m.variant == 0 ? t > (m.stop_value + m.afterlife_time) : t > m.stop_value;
+    case 3: return t > m.temp_period * m.stop_value;
+    default: return false;
+    }
+}
+
+}  // namespace
+
+long long plan_steps(const VxaModel& m, double dt)
+{
+    if (m.stop_type == 0) throw std::runtime_error("StopConditionType 0 (none) never terminates");
+    if (!(dt > 0)) throw std::runtime_error("non-positive time step");
+    double t = 0;
+    long long steps = 0;
+    const long long cap = 2000000000LL;
+    while (!stop_met(m, t, steps)) {
+        t += dt;
+        if (++steps > cap) throw std::runtime_error("stop condition needs more than 2e9 steps");
+    }
+    return steps;
+}
+
+RobotModel build_robot(const VxaModel& vxa)
+{
+    RobotModel r;
+    r.vxa = vxa;
+    const VxaModel& m = r.vxa;
+    const int nx = m.nx, ny = m.ny, nz = m.nz;
+    const size_t ncell = (size_t)nx * ny * nz;
+    std::vector<int> x2s(ncell, -1);
+    for (size_t i = 0; i < ncell; ++i)
+        if (m.structure[i]) { x2s[i] = r.nvox++; r.struct_index.push_back((int)i); }
+    if (r.nvox == 0) return r;
+    if (m.has_phase_offset && (int)m.phase_offset.size() < r.nvox) throw std::runtime_error("<PhaseOffset> has fewer values than voxels");
+    if (m.has_stiffness && (int)m.stiffness.size() < r.nvox) throw std::runtime_error("<Stiffness> has fewer values than voxels");
+    if (m.has_temp_amp_damp && (int)m.temp_amp_damp.size() < r.nvox) throw std::runtime_error("<TempAmpDamp> has fewer values than voxels");
+
+    const double size = m.lattice_dim * 1.0;   // GetLatDimEnv().x with X_Dim_Adj == 1 (VX_Object.h:377, VX_Sim.cpp:528)
+    r.nbr.assign((size_t)r.nvox * 6, -1);
+    r.vox_class.resize(r.nvox);
+    r.nom_pos.resize((size_t)r.nvox * 3);
+    r.phase_offset.assign(r.nvox, 0.0f);
+    r.temp_amp_damp.assign(r.nvox, 1.0f);
+    r.bond_class.assign((size_t)r.nvox * 3, -1);
+    std::vector<double> link_E(r.nvox);     // Vox_E at LinkVoxels time
+    for (int v = 0; v < r.nvox; ++v) {
+        int i = r.struct_index[v];
+        int iz = i / (nx * ny), iy = (i - iz * nx * ny) / nx, ix = i - iz * nx * ny - iy * nx;
+        int mat = m.structure[i];
+        const Material& pm = m.palette[mat];
+        if (!(pm.rho > 0) || !(pm.E > 0)) throw std::runtime_error("material with non-positive density or modulus");
+        bool evolved = m.has_stiffness;
+        VoxClass c = make_vox_class(m, mat, size, evolved, evolved ? m.stiffness[v] : 0.0);
+        r.vox_class[v] = intern(r.vox_classes, c);
+        link_E[v] = (m.variant == 1 && evolved) ? m.stiffness[v] : pm.E;
+        r.nom_pos[3 * v + 0] = size * (ix + 0.5);
+        r.nom_pos[3 * v + 1] = size * (iy + 0.5);
+        r.nom_pos[3 * v + 2] = size * (iz + 0.5);
+        if (m.has_phase_offset) r.phase_offset[v] = (float)m.phase_offset[v];
+        if (m.has_temp_amp_damp) r.temp_amp_damp[v] = (float)m.temp_amp_damp[v];
+        const int step[3] = {1, nx, nx * ny};
+        const int coord[3] = {ix, iy, iz}, lim[3] = {nx, ny, nz};
+        for (int a = 0; a < 3; ++a) {
+            if (coord[a] + 1 < lim[a] && m.structure[i + step[a]]) r.nbr[(size_t)v * 6 + 2 * a] = x2s[i + step[a]];
+            if (coord[a] - 1 >= 0 && m.structure[i - step[a]]) r.nbr[(size_t)v * 6 + 2 * a + 1] = x2s[i - step[a]];
+        }
+    }
+    // permanent bonds in reference order: for each voxel +X, +Y, +Z (VX_Sim.cpp:623-641); CalcMaxDt alongside
+    double max_freq2 = 0;
+    for (int v = 0; v < r.nvox; ++v)
+        for (int a = 0; a < 3; ++a) {
+            int o = r.nbr[(size_t)v * 6 + 2 * a];
+            if (o < 0) continue;
+            const VoxClass& c1 = r.vox_classes[r.vox_class[v]];
+            const VoxClass& c2 = r.vox_classes[r.vox_class[o]];
+            BondClass b = make_bond_class(m, c1, link_E[v], c2, link_E[o]);
+            r.bond_class[(size_t)v * 3 + a] = intern(r.bond_classes, b);
+            r.nbond++;
+            if (b.a1 / c1.mass > max_freq2) max_freq2 = b.a1 / c1.mass;
+            if (b.a1 / c2.mass > max_freq2) max_freq2 = b.a1 / c2.mass;
+        }
+    if (r.nbond == 0)
+        for (int v = 0; v < r.nvox; ++v) {
+            const VoxClass& c = r.vox_classes[r.vox_class[v]];
+            if (c.E / c.mass > max_freq2) max_freq2 = c.E / c.mass;
+        }
+    r.opt_dt = 1.0 / (std::sqrt(max_freq2) * 2 * (double)3.1415926);   // VX_Sim.cpp:1724-1725
+    r.dt = m.dt_frac * r.opt_dt;
+    r.planned_steps = plan_steps(m, r.dt);
+
+    // surface voxels + CalcNearby exclusion lists (VX_Sim.cpp:649-659)
+    const int hops = (int)(m.collision_horizon * 1.5);
+    std::vector<int> scratch;
+    std::vector<unsigned char> mark(r.nvox, 0);
+    r.near_off.assign(r.nvox + 1, 0);
+    for (int v = 0; v < r.nvox; ++v) {
+        bool surface = false;
+        for (int d = 0; d < 6; ++d) if (r.nbr[(size_t)v * 6 + d] < 0) surface = true;
+        if (surface) r.surf.push_back(v);
+        if (m.self_col_enabled && surface) {   // only surface voxels are ever tested (VX_Sim.cpp:2369-2387)
+            scratch.clear();
+            scratch.push_back(v); mark[v] = 1;
+            size_t start = 0, stop = 1;
+            for (int h = 0; h < hops; ++h) {
+                for (size_t j = start; j < stop; ++j)
+                    for (int d = 0; d < 6; ++d) {
+                        int o = r.nbr[(size_t)scratch[j] * 6 + d];
+                        if (o >= 0 && !mark[o]) { mark[o] = 1; scratch.push_back(o); }
+                    }
+                start = stop; stop = scratch.size();
+            }
+            for (int s : scratch) mark[s] = 0;
+            std::sort(scratch.begin(), scratch.end());
+            r.near_idx.insert(r.near_idx.end(), scratch.begin(), scratch.end());
+        }
+        r.near_off[v + 1] = (int)r.near_idx.size();
+    }
+    r.nsurf = (int)r.surf.size();
+    (void)same_bits;
+    return r;
+}
+
+}  // namespace vxh

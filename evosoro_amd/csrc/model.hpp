@@ -1,0 +1,61 @@
+// Host-side model builder: VxaModel -> voxel/bond tables in the reference's ordering.
+// Reference: CVX_Sim::Import / CreatePermBond / ResetSimulation / CalcMaxDt
+// (evosoro/_voxcad/Voxelyze/VX_Sim.cpp:488-751,839-1007,1693-1727), CVX_Voxel::SetMaterial / CalcNearby
+// (VX_Voxel.cpp:94-128,171-209), CVX_Bond::LinkVoxels / UpdateConstants (VX_Bond.cpp:65-173).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "vxa_reader.hpp"
+
+namespace vxh {
+
+// constants shared by every voxel of one (material, nominal size[, evolved stiffness]) combination
+struct VoxClass {
+    double mass, mass_inv, inertia, inertia_inv, first_moment;
+    double c_lin;      // _2xSqMxExS
+    double c_ang;      // _2xSqIxExSxSxS
+    double E;          // Vox_E (floor stiffness, collision bonds)
+    double mat_E;      // Elastic_Mod of the material model (axial stress)
+    double stress_E;   // modulus actually multiplied with strain (land: mat_E; land_water: (float)Vox_E)
+    double k_floor;    // 2*Vox_E*NominalSize
+    double u_static, u_dynamic, cte, nom_size;
+    int mat;
+};
+
+// constants of one internal bond, shared by every bond between the same two voxel classes
+struct BondClass {
+    double L, a1, a2, b1, b2, b3;
+    double sq_a1m1, sq_a1m2, sq_a2i1, sq_a2i2, sq_b1m1, sq_b1m2, sq_b2fm1, sq_b2fm2, sq_b3i1, sq_b3i2;
+    double stress_E1, stress_E2, area_sum;
+    int homogeneous;
+};
+
+struct RobotModel {
+    VxaModel vxa;
+    int nvox = 0, nbond = 0, nsurf = 0;
+    // per voxel (simulation index order = ascending structure index of occupied cells)
+    std::vector<int> struct_index;          // StoXIndexMap
+    std::vector<int> nbr;                   // [nvox*6] voxel index in direction PX,NX,PY,NY,PZ,NZ or -1
+    std::vector<int> vox_class;             // index into `vox_classes`
+    std::vector<double> nom_pos;            // [nvox*3]
+    std::vector<float> phase_offset, temp_amp_damp;
+    // per bond slot (voxel v, axis a) -> slot 3*v+a ; -1 class = no bond
+    std::vector<int> bond_class;            // [nvox*3]
+    // collisions
+    std::vector<int> surf;                  // surface voxels, ascending
+    std::vector<int> near_off, near_idx;    // CSR over ALL voxels: sorted voxel indices within N hops (self included)
+    // local class tables (merged batch-wide by the engine)
+    std::vector<VoxClass> vox_classes;
+    std::vector<BondClass> bond_classes;
+    double opt_dt = 0, dt = 0;
+    long long planned_steps = 0;            // TimeStep() calls the reference main loop would make
+};
+
+RobotModel build_robot(const VxaModel& vxa);   // throws std::runtime_error
+
+// number of TimeStep calls until StopConditionMet, replaying CurTime += dt in double precision
+long long plan_steps(const VxaModel& vxa, double dt);
+
+}  // namespace vxh

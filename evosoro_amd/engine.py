@@ -1,0 +1,202 @@
+"""ctypes binding of the C ABI in include/vxhip.h (libvxhip.so, built in-tree by evosoro_amd/csrc/Makefile).
+
+There is no fallback: if the shared library is missing or no HIP device is usable this module raises —
+the product path never routes through a CPU implementation.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvxhip.so")
+CLI_PATH = os.path.join(_HERE, "voxelyze")
+
+VOXCAD, VOXCAD_LAND_WATER = 0, 1
+ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
+
+EXPORTS = ["vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_num_robots", "vxh_robot_dims",
+           "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
+           "vxh_fitness_file_name", "vxh_get_state", "vxh_get_counters", "vxh_set_option", "vxh_strerror",
+           "vxh_last_error", "vxh_version"]
+
+
+class VxhResult(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int), ("steps", ctypes.c_int), ("nvox", ctypes.c_int), ("nbond", ctypes.c_int),
+                ("dt", ctypes.c_double), ("cur_time", ctypes.c_double), ("lifetime", ctypes.c_double),
+                ("ini_cm", ctypes.c_double * 3), ("cur_cm", ctypes.c_double * 3),
+                ("norm_final_dist", ctypes.c_double), ("norm_regime_dist", ctypes.c_double),
+                ("norm_frozen_dist", ctypes.c_double), ("final_dist", ctypes.c_double),
+                ("final_dist_y", ctypes.c_double), ("anterior_dist", ctypes.c_double),
+                ("posterior_dist", ctypes.c_double), ("anterior_y", ctypes.c_double),
+                ("posterior_y", ctypes.c_double), ("end_of_life_posterior_y", ctypes.c_double),
+                ("fall_adj_post_y", ctypes.c_double), ("num_non_feet_touching_floor", ctypes.c_double),
+                ("num_touching_floor", ctypes.c_double), ("norm_abs_disp", ctypes.c_double),
+                ("norm_dist_x", ctypes.c_double), ("norm_dist_y", ctypes.c_double), ("norm_dist_z", ctypes.c_double),
+                ("col_rebuilds", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+    def as_dict(self):
+        out = {}
+        for name, ctype in self._fields_:
+            val = getattr(self, name)
+            out[name] = list(val) if hasattr(val, "__len__") else val
+        return out
+
+
+class VxhCounters(ctypes.Structure):
+    _fields_ = [("voxel_steps", ctypes.c_double), ("bond_steps", ctypes.c_double),
+                ("algorithmic_bytes", ctypes.c_double), ("kernel_seconds", ctypes.c_double),
+                ("run_seconds", ctypes.c_double), ("launches", ctypes.c_longlong), ("max_steps", ctypes.c_longlong)]
+
+
+class VxhError(RuntimeError):
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, "libvxhip status %d: %s" % (status, message))
+        self.status = status
+
+
+def build(force=False):
+    """Compile libvxhip.so + voxelyze with hipcc for gfx950 (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
+    newest = max(newest, os.path.getmtime(os.path.join(_HERE, "..", "include", "vxhip.h")))
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(CLI_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libvxhip.so and declare the prototypes; raises OSError if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libvxhip.so not found at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I, D, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_longlong
+    lib.vxh_create.argtypes = [ctypes.POINTER(P), I, I]
+    lib.vxh_destroy.argtypes = [P]
+    lib.vxh_destroy.restype = None
+    lib.vxh_add_vxa_file.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(I)]
+    lib.vxh_add_vxa_buffer.argtypes = [P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(I)]
+    lib.vxh_num_robots.argtypes = [P]
+    lib.vxh_robot_dims.argtypes = [P, I, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(D), ctypes.POINTER(LL)]
+    lib.vxh_run.argtypes = [P]
+    lib.vxh_step.argtypes = [P, LL]
+    lib.vxh_reset.argtypes = [P]
+    lib.vxh_clear.argtypes = [P]
+    lib.vxh_get_result.argtypes = [P, I, ctypes.POINTER(VxhResult)]
+    lib.vxh_write_result_xml.argtypes = [P, I, ctypes.c_char_p]
+    lib.vxh_fitness_file_name.argtypes = [P, I, ctypes.c_char_p, ctypes.c_size_t]
+    lib.vxh_get_state.argtypes = [P, I, P, I]
+    lib.vxh_get_counters.argtypes = [P, ctypes.POINTER(VxhCounters)]
+    lib.vxh_set_option.argtypes = [P, ctypes.c_char_p, D]
+    lib.vxh_strerror.argtypes = [I]
+    lib.vxh_strerror.restype = ctypes.c_char_p
+    lib.vxh_last_error.argtypes = [P]
+    lib.vxh_last_error.restype = ctypes.c_char_p
+    lib.vxh_version.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+class Engine(object):
+    """One population shard on one GPU: add .vxa robots, run them all at once, read results."""
+
+    def __init__(self, variant=VOXCAD, device=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.vxh_create(ctypes.byref(self._h), variant, device)
+        if rc != 0:
+            self._h = ctypes.c_void_p()
+            raise VxhError(rc, self._lib.vxh_strerror(rc).decode())
+        self.variant = variant
+
+    def _check(self, rc):
+        if rc != 0:
+            raise VxhError(rc, "%s (%s)" % (self._lib.vxh_strerror(rc).decode(),
+                                            self._lib.vxh_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.vxh_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def add_vxa_file(self, path):
+        idx = ctypes.c_int(-1)
+        self._check(self._lib.vxh_add_vxa_file(self._h, os.fsencode(path), ctypes.byref(idx)))
+        return idx.value
+
+    def add_vxa_text(self, text):
+        raw = text.encode("latin-1") if isinstance(text, str) else text
+        idx = ctypes.c_int(-1)
+        self._check(self._lib.vxh_add_vxa_buffer(self._h, raw, len(raw), ctypes.byref(idx)))
+        return idx.value
+
+    def num_robots(self):
+        return self._lib.vxh_num_robots(self._h)
+
+    def dims(self, robot):
+        nvox, nbond, dt, steps = ctypes.c_int(), ctypes.c_int(), ctypes.c_double(), ctypes.c_longlong()
+        self._check(self._lib.vxh_robot_dims(self._h, robot, ctypes.byref(nvox), ctypes.byref(nbond),
+                                             ctypes.byref(dt), ctypes.byref(steps)))
+        return {"nvox": nvox.value, "nbond": nbond.value, "dt": dt.value, "planned_steps": steps.value}
+
+    def run(self):
+        self._check(self._lib.vxh_run(self._h))
+
+    def step(self, n):
+        self._check(self._lib.vxh_step(self._h, n))
+
+    def reset(self):
+        self._check(self._lib.vxh_reset(self._h))
+
+    def clear(self):
+        self._check(self._lib.vxh_clear(self._h))
+
+    def result(self, robot):
+        out = VxhResult()
+        self._check(self._lib.vxh_get_result(self._h, robot, ctypes.byref(out)))
+        return out
+
+    def write_result_xml(self, robot, path=None):
+        self._check(self._lib.vxh_write_result_xml(self._h, robot, None if path is None else os.fsencode(path)))
+
+    def fitness_file_name(self, robot):
+        buf = ctypes.create_string_buffer(4096)
+        self._check(self._lib.vxh_fitness_file_name(self._h, robot, buf, len(buf)))
+        return buf.value.decode()
+
+    def state(self, robot):
+        n = self.dims(robot)["nvox"]
+        out = np.zeros((n, 14), dtype=np.float64)
+        self._check(self._lib.vxh_get_state(self._h, robot, out.ctypes.data, n))
+        return out
+
+    def counters(self):
+        out = VxhCounters()
+        self._check(self._lib.vxh_get_counters(self._h, ctypes.byref(out)))
+        return out
+
+    def set_option(self, key, value):
+        self._check(self._lib.vxh_set_option(self._h, key.encode(), float(value)))
+
+    def version(self):
+        return self._lib.vxh_version().decode()

@@ -1,0 +1,108 @@
+/* libvxhip — C ABI of the MI355X-native batched Voxelyze time-stepper.
+ *
+ * This is the drop-in boundary for evosoro's "one `voxelyze -f file.vxa` process per robot" path.  Each
+ * entry point names the reference interface it replaces (paths relative to the reference repository,
+ * VX/ = evosoro/_voxcad/Voxelyze/, LW/ = evosoro/_voxcad_land_water/Voxelyze/):
+ *
+ *   vxh_add_vxa_file / _buffer  CVX_Sim::LoadVXAFile + ReadVXA            VX/VX_Sim.cpp:159-203
+ *                               (voxelyzeMain/main.cpp:55, `-f <file>` argument :33-36)
+ *   vxh_run                     Import + the `while(!StopConditionMet()) TimeStep()` loop
+ *                               voxelyzeMain/main.cpp:62-111; VX/VX_Sim.cpp:488-717,1054-1156,1763-1933
+ *                               for EVERY queued robot at once (replaces the N concurrent processes of
+ *                               evosoro/tools/evaluation.py:89-90)
+ *   vxh_get_result              the values CVX_SimGA::WriteResultFile prints  VX/VX_SimGA.cpp:33-168,
+ *                               LW/VX_SimGA.cpp:33-77
+ *   vxh_write_result_xml        CVX_SimGA::SaveResultFile(FitnessFileName)    VX/VX_SimGA.cpp:25-30,
+ *                               voxelyzeMain/main.cpp:130 (same tags, 6 significant digits)
+ *   vxh_get_state               CVXS_Voxel::GetCurPos/GetCurAngle/GetCurScale/GetCurVel (trajectory parity)
+ *   vxh_step                    CVX_Sim::TimeStep called n times (parity tests on early steps)
+ *
+ * Conventions: plain C types only; every function returns 0 (VXH_OK) or a negative vxh_status; the caller
+ * owns every buffer it passes; a handle is not thread-safe (use one per thread / per GPU process).
+ * There is NO CPU fallback: vxh_create fails with VXH_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef VXHIP_H
+#define VXHIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vxh_engine vxh_engine;
+
+enum vxh_status {
+    VXH_OK = 0,
+    VXH_ERR_ARG = -1,        /* bad argument / index out of range */
+    VXH_ERR_NO_DEVICE = -2,  /* no usable HIP device (the engine has no CPU path) */
+    VXH_ERR_PARSE = -3,      /* malformed .vxa */
+    VXH_ERR_IO = -4,         /* cannot read/write a file */
+    VXH_ERR_HIP = -5,        /* a HIP runtime call failed, see vxh_last_error */
+    VXH_ERR_STATE = -6,      /* call order (e.g. results before vxh_run) */
+    VXH_ERR_UNSUPPORTED = -7 /* .vxa uses a feature outside the supported scope */
+};
+
+enum vxh_variant { VXH_VOXCAD = 0, VXH_VOXCAD_LAND_WATER = 1 };
+
+/* per-robot outcome; the reference has no such codes: a diverged or empty robot makes its process spin
+ * forever and evosoro times it out (evaluation.py:107-119). */
+enum vxh_robot_status { VXH_ROBOT_PENDING = 0, VXH_ROBOT_FINISHED = 1, VXH_ROBOT_DIVERGED = 2, VXH_ROBOT_EMPTY = 3,
+                        VXH_ROBOT_COL_OVERFLOW = 4 };
+
+typedef struct vxh_result {
+    int status;            /* vxh_robot_status */
+    int steps;             /* CurStepCount */
+    int nvox, nbond;
+    double dt;             /* DtFrac*OptimalDt */
+    double cur_time;       /* CurTime */
+    double lifetime;       /* <Lifetime> */
+    double ini_cm[3];      /* IniCM */
+    double cur_cm[3];      /* SS.CurCM after the last step */
+    /* _voxcad tags, VX/VX_SimGA.cpp:145-168 */
+    double norm_final_dist, norm_regime_dist, norm_frozen_dist, final_dist, final_dist_y;
+    double anterior_dist, posterior_dist, anterior_y, posterior_y, end_of_life_posterior_y, fall_adj_post_y;
+    double num_non_feet_touching_floor, num_touching_floor;
+    /* _voxcad_land_water tags, LW/VX_SimGA.cpp:58-62 */
+    double norm_abs_disp, norm_dist_x, norm_dist_y, norm_dist_z;
+    int col_rebuilds;      /* diagnostic: how often CalcL1Bonds ran (VX/VX_Sim.cpp:1741-1747) */
+    int reserved;
+} vxh_result;
+
+typedef struct vxh_counters {
+    double voxel_steps;        /* sum over robots of nvox * steps taken in vxh_run/vxh_step so far */
+    double bond_steps;         /* sum of nbond * steps */
+    double algorithmic_bytes;  /* sum of (224*nvox + 144*nbond) * steps, SURVEY.md section 8(d) */
+    double kernel_seconds;     /* HIP-event time of the stepping region on the engine's stream */
+    double run_seconds;        /* host wall time of vxh_run incl. upload/download */
+    long long launches;        /* step-kernel launches */
+    long long max_steps;       /* largest per-robot step count */
+} vxh_counters;
+
+int  vxh_create(vxh_engine** out, int variant, int device_id);
+void vxh_destroy(vxh_engine* e);
+
+int  vxh_add_vxa_file(vxh_engine* e, const char* path, int* robot_index_out);
+int  vxh_add_vxa_buffer(vxh_engine* e, const char* xml, size_t len, int* robot_index_out);
+int  vxh_num_robots(const vxh_engine* e);
+int  vxh_robot_dims(const vxh_engine* e, int robot, int* nvox, int* nbond, double* dt, long long* planned_steps);
+
+int  vxh_run(vxh_engine* e);                         /* every robot to its own stop condition */
+int  vxh_step(vxh_engine* e, long long nsteps);      /* at most nsteps more TimeStep()s per robot */
+int  vxh_reset(vxh_engine* e);                       /* back to the imported state (ResetSimulation) */
+int  vxh_clear(vxh_engine* e);                       /* drop all robots */
+
+int  vxh_get_result(const vxh_engine* e, int robot, vxh_result* out);
+int  vxh_write_result_xml(const vxh_engine* e, int robot, const char* path_or_null);
+int  vxh_fitness_file_name(const vxh_engine* e, int robot, char* buf, size_t cap);
+/* per voxel 14 doubles: pos3, quat(w,x,y,z), scale, vel3, angvel3; capacity in voxels */
+int  vxh_get_state(const vxh_engine* e, int robot, double* out14n, int capacity);
+int  vxh_get_counters(const vxh_engine* e, vxh_counters* out);
+int  vxh_set_option(vxh_engine* e, const char* key, double value);
+
+const char* vxh_strerror(int status);
+const char* vxh_last_error(const vxh_engine* e);
+const char* vxh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

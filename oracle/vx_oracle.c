@@ -138,7 +138,7 @@ struct vxo_sim {
     int nvox, nbond, nsurf, ncol, capcol;
     voxel* vox; ibond* bond; int* surf; cbond* col;
     double lat, opt_dt, dt, cur_time; int steps, status, cm_init;
-    double max_disp_since_update; int col_enable_changed;
+    double max_disp_since_update; int col_enable_changed, rebuilds;
     double max_vox_vel; v3 cur_cm, ini_cm; double end_of_life_posterior_y;
 };
 
@@ -350,6 +350,7 @@ static void vox_link_col(voxel* v, int ci)
 static void calc_l1_bonds(vxo_sim* s, double Dist)
 {
     double FilterDist = Dist * 1.5 * s->lat, FilterDist2 = FilterDist * FilterDist;
+    s->rebuilds++;
     for (int i = 0; i < s->nvox; i++) s->vox[i].ncol = 0;                           /* DeleteCollisionBonds :462-471 */
     s->ncol = 0;
     for (int i = 0; i < s->nsurf; i++) {
@@ -713,7 +714,7 @@ void vxo_get_info(const vxo_sim* s, vxo_info* o)
 {
     memset(o, 0, sizeof(*o));
     o->nvox = s->nvox; o->nbond = s->nbond; o->nsurf = s->nsurf; o->ncol = s->ncol; o->steps = s->steps; o->status = s->status;
-    o->cm_initialized = s->cm_init;
+    o->cm_initialized = s->cm_init; o->col_rebuilds = s->rebuilds;
     for (int i = 0; i < s->nbond; i++) o->n_small_angle += s->bond[i].small_angle;
     o->opt_dt = s->opt_dt; o->dt = s->dt; o->cur_time = s->cur_time; o->max_vox_vel = s->max_vox_vel;
     o->cur_cm[0] = s->cur_cm.x; o->cur_cm[1] = s->cur_cm.y; o->cur_cm[2] = s->cur_cm.z;

@@ -50,7 +50,7 @@ typedef struct vxo_model {
 
 typedef struct vxo_info {
     int nvox, nbond, nsurf, ncol, steps, status; /* status 0 running, 1 finished, 2 diverged, 3 empty */
-    int cm_initialized, n_small_angle;
+    int cm_initialized, n_small_angle, col_rebuilds, reserved;
     double opt_dt, dt, cur_time, max_vox_vel;
     double cur_cm[3], ini_cm[3];
 } vxo_info;

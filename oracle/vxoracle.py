@@ -46,7 +46,7 @@ class VxoModel(ctypes.Structure):
 class VxoInfo(ctypes.Structure):
     _fields_ = [("nvox", ctypes.c_int), ("nbond", ctypes.c_int), ("nsurf", ctypes.c_int), ("ncol", ctypes.c_int),
                 ("steps", ctypes.c_int), ("status", ctypes.c_int), ("cm_initialized", ctypes.c_int),
-                ("n_small_angle", ctypes.c_int), ("opt_dt", ctypes.c_double), ("dt", ctypes.c_double),
+                ("n_small_angle", ctypes.c_int), ("col_rebuilds", ctypes.c_int), ("reserved", ctypes.c_int), ("opt_dt", ctypes.c_double), ("dt", ctypes.c_double),
                 ("cur_time", ctypes.c_double), ("max_vox_vel", ctypes.c_double),
                 ("cur_cm", ctypes.c_double * 3), ("ini_cm", ctypes.c_double * 3)]
 

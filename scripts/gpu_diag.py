@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Developer diagnostic (GPU box): per-step error of the HIP engine against the CPU oracle on the golden robots,
+then a timing of a synthetic batch.  Not part of the product or of the test-suite."""
+import os
+import sys
+import time
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from evosoro_amd import engine, workloads  # noqa: E402
+from evosoro_amd.base import Sim, Env  # noqa: E402
+from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file  # noqa: E402
+from oracle import vxoracle as vo  # noqa: E402
+
+CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4"]
+G = os.path.join(REPO, "tests", "golden")
+
+
+def errors():
+    with engine.Engine(engine.VOXCAD, 0) as eng:
+        for n in CASES:
+            eng.add_vxa_file(os.path.join(G, "vxa", n + ".vxa"))
+        sims = [vo.OracleSim.from_vxa(os.path.join(G, "vxa", n + ".vxa")) for n in CASES]
+        done = 0
+        for upto in (1, 2, 5, 10, 50, 200, 1000):
+            eng.step(upto - done)
+            done = upto
+            for i, (n, sim) in enumerate(zip(CASES, sims)):
+                sim.step(upto - sim.info().steps)
+                w, g = sim.state(), eng.state(i)
+                lat = sim.model["lattice_dim"]
+                print("step %5d %-12s pos %.3e vox  quat %.3e  scale %.3e  vel %.3e" % (
+                    upto, n, np.abs(g[:, :3] - w[:, :3]).max() / lat, np.abs(g[:, 3:7] - w[:, 3:7]).max(),
+                    np.abs(g[:, 7] - w[:, 7]).max() / lat, np.abs(g[:, 8:11] - w[:, 8:11]).max()))
+        eng.run()
+        for i, n in enumerate(CASES):
+            tr = vo.read_trace(os.path.join(G, "expected", n + ".final.bin"))
+            x = vo.read_result_xml(os.path.join(G, "expected", n + ".xml"))
+            r = eng.result(i)
+            lat = sims[i].model["lattice_dim"]
+            print("final %-12s status %d steps %d/%d  dCoM %.3e vox  NormFinalDist %.6g (ref %.6g) finalDistY %.6g (ref %.6g)" % (
+                n, r.status, r.steps, tr["total_steps"], np.abs(np.array(r.cur_cm) - tr["cur_cm"]).max() / lat,
+                r.norm_final_dist, x["NormFinalDist"], r.final_dist_y, x["finalDistY"]))
+
+
+def timing(count, shape, sim_time, selfcol=True, graph_steps=32):
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    sim = Sim(self_collisions_enabled=selfcol, dt_frac=0.9, simulation_time=sim_time, fitness_eval_init_time=min(0.1, sim_time / 5))
+    env = Env()
+    with engine.Engine(engine.VOXCAD, 0) as eng:
+        eng.set_option("graph_steps", graph_steps)
+        for ind in workloads.population(count, shape):
+            write_voxelyze_file(sim, env, ind, tmp, "t")
+            eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "t--id_%05i.vxa" % ind.id))
+        t0 = time.time()
+        eng.run()
+        wall = time.time() - t0
+        c = eng.counters()
+        st = [eng.result(i).status for i in range(count)]
+        print("batch %d x %s sim %.3fs col=%d graph=%d: voxel_steps %.3e max_steps %d kernel %.3fs wall %.3fs -> %.3e vox-steps/s (kernel), alg GB/s %.1f, statuses %s" % (
+            count, shape, sim_time, selfcol, graph_steps, c.voxel_steps, c.max_steps, c.kernel_seconds, wall,
+            c.voxel_steps / c.kernel_seconds, c.algorithmic_bytes / c.kernel_seconds / 1e9, sorted(set(st))))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["errors", "timing"]
+    if "errors" in what:
+        errors()
+    if "timing" in what:
+        timing(64, (6, 6, 6), 0.05)
+        timing(64, (10, 10, 10), 0.02)
+        timing(512, (10, 10, 10), 0.01)
+        timing(512, (10, 10, 10), 0.01, graph_steps=0)
+
+
+def bisect(name, nocol):
+    text = open(os.path.join(G, "vxa", name + ".vxa")).read()
+    if nocol:
+        text = text.replace("<SelfColEnabled>1</SelfColEnabled>", "<SelfColEnabled>0</SelfColEnabled>")
+    sim = vo.OracleSim(vo.parse_vxa(text))
+    with engine.Engine(engine.VOXCAD, 0) as eng:
+        eng.add_vxa_text(text)
+        for upto in list(range(1, 60)) + [80, 100, 150, 200]:
+            eng.step(upto - sim.info().steps)
+            sim.step(upto - sim.info().steps)
+            w, g = sim.state(), eng.state(0)
+            lat = sim.model["lattice_dim"]
+            i = sim.info()
+            e = np.abs(g[:, :3] - w[:, :3]).max(axis=1) / lat
+            print("%s nocol=%d step %4d pos %.3e vox (voxel %d) ncol_oracle %d rebuilds oracle %d" % (
+                name, nocol, upto, e.max(), int(e.argmax()), i.ncol, i.col_rebuilds))
+        eng.run()
+        print("gpu rebuilds", eng.result(0).col_rebuilds)
+
+
+if __name__ == "__main__" and "bisect" in sys.argv[1:]:
+    bisect("phase4", False)
+    bisect("phase4", True)
+
+
+if __name__ == "__main__" and "prof" in sys.argv[1:]:
+    timing(512, (10, 10, 10), 0.01)
