@@ -20,7 +20,8 @@ enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_ST
                   RF_HORIZON_COL = 128 };
 
 struct DRobot {               // constant per robot
-    int vox_begin, nvox, surf_begin, nsurf, flags, stop_type;
+    int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr, pad0;
+    long long excl_begin;     // first word of this robot's exclusion rows in DBatch::excl
     double dt, lat, bond_z_half, slow_z, col_z, grav_acc;
     double init_cm_time, stop_value, afterlife, temp_period_d;
     double min_temp_fact, growth_amplitude, col_horizon, filter_dist2, drag_coef;
@@ -32,7 +33,7 @@ struct DRobotState {          // mutable per robot
     double ini_cm[3];
     double eol_post_y;
     unsigned long long maxvel2_bits;
-    int steps, status, cm_init, active, diverged, col_overflow, ncol_links, rebuilds;
+    int steps, status, cm_init, active, diverged, col_overflow, rebuild_now, rebuilds;
 };
 
 enum { VXH_MAXCOL = 64 };     // collision partners kept per surface voxel (overflow -> VXH_ROBOT_COL_OVERFLOW)
@@ -40,6 +41,7 @@ enum { VXH_MAXCOL = 64 };     // collision partners kept per surface voxel (over
 // all device pointers of a batch; passed to kernels by value
 struct DBatch {
     int n_robots, nv;                 // nv = total padded voxel slots (multiple of 64 per robot)
+    int dbg, pad1;                    // developer switches (scripts/gpu_diag.py), 0 in production
     const DRobot* robot;
     DRobotState* rstate;
     const int* wave_robot;            // [nv/64] robot of each 64-voxel group
@@ -51,24 +53,24 @@ struct DBatch {
     const int* nbr;                   // [6*nv] direction-major, global voxel slot or -1
     const float* phase;               // [nv]
     const float* amp_damp;            // [nv]
-    // voxel state: pos/scale double-buffered (collision forces read other voxels' previous positions)
-    double* pos[2][3];
-    double* scale[2];
-    double* quat[4];                  // w, x, y, z
-    double* lin_mom[3];
-    double* ang_mom[3];
-    // bond state (axis-major slots 3*nv): history _LastPos2, _LastAngle1, _LastAngle2 and the small-angle flag
-    double* hist[9];
+    // voxel state, 18 component planes of nv doubles each: [0..3] pos xyz + scale (buffer 0), [4..7] the same
+    // (buffer 1; positions/scale are double-buffered because collision forces read OTHER voxels' previous
+    // positions), [8..11] quaternion w x y z, [12..14] linear momentum, [15..17] angular momentum
+    double* vs;
+    // bond history, 9 planes of 3*nv (axis-major slots): _LastPos2, _LastAngle1, _LastAngle2 ; + small-angle flag
+    double* hist;
     unsigned char* small_angle;
-    // bond outputs of the current step: F1, M1, F2, M2
-    double* bout[12];
+    // streaming path only: bond outputs of the current step, 12 planes of 3*nv: F1, M1, F2, M2
+    double* bout;
     // collisions
     const int* surf;                  // global voxel slots of surface voxels, per robot contiguous
     const int* surf_ord;              // [nv] ordinal in the robot's surface list or -1
-    const int* near_off;              // [nv+1] CSR of the CalcNearby exclusion lists (global voxel slots)
-    const int* near_idx;
+    const unsigned long long* excl;   // CalcNearby exclusion as bit rows: per robot nsurf rows of excl_wpr 64-bit words,
+                                      // bit j of row i set when surface voxels i and j are within the hop horizon
     int* col_cnt;                     // [total surface voxels]
-    int* col_partner;                 // [total surface voxels * VXH_MAXCOL] global voxel slots
+    int col_rows, pad2;               // total surface voxels of colliding robots
+    int* col_partner;                 // [VXH_MAXCOL][col_rows] (partner-major) global voxel slots
+    double* col_a1;                   // same shape: linear stiffness a1 of that collision bond
     // constants from Vec3D.h evaluated by the host libm (thresholds of the small-angle logic)
     double small_angle_w, smallish_angle_w, slthresh_acos2sqrt;
 };

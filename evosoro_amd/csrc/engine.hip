@@ -35,6 +35,12 @@ int intern_bytes(std::vector<T>& table, const T& value)
 struct Engine::Device {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // fused path: robots grouped by workgroup size (256/512/768/1024 threads), one stream per class so that
+    // the classes fill the chip together
+    hipStream_t class_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t class_t0[4] = {nullptr, nullptr, nullptr, nullptr}, class_t1[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int* class_list[4] = {nullptr, nullptr, nullptr, nullptr};
+    int class_count[4] = {0, 0, 0, 0};
     std::vector<void*> allocs;
     DBatch B{};
     std::vector<DRobot> h_robot;
@@ -45,6 +51,10 @@ struct Engine::Device {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_rounds = 0;
+    int max_nvox = 0;                     // largest robot of the batch (selects the fused block size)
+    int reb_blocks = 0;                   // streaming path: collision-rebuild blocks appended to k_bonds
+    const int* reb_robot = nullptr;
+    const int* reb_i0 = nullptr;
 
     template <class T>
     T* upload(const std::vector<T>& h, size_t min_count = 1)
@@ -87,6 +97,11 @@ Engine::Engine(int variant, int device_id) : variant_(variant), device_id_(devic
     HIP_OK(hipStreamCreateWithFlags(&dev_->stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&dev_->ev0));
     HIP_OK(hipEventCreate(&dev_->ev1));
+    for (int c = 0; c < 4; ++c) {
+        HIP_OK(hipStreamCreateWithFlags(&dev_->class_stream[c], hipStreamNonBlocking));
+        HIP_OK(hipEventCreate(&dev_->class_t0[c]));
+        HIP_OK(hipEventCreate(&dev_->class_t1[c]));
+    }
 }
 
 Engine::~Engine()
@@ -97,6 +112,7 @@ Engine::~Engine()
         if (dev_->ev0) hipEventDestroy(dev_->ev0);
         if (dev_->ev1) hipEventDestroy(dev_->ev1);
         if (dev_->stream) hipStreamDestroy(dev_->stream);
+        for (int c = 0; c < 4; ++c) { if (dev_->class_stream[c]) hipStreamDestroy(dev_->class_stream[c]); if (dev_->class_t0[c]) hipEventDestroy(dev_->class_t0[c]); if (dev_->class_t1[c]) hipEventDestroy(dev_->class_t1[c]); }
     }
 }
 
@@ -110,7 +126,7 @@ int Engine::add_vxa(const char* data, size_t len)
     }
     robots_.push_back(build_robot(vxa));
     prepared_ = false;
-    downloaded_ = false;
+    state_downloaded_ = control_downloaded_ = false;
     return (int)robots_.size() - 1;
 }
 
@@ -120,13 +136,16 @@ void Engine::clear()
     dev_->free_all();
     robots_.clear();
     host_.clear();
-    prepared_ = downloaded_ = false;
+    prepared_ = state_downloaded_ = control_downloaded_ = false;
     rounds_done_ = 0;
 }
 
 void Engine::set_option(const std::string& key, double value)
 {
-    if (key == "graph_steps") { graph_steps_ = (int)value; if (dev_->graph_exec) { hipGraphExecDestroy(dev_->graph_exec); dev_->graph_exec = nullptr; } }
+    if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; }
+    else if (key == "fused") fused_ = value != 0;
+    else if (key == "steps_per_launch") steps_per_launch_ = (int)value;
+    else if (key == "graph_steps") { graph_steps_ = (int)value; if (dev_->graph_exec) { hipGraphExecDestroy(dev_->graph_exec); dev_->graph_exec = nullptr; } }
     else throw std::invalid_argument("unknown option " + key);
 }
 
@@ -143,17 +162,20 @@ void Engine::prepare()
     D.surf_begin.assign(nr, 0);
     int nv = 0, ns = 0;
     D.max_planned = 0;
+    D.max_nvox = 0;
     for (int r = 0; r < nr; ++r) {
         D.vox_begin[r] = nv;
         D.surf_begin[r] = ns;
         nv += (robots_[r].nvox + 63) / 64 * 64;
         ns += robots_[r].vxa.self_col_enabled ? robots_[r].nsurf : 0;
         if (robots_[r].nvox > 0) D.max_planned = std::max(D.max_planned, robots_[r].planned_steps);
+        D.max_nvox = std::max(D.max_nvox, robots_[r].nvox);
     }
     if (nv == 0) nv = 64;
     D.total_surf = ns;
 
-    std::vector<int> wave_robot(nv / 64, -1), nbr((size_t)6 * nv, -1), surf(std::max(ns, 1), 0), surf_ord(nv, -1), near_off((size_t)nv + 1, 0), near_idx;
+    std::vector<int> wave_robot(nv / 64, -1), nbr((size_t)6 * nv, -1), surf(std::max(ns, 1), 0), surf_ord(nv, -1);
+    std::vector<unsigned long long> excl;
     std::vector<unsigned short> vclass(nv, 0);
     std::vector<short> bclass((size_t)3 * nv, -1);
     std::vector<float> phase(nv, 0.f), amp_damp(nv, 1.f);
@@ -200,11 +222,21 @@ void Engine::prepare()
         }
         if (X.self_col_enabled)
             for (int i = 0; i < M.nsurf; ++i) { surf[D.surf_begin[r] + i] = base + M.surf[i]; surf_ord[base + M.surf[i]] = i; }
-        // CSR of the CalcNearby exclusion rows over every slot (empty rows for padding / non-colliding robots)
-        for (int v = 0; v < (M.nvox + 63) / 64 * 64; ++v) {
-            near_off[base + v] = (int)near_idx.size();
-            if (v < M.nvox && X.self_col_enabled)
-                for (int k = M.near_off[v]; k < M.near_off[v + 1]; ++k) near_idx.push_back(base + M.near_idx[k]);
+        // CalcNearby exclusion lists as bit rows over surface ordinals
+        long long excl_begin = (long long)excl.size();
+        int wpr = 0;
+        if (X.self_col_enabled) {
+            wpr = (M.nsurf + 63) / 64;
+            excl.resize(excl.size() + (size_t)M.nsurf * wpr, 0ull);
+            std::vector<int> ord(M.nvox, -1);
+            for (int i = 0; i < M.nsurf; ++i) ord[M.surf[i]] = i;
+            for (int i = 0; i < M.nsurf; ++i) {
+                const int vi = M.surf[i];
+                for (int k = M.near_off[vi]; k < M.near_off[vi + 1]; ++k) {
+                    const int j = ord[M.near_idx[k]];
+                    if (j >= 0) excl[(size_t)excl_begin + (size_t)i * wpr + (j >> 6)] |= 1ull << (j & 63);
+                }
+            }
         }
         DRobot& R = D.h_robot[r];
         R.vox_begin = base; R.nvox = M.nvox; R.surf_begin = D.surf_begin[r]; R.nsurf = X.self_col_enabled ? M.nsurf : 0;
@@ -212,7 +244,7 @@ void Engine::prepare()
                   (X.temp_enabled ? RF_TEMP : 0) | ((X.sticky_floor && variant_ == 0) ? RF_STICKY : 0) |
                   ((variant_ == 1 && X.fluid_env) ? RF_FLUID : 0) | (variant_ == 1 ? RF_LW : 0) |
                   ((X.col_system == 2 || X.col_system == 3) ? RF_HORIZON_COL : 0);
-        R.stop_type = X.stop_type;
+        R.stop_type = X.stop_type; R.excl_wpr = wpr; R.excl_begin = excl_begin;
         R.dt = M.dt; R.lat = X.lattice_dim; R.bond_z_half = 0.5 * X.bond_damping_z; R.slow_z = X.slow_damping_z; R.col_z = X.col_damping_z;
         R.grav_acc = X.grav_acc; R.init_cm_time = X.init_cm_time; R.stop_value = X.stop_value;
         R.afterlife = variant_ == 0 ? X.afterlife_time : 0.0;
@@ -226,10 +258,8 @@ void Engine::prepare()
         S.max_disp = (double)FLT_MAX;      // ClearAll, VX_Sim.cpp:369: forces a collision-list build on the first step
         S.status = M.nvox == 0 ? 3 : 0;
     }
-    near_off[nv] = (int)near_idx.size();
-
     DBatch& B = D.B;
-    B.n_robots = nr; B.nv = nv;
+    B.n_robots = nr; B.nv = nv; B.dbg = dbg_;
     B.robot = D.upload(D.h_robot);
     B.rstate = D.upload(rstate);
     B.wave_robot = D.upload(wave_robot);
@@ -240,38 +270,69 @@ void Engine::prepare()
     B.nbr = D.upload(nbr);
     B.phase = D.upload(phase);
     B.amp_damp = D.upload(amp_damp);
-    B.pos[0][0] = D.upload(px); B.pos[0][1] = D.upload(py); B.pos[0][2] = D.upload(pz);
-    B.pos[1][0] = D.upload(px); B.pos[1][1] = D.upload(py); B.pos[1][2] = D.upload(pz);
-    B.scale[0] = D.upload(sc); B.scale[1] = D.upload(sc);
-    B.quat[0] = D.upload(qw);
-    for (int k = 1; k < 4; ++k) B.quat[k] = D.alloc_zero<double>(nv);
-    for (int k = 0; k < 3; ++k) { B.lin_mom[k] = D.alloc_zero<double>(nv); B.ang_mom[k] = D.alloc_zero<double>(nv); }
-    for (int k = 0; k < 9; ++k) B.hist[k] = D.alloc_zero<double>((size_t)3 * nv);
+    {
+        std::vector<double> vs((size_t)18 * nv, 0.0);
+        for (int b = 0; b < 2; ++b) {
+            std::copy(px.begin(), px.end(), vs.begin() + (size_t)(4 * b + 0) * nv);
+            std::copy(py.begin(), py.end(), vs.begin() + (size_t)(4 * b + 1) * nv);
+            std::copy(pz.begin(), pz.end(), vs.begin() + (size_t)(4 * b + 2) * nv);
+            std::copy(sc.begin(), sc.end(), vs.begin() + (size_t)(4 * b + 3) * nv);
+        }
+        std::copy(qw.begin(), qw.end(), vs.begin() + (size_t)8 * nv);
+        B.vs = D.upload(vs);
+    }
+    B.hist = D.alloc_zero<double>((size_t)9 * 3 * nv);
     B.small_angle = D.upload(small);
-    for (int k = 0; k < 12; ++k) B.bout[k] = D.alloc_zero<double>((size_t)3 * nv);
+    B.bout = D.alloc_zero<double>((size_t)12 * 3 * nv);
     B.surf = D.upload(surf);
     B.surf_ord = D.upload(surf_ord);
-    B.near_off = D.upload(near_off);
-    B.near_idx = D.upload(near_idx);
+    B.excl = D.upload(excl);
+    B.col_rows = std::max(ns, 1);
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
+    B.col_a1 = D.alloc_zero<double>((size_t)std::max(ns, 1) * VXH_MAXCOL);
+    {   // fused path: size classes, most steps first inside a class
+        std::vector<int> lists[4];
+        for (int r = 0; r < nr; ++r) {
+            const int n = robots_[r].nvox;
+            if (n == 0 || n > 1024) continue;
+            lists[n <= 256 ? 0 : (n <= 512 ? 1 : (n <= 768 ? 2 : 3))].push_back(r);
+        }
+        for (int c = 0; c < 4; ++c) {
+            std::stable_sort(lists[c].begin(), lists[c].end(), [&](int a, int b) {
+                return (double)robots_[a].planned_steps * robots_[a].nvox > (double)robots_[b].planned_steps * robots_[b].nvox; });
+            D.class_count[c] = (int)lists[c].size();
+            D.class_list[c] = D.upload(lists[c]);
+        }
+    }
+    {   // streaming path: one rebuild block per 256 surface voxels of every colliding robot
+        std::vector<int> rr, ri;
+        for (int r = 0; r < nr; ++r)
+            if (robots_[r].vxa.self_col_enabled)
+                for (int i0 = 0; i0 < robots_[r].nsurf; i0 += 256) { rr.push_back(r); ri.push_back(i0); }
+        D.reb_blocks = (int)rr.size();
+        D.reb_robot = D.upload(rr);
+        D.reb_i0 = D.upload(ri);
+    }
     B.small_angle_w = std::cos(VXH_SMALL_ANGLE_RAD * 0.5);                    // Vec3D.h:55-59
     B.smallish_angle_w = std::cos(VXH_HYST * VXH_SMALL_ANGLE_RAD * 0.5);
     B.slthresh_acos2sqrt = 1.0 - 0.9988 * 0.9988;
     prepared_ = true;
-    downloaded_ = false;
+    state_downloaded_ = control_downloaded_ = false;
+    host_.clear();
     rounds_done_ = 0;
     counters_ = vxh_counters{};
 }
 
 void Engine::reset() { if (!robots_.empty()) prepare(); }
 
-static void launch_round(const DBatch& B, hipStream_t s, long long cap)
+template <int BLOCK>
+static void launch_fused(const DBatch& B, const int* list, int count, hipStream_t s, long long cap, int iters)
 {
-    const int nb_b = (3 * B.nv + 255) / 256, nb_v = (B.nv + 255) / 256;
-    hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, s, B, cap, 1);
-    hipLaunchKernelGGL(k_bonds, dim3(nb_b), dim3(256), 0, s, B);
-    hipLaunchKernelGGL(k_voxels, dim3(nb_v), dim3(256), 0, s, B);
+    static bool attr_set = false;
+    const size_t lds = (size_t)18 * BLOCK * sizeof(double);
+    if (!attr_set) { hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); attr_set = true; }
+    hipLaunchKernelGGL(k_robot_steps<BLOCK>, dim3(count), dim3(BLOCK), lds, s, B, list, cap, iters);
 }
 
 void Engine::advance(long long max_rounds)
@@ -280,33 +341,88 @@ void Engine::advance(long long max_rounds)
     Device& D = *dev_;
     const DBatch& B = D.B;
     const long long cap_all = 0x7fffffffffffffffLL;
-    long long todo = std::min(max_rounds, std::max(0LL, D.max_planned - rounds_done_));
-    const long long cap = (max_rounds >= D.max_planned - rounds_done_) ? cap_all : rounds_done_ + max_rounds;
+    const long long remaining = std::max(0LL, D.max_planned - rounds_done_);
+    const long long todo = std::min(max_rounds, remaining);
+    const long long cap = (max_rounds >= remaining) ? cap_all : rounds_done_ + max_rounds;
+    const bool fused = fused_ && D.max_nvox <= 1024;
+    // per-robot step counts before, to attribute the work of this call
+    std::vector<int> steps_before(robots_.size());
+    for (size_t r = 0; r < robots_.size(); ++r) steps_before[r] = host_.size() == robots_.size() ? host_[r].steps : 0;
     HIP_OK(hipEventRecord(D.ev0, D.stream));
-    long long launched = 0;
-    if (graph_steps_ > 1 && cap == cap_all && todo >= graph_steps_) {
-        if (!D.graph_exec || D.graph_rounds != graph_steps_) {
-            if (D.graph_exec) { hipGraphExecDestroy(D.graph_exec); D.graph_exec = nullptr; }
-            if (D.graph) { hipGraphDestroy(D.graph); D.graph = nullptr; }
-            HIP_OK(hipStreamBeginCapture(D.stream, hipStreamCaptureModeThreadLocal));
-            for (int k = 0; k < graph_steps_; ++k) launch_round(B, D.stream, cap_all);
-            HIP_OK(hipStreamEndCapture(D.stream, &D.graph));
-            HIP_OK(hipGraphInstantiate(&D.graph_exec, D.graph, nullptr, nullptr, 0));
-            D.graph_rounds = graph_steps_;
+    long long launches = 0, class_launches[4] = {0, 0, 0, 0};
+    if (fused) {
+        const int iters = std::max(1, steps_per_launch_);
+        for (int c = 0; c < 4; ++c)
+            if (D.class_count[c]) { HIP_OK(hipStreamWaitEvent(D.class_stream[c], D.ev0, 0)); HIP_OK(hipEventRecord(D.class_t0[c], D.class_stream[c])); }
+        for (long long done = 0; done < todo || done == 0; done += iters) {
+            if (D.class_count[3]) launch_fused<1024>(B, D.class_list[3], D.class_count[3], D.class_stream[3], cap, iters);
+            if (D.class_count[2]) launch_fused<768>(B, D.class_list[2], D.class_count[2], D.class_stream[2], cap, iters);
+            if (D.class_count[1]) launch_fused<512>(B, D.class_list[1], D.class_count[1], D.class_stream[1], cap, iters);
+            if (D.class_count[0]) launch_fused<256>(B, D.class_list[0], D.class_count[0], D.class_stream[0], cap, iters);
+            for (int c = 0; c < 4; ++c) if (D.class_count[c]) { ++launches; ++class_launches[c]; }
         }
-        while (todo - launched >= graph_steps_) { HIP_OK(hipGraphLaunch(D.graph_exec, D.stream)); launched += graph_steps_; }
+        for (int c = 0; c < 4; ++c)
+            if (D.class_count[c]) { HIP_OK(hipEventRecord(D.class_t1[c], D.class_stream[c])); HIP_OK(hipStreamWaitEvent(D.stream, D.class_t1[c], 0)); }
+    } else {
+        const int nb_b = (3 * B.nv + 255) / 256, nb_v = (B.nv + 255) / 256;
+        auto round = [&](long long c) {
+            hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, c, 1);
+            hipLaunchKernelGGL(k_bonds, dim3(nb_b + D.reb_blocks), dim3(256), 0, D.stream, B, nb_b, D.reb_robot, D.reb_i0);
+            hipLaunchKernelGGL(k_voxels, dim3(nb_v), dim3(256), 0, D.stream, B);
+        };
+        long long launched = 0;
+        if (graph_steps_ > 1 && cap == cap_all && todo >= graph_steps_) {
+            if (!D.graph_exec || D.graph_rounds != graph_steps_) {
+                if (D.graph_exec) { hipGraphExecDestroy(D.graph_exec); D.graph_exec = nullptr; }
+                if (D.graph) { hipGraphDestroy(D.graph); D.graph = nullptr; }
+                HIP_OK(hipStreamBeginCapture(D.stream, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < graph_steps_; ++k) round(cap_all);
+                HIP_OK(hipStreamEndCapture(D.stream, &D.graph));
+                HIP_OK(hipGraphInstantiate(&D.graph_exec, D.graph, nullptr, nullptr, 0));
+                D.graph_rounds = graph_steps_;
+            }
+            while (todo - launched >= graph_steps_) { HIP_OK(hipGraphLaunch(D.graph_exec, D.stream)); launched += graph_steps_; }
+        }
+        for (; launched < todo; ++launched) round(cap);
+        hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, cap, 0);   // finish the last step
+        launches = 3 * todo + 1;
     }
-    for (; launched < todo; ++launched) launch_round(B, D.stream, cap);
-    hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, cap, 0);   // finish the last step
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(D.ev1, D.stream));
     HIP_OK(hipStreamSynchronize(D.stream));
     float ms = 0;
     HIP_OK(hipEventElapsedTime(&ms, D.ev0, D.ev1));
     counters_.kernel_seconds += ms * 1e-3;
-    counters_.launches += 3 * todo + 1;
+    counters_.launches += launches;
     rounds_done_ += todo;
-    downloaded_ = false;
+    state_downloaded_ = false;
+    download_control();
+
+    // dominant kernel of this call: the size class that processed most voxel-steps (fused) / the whole call (streaming)
+    double cls_vs[4] = {0, 0, 0, 0}, cls_ab[4] = {0, 0, 0, 0};
+    double all_vs = 0, all_ab = 0;
+    for (size_t r = 0; r < robots_.size(); ++r) {
+        const int n = robots_[r].nvox;
+        if (n == 0) continue;
+        const double ds = host_[r].steps - steps_before[r];
+        const int c = n <= 256 ? 0 : (n <= 512 ? 1 : (n <= 768 ? 2 : 3));
+        cls_vs[c] += ds * n; cls_ab[c] += ds * (224.0 * n + 144.0 * robots_[r].nbond);
+        all_vs += ds * n; all_ab += ds * (224.0 * n + 144.0 * robots_[r].nbond);
+    }
+    if (fused) {
+        int best = 0;
+        for (int c = 1; c < 4; ++c) if (cls_vs[c] > cls_vs[best]) best = c;
+        float cms = 0;
+        if (D.class_count[best]) HIP_OK(hipEventElapsedTime(&cms, D.class_t0[best], D.class_t1[best]));
+        static const int blocks[4] = {256, 512, 768, 1024};
+        counters_.dominant_block = blocks[best]; counters_.dominant_robots = D.class_count[best];
+        counters_.dominant_launches = class_launches[best]; counters_.dominant_seconds = cms * 1e-3;
+        counters_.dominant_alg_bytes = cls_ab[best]; counters_.dominant_voxel_steps = cls_vs[best];
+    } else {
+        counters_.dominant_block = 0; counters_.dominant_robots = (int)robots_.size();
+        counters_.dominant_launches = todo; counters_.dominant_seconds = ms * 1e-3;
+        counters_.dominant_alg_bytes = all_ab; counters_.dominant_voxel_steps = all_vs;
+    }
 }
 
 void Engine::run()
@@ -315,7 +431,6 @@ void Engine::run()
     if (robots_.empty()) return;
     if (!prepared_) prepare();
     advance(0x7fffffffffffffffLL / 4);
-    download();
     counters_.run_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
@@ -325,29 +440,17 @@ void Engine::step(long long n)
     if (robots_.empty() || n <= 0) return;
     if (!prepared_) prepare();
     advance(n);
-    download();
     counters_.run_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-void Engine::download()
+// per-robot control blocks (a few hundred bytes each): status, step counts, IniCM -> counters
+void Engine::download_control()
 {
-    HIP_OK(hipSetDevice(device_id_));
     Device& D = *dev_;
-    const DBatch& B = D.B;
-    const int nr = (int)robots_.size(), nv = B.nv;
+    const int nr = (int)robots_.size();
     std::vector<DRobotState> rstate(nr);
-    HIP_OK(hipMemcpy(rstate.data(), B.rstate, sizeof(DRobotState) * nr, hipMemcpyDeviceToHost));
-    std::vector<double> tmp[2][4], q[4], lm[3], am[3];
-    for (int b = 0; b < 2; ++b) {
-        for (int k = 0; k < 3; ++k) { tmp[b][k].resize(nv); HIP_OK(hipMemcpy(tmp[b][k].data(), B.pos[b][k], sizeof(double) * nv, hipMemcpyDeviceToHost)); }
-        tmp[b][3].resize(nv); HIP_OK(hipMemcpy(tmp[b][3].data(), B.scale[b], sizeof(double) * nv, hipMemcpyDeviceToHost));
-    }
-    for (int k = 0; k < 4; ++k) { q[k].resize(nv); HIP_OK(hipMemcpy(q[k].data(), B.quat[k], sizeof(double) * nv, hipMemcpyDeviceToHost)); }
-    for (int k = 0; k < 3; ++k) {
-        lm[k].resize(nv); HIP_OK(hipMemcpy(lm[k].data(), B.lin_mom[k], sizeof(double) * nv, hipMemcpyDeviceToHost));
-        am[k].resize(nv); HIP_OK(hipMemcpy(am[k].data(), B.ang_mom[k], sizeof(double) * nv, hipMemcpyDeviceToHost));
-    }
-    host_.assign(nr, HostState());
+    HIP_OK(hipMemcpy(rstate.data(), D.B.rstate, sizeof(DRobotState) * nr, hipMemcpyDeviceToHost));
+    if ((int)host_.size() != nr) host_.assign(nr, HostState());
     double vs = 0, bs = 0, ab = 0; long long mx = 0;
     for (int r = 0; r < nr; ++r) {
         const RobotModel& M = robots_[r];
@@ -356,25 +459,43 @@ void Engine::download()
         H.cur_time = S.cur_time; H.steps = S.steps; H.status = S.status; H.cm_init = S.cm_init; H.rebuilds = S.rebuilds;
         H.eol_post_y = S.eol_post_y;
         for (int k = 0; k < 3; ++k) H.ini_cm[k] = S.ini_cm[k];
-        if (S.status == 0 && S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
-        else if (S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
-        const int n = M.nvox, base = D.vox_begin[r], b = S.steps & 1;
-        H.pos.resize((size_t)3 * n); H.quat.resize((size_t)4 * n); H.scale.resize(n); H.lin_mom.resize((size_t)3 * n); H.ang_mom.resize((size_t)3 * n);
-        for (int v = 0; v < n; ++v) {
-            for (int k = 0; k < 3; ++k) { H.pos[3 * v + k] = tmp[b][k][base + v]; H.lin_mom[3 * v + k] = lm[k][base + v]; H.ang_mom[3 * v + k] = am[k][base + v]; }
-            for (int k = 0; k < 4; ++k) H.quat[4 * v + k] = q[k][base + v];
-            H.scale[v] = tmp[b][3][base + v];
-        }
-        vs += (double)n * S.steps; bs += (double)M.nbond * S.steps; ab += (224.0 * n + 144.0 * M.nbond) * S.steps;
+        if (S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
+        vs += (double)M.nvox * S.steps; bs += (double)M.nbond * S.steps; ab += (224.0 * M.nvox + 144.0 * M.nbond) * S.steps;
         mx = std::max(mx, (long long)S.steps);
     }
     counters_.voxel_steps = vs; counters_.bond_steps = bs; counters_.algorithmic_bytes = ab; counters_.max_steps = mx;
-    downloaded_ = true;
+    control_downloaded_ = true;
+}
+
+// full voxel state (lazy: only when results or trajectories are requested)
+void Engine::download()
+{
+    HIP_OK(hipSetDevice(device_id_));
+    Device& D = *dev_;
+    const DBatch& B = D.B;
+    const int nr = (int)robots_.size(), nv = B.nv;
+    if (!control_downloaded_) download_control();
+    std::vector<double> planes((size_t)18 * nv);
+    HIP_OK(hipMemcpy(planes.data(), B.vs, sizeof(double) * planes.size(), hipMemcpyDeviceToHost));
+    auto plane = [&](int comp) { return planes.data() + (size_t)comp * nv; };
+    for (int r = 0; r < nr; ++r) {
+        const RobotModel& M = robots_[r];
+        HostState& H = host_[r];
+        const int n = M.nvox, base = D.vox_begin[r], b = H.steps & 1;
+        H.pos.resize((size_t)3 * n); H.quat.resize((size_t)4 * n); H.scale.resize(n); H.lin_mom.resize((size_t)3 * n); H.ang_mom.resize((size_t)3 * n);
+        for (int v = 0; v < n; ++v) {
+            for (int k = 0; k < 3; ++k) { H.pos[3 * v + k] = plane(4 * b + k)[base + v]; H.lin_mom[3 * v + k] = plane(12 + k)[base + v]; H.ang_mom[3 * v + k] = plane(15 + k)[base + v]; }
+            for (int k = 0; k < 4; ++k) H.quat[4 * v + k] = plane(8 + k)[base + v];
+            H.scale[v] = plane(4 * b + 3)[base + v];
+        }
+    }
+    state_downloaded_ = true;
 }
 
 void Engine::result(int robot, vxh_result* out)
 {
-    if (!downloaded_) throw std::logic_error("results requested before vxh_run/vxh_step");
+    if (!prepared_) throw std::logic_error("results requested before vxh_run/vxh_step");
+    if (!state_downloaded_) download();
     compute_result(robots_[robot], host_[robot], out);
 }
 
@@ -383,7 +504,7 @@ void Engine::state14(int robot, double* out, int capacity)
     const RobotModel& M = robots_[robot];
     if (capacity < M.nvox) throw std::invalid_argument("state buffer too small");
     if (!prepared_) prepare();
-    if (!downloaded_) download();
+    if (!state_downloaded_) download();
     const HostState& H = host_[robot];
     for (int v = 0; v < M.nvox; ++v) {
         const VoxClass& C = M.vox_classes[M.vox_class[v]];

@@ -37,13 +37,17 @@ private:
     void prepare();                            // build + upload the batch
     void advance(long long max_rounds);        // launch step rounds
     void download();
+    void download_control();
     int variant_, device_id_;
     std::vector<RobotModel> robots_;
     std::vector<HostState> host_;
     std::unique_ptr<Device> dev_;
-    bool prepared_ = false, downloaded_ = false;
+    bool prepared_ = false, state_downloaded_ = false, control_downloaded_ = false;
     long long rounds_done_ = 0;
-    int graph_steps_ = 32;                     // step rounds captured per hipGraph launch (0 = plain launches)
+    int graph_steps_ = 32;                     // streaming path: step rounds captured per hipGraph launch (0 = plain launches)
+    int dbg_ = 0;
+    bool fused_ = true;                        // one-workgroup-per-robot fused kernel when every robot has <= 1024 voxels
+    int steps_per_launch_ = 64;                // fused path: time steps per kernel launch
     vxh_counters counters_{};
 };
 

@@ -47,7 +47,10 @@ class VxhResult(ctypes.Structure):
 class VxhCounters(ctypes.Structure):
     _fields_ = [("voxel_steps", ctypes.c_double), ("bond_steps", ctypes.c_double),
                 ("algorithmic_bytes", ctypes.c_double), ("kernel_seconds", ctypes.c_double),
-                ("run_seconds", ctypes.c_double), ("launches", ctypes.c_longlong), ("max_steps", ctypes.c_longlong)]
+                ("run_seconds", ctypes.c_double), ("launches", ctypes.c_longlong), ("max_steps", ctypes.c_longlong),
+                ("dominant_block", ctypes.c_int), ("dominant_robots", ctypes.c_int),
+                ("dominant_launches", ctypes.c_longlong), ("dominant_seconds", ctypes.c_double),
+                ("dominant_alg_bytes", ctypes.c_double), ("dominant_voxel_steps", ctypes.c_double)]
 
 
 class VxhError(RuntimeError):

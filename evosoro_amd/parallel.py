@@ -1,0 +1,122 @@
+"""Population sharding across GPUs and the fitness gather.
+
+The reference evaluates a generation by launching one OS process per robot and letting the kernel schedule them
+over the host cores (evosoro/tools/evaluation.py:59-90); results come back through files.  Here a generation is
+a batch: robots are independent, so the batch is partitioned over the ranks of a `torch.distributed` job (one
+process per GPU, backend "nccl" = RCCL over xGMI on MI355X, "gloo" on CPU for tests), every rank steps its shard
+on its own GPU with no data-path communication, and ONE collective returns the fixed-size result records
+(<= 256 B per robot) to every rank.
+"""
+import numpy as np
+
+RECORD_FIELDS = ["status", "steps", "nvox", "nbond", "dt", "cur_time", "lifetime",
+                 "ini_cm_x", "ini_cm_y", "ini_cm_z", "cur_cm_x", "cur_cm_y", "cur_cm_z",
+                 "norm_final_dist", "norm_regime_dist", "norm_frozen_dist", "final_dist", "final_dist_y",
+                 "anterior_dist", "posterior_dist", "anterior_y", "posterior_y", "end_of_life_posterior_y",
+                 "fall_adj_post_y", "num_non_feet_touching_floor", "num_touching_floor",
+                 "norm_abs_disp", "norm_dist_x", "norm_dist_y", "norm_dist_z", "col_rebuilds"]
+RECORD_LEN = len(RECORD_FIELDS)
+
+
+def result_to_record(res):
+    """vxh_result (ctypes struct from evosoro_amd.engine) -> float64 vector in RECORD_FIELDS order."""
+    rec = np.empty(RECORD_LEN, dtype=np.float64)
+    rec[0:7] = (res.status, res.steps, res.nvox, res.nbond, res.dt, res.cur_time, res.lifetime)
+    rec[7:10] = list(res.ini_cm)
+    rec[10:13] = list(res.cur_cm)
+    for k, name in enumerate(RECORD_FIELDS[13:]):
+        rec[13 + k] = getattr(res, name)
+    return rec
+
+
+def shard_by_cost(costs, world_size):
+    """Greedy longest-processing-time partition: returns, per rank, the sorted list of item indices.
+
+    cost of a robot = voxels x time steps (the step count varies 10x with the stiffest material present,
+    SURVEY.md section 7).  Deterministic: ties broken by index.
+    """
+    costs = np.asarray(costs, dtype=np.float64)
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(i)
+        loads[r] += costs[i]
+    return [sorted(s) for s in shards]
+
+
+def shard_round_robin(count, world_size):
+    return [list(range(r, count, world_size)) for r in range(world_size)]
+
+
+def gather_records(local_records, local_indices, total, device=None):
+    """All ranks receive the full [total, RECORD_LEN] table.  Single all_gather of a padded per-rank block.
+
+    Without an initialised process group (single GPU) this is a plain scatter into the table.
+    """
+    import torch
+    import torch.distributed as dist
+    table = np.zeros((total, RECORD_LEN), dtype=np.float64)
+    local_records = np.asarray(local_records, dtype=np.float64).reshape(-1, RECORD_LEN)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        table[list(local_indices)] = local_records
+        return table
+    world = dist.get_world_size()
+    per_rank = (total + world - 1) // world + 1          # LPT shards may be uneven: allow slack, verified below
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    mine = torch.tensor([len(local_indices)], dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, mine)
+    per_rank = int(max(per_rank, int(counts.max().item())))
+    block = torch.zeros((per_rank, RECORD_LEN + 1), dtype=torch.float64, device=device)
+    if len(local_indices):
+        block[:len(local_indices), 0] = torch.tensor(list(local_indices), dtype=torch.float64, device=device)
+        block[:len(local_indices), 1:] = torch.from_numpy(local_records).to(block.device)
+    gathered = torch.zeros((world * per_rank, RECORD_LEN + 1), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(gathered, block)
+    gathered = gathered.cpu().numpy().reshape(world, per_rank, RECORD_LEN + 1)
+    counts = counts.cpu().numpy()
+    for r in range(world):
+        for k in range(int(counts[r])):
+            table[int(gathered[r, k, 0])] = gathered[r, k, 1:]
+    return table
+
+
+def run_shard(engine_module, paths, variant, device_index, options=None, write_xml=True):
+    """Step the given .vxa files as one batch on one GPU; returns (records [n, RECORD_LEN], counters)."""
+    records = np.zeros((len(paths), RECORD_LEN), dtype=np.float64)
+    if not paths:
+        return records, None
+    with engine_module.Engine(variant, device_index) as eng:
+        for key, val in (options or {}).items():
+            eng.set_option(key, val)
+        for path in paths:
+            eng.add_vxa_file(path)
+        eng.run()
+        for i in range(len(paths)):
+            res = eng.result(i)
+            records[i] = result_to_record(res)
+            if write_xml and res.status == engine_module.ROBOT_FINISHED and eng.fitness_file_name(i):
+                eng.write_result_xml(i)
+        counters = eng.counters()
+    return records, counters
+
+
+def run_population(engine_module, paths, variant=0, costs=None, options=None, write_xml=True):
+    """Evaluate every .vxa of a generation; with an initialised process group the files are sharded over ranks.
+
+    Returns the full record table (identical on every rank).
+    """
+    import torch
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if distributed:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        shards = shard_by_cost(costs, world) if costs is not None else shard_round_robin(len(paths), world)
+        mine = shards[rank]
+    else:
+        mine = list(range(len(paths)))
+    device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    records, _ = run_shard(engine_module, [paths[i] for i in mine], variant, device_index, options, write_xml)
+    device = torch.device("cuda", device_index) if (distributed and dist.get_backend() == "nccl") else None
+    return gather_records(records, mine, len(paths), device)

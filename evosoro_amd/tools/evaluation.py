@@ -1,0 +1,117 @@
+"""evaluate_all: evaluate every individual of a population — one batched GPU run instead of one OS process each.
+
+Drop-in for evosoro/tools/evaluation.py:18-219 (same signature, same side effects):
+  * every individual is serialised with write_voxelyze_file and gets `ind.md5`                 (reference :62)
+  * invalid phenotypes get the worst value of every objective except "age"                     (:65-69)
+  * with zero actuation variance an md5 already evaluated reuses the cached objective values   (:72-81)
+  * the rest are simulated; `pop.total_evaluations`, `pop.all_evaluated_individuals_ids`,
+    `pop.already_evaluated[md5]` and `pop.best_fit_so_far` are maintained                      (:84-86,179-190)
+  * objectives with a tag are read back from the result XML (6 significant digits, through
+    read_voxlyze_results exactly as in the reference), objectives without a tag are computed
+    from the phenotype with their node_func                                                    (:160-177)
+  * .vxa housekeeping: champions copied to bestSoFar/fitOnly, lineages to ancestors/, the
+    generation's files moved to Gen_%04i/ or deleted                                           (:185-203)
+  * individuals whose simulation did not finish (diverged, empty, ...) keep the worst value, which is
+    what the reference leaves after its timeout                                                (:107-119,213-215)
+What changes is the transport: instead of `sub.Popen("./voxelyze -f ...")` per robot and polling
+fitnessFiles/ (:89-90,128-158), all pending robots go through libvxhip in ONE call (sharded over the
+GPUs of the job when torch.distributed is initialised), which writes the same result XMLs.
+`max_eval_time` and `time_to_try_again` are accepted for compatibility; there is nothing to time out.
+"""
+import os
+import shutil
+import time
+
+import numpy as np
+
+from evosoro_amd.tools.read_write_voxelyze import read_voxlyze_results, write_voxelyze_file
+
+
+def _vxa_path(run_directory, run_name, ident):
+    return run_directory + "/voxelyzeFiles/" + run_name + "--id_%05i.vxa" % ident
+
+
+def _estimated_cost(ind):
+    """voxels x relative step count (a stiff 'bone' material, id 2, shrinks dt about tenfold)."""
+    for _, details in ind.genotype.to_phenotype_mapping.items():
+        if details["tag"] == "<Data>":
+            state = np.asarray(details["state"])
+            return float(np.count_nonzero(state)) * (10.0 if (state == 2).any() else 1.0)
+    return float(np.prod(ind.genotype.orig_size_xyz))
+
+
+def evaluate_all(sim, env, pop, print_log, save_vxa_every, run_directory, run_name, max_eval_time=60,
+                 time_to_try_again=10, save_lineages=False, variant=0, engine_module=None, engine_options=None):
+    start_time = time.time()
+    if engine_module is None:
+        from evosoro_amd import engine as engine_module   # fails loudly when libvxhip.so / a GPU is missing
+    from evosoro_amd import parallel
+
+    pending = []
+    for ind in pop:
+        ind.md5 = write_voxelyze_file(sim, env, ind, run_directory, run_name)
+        if not ind.phenotype.is_valid():
+            for rank, goal in pop.objective_dict.items():
+                if goal["name"] != "age":
+                    setattr(ind, goal["name"], goal["worst_value"])
+            print_log.message("Skipping invalid individual")
+        elif env.actuation_variance == 0 and ind.md5 in pop.already_evaluated:
+            for rank, goal in pop.objective_dict.items():
+                if goal["tag"] is not None:
+                    setattr(ind, goal["name"], pop.already_evaluated[ind.md5][rank])
+            if save_vxa_every > 0 and pop.gen % save_vxa_every == 0:
+                shutil.copy(_vxa_path(run_directory, run_name, ind.id),
+                            run_directory + "/Gen_%04i/" % pop.gen + run_name +
+                            "--Gen_%04i--fit_%.08f--id_%05i.vxa" % (pop.gen, ind.fitness, ind.id))
+        else:
+            pop.total_evaluations += 1
+            pending.append(ind)
+
+    print_log.message("Launched {0} voxelyze calls, out of {1} individuals".format(len(pending), len(pop)))
+
+    if pending:
+        os.makedirs(run_directory + "/fitnessFiles", exist_ok=True)
+        paths = [_vxa_path(run_directory, run_name, ind.id) for ind in pending]
+        table = parallel.run_population(engine_module, paths, variant=variant,
+                                        costs=[_estimated_cost(ind) for ind in pending], options=engine_options)
+    num_finished = 0
+    for k, ind in enumerate(pending):
+        status = int(table[k, 0])
+        xml = run_directory + "/fitnessFiles/softbotsOutput--id_%05i.xml" % ind.id
+        if status != engine_module.ROBOT_FINISHED or not os.path.exists(xml):
+            print_log.message("WARNING: simulation of id {0} did not finish (status {1}); "
+                              "the min fitness was assigned".format(ind.id, status))
+            continue
+        num_finished += 1
+        values = read_voxlyze_results(pop, print_log, xml)
+        print_log.message("{0} fit = {1} ({2} / {3})".format(os.path.basename(xml), values[0], num_finished,
+                                                             len(pending)))
+        os.remove(xml)
+        for rank, details in pop.objective_dict.items():
+            if values[rank] is not None:
+                setattr(ind, details["name"], values[rank])
+            else:
+                for name, details_phenotype in ind.genotype.to_phenotype_mapping.items():
+                    if name == details["output_node_name"]:
+                        setattr(ind, details["name"], details["node_func"](details_phenotype["state"]))
+        pop.already_evaluated[ind.md5] = [getattr(ind, details["name"]) for rank, details in pop.objective_dict.items()]
+        pop.all_evaluated_individuals_ids += [ind.id]
+
+        vxa = _vxa_path(run_directory, run_name, ind.id)
+        stamped = run_name + "--Gen_%04i--fit_%.08f--id_%05i.vxa" % (pop.gen, ind.fitness, ind.id)
+        if ind.fitness > pop.best_fit_so_far:
+            pop.best_fit_so_far = ind.fitness
+            shutil.copy(vxa, run_directory + "/bestSoFar/fitOnly/" + stamped)
+        if save_lineages:
+            shutil.copy(vxa, run_directory + "/ancestors/")
+        if save_vxa_every > 0 and pop.gen % save_vxa_every == 0:
+            shutil.move(vxa, run_directory + "/Gen_%04i/" % pop.gen + stamped)
+        else:
+            os.remove(vxa)
+
+    if num_finished < len(pending):
+        print_log.message("WARNING: Couldn't get a fitness value in time for some individuals. "
+                          "The min fitness was assigned for these individuals")
+    print_log.message("\nAll Voxelyze evals finished in {} seconds".format(time.time() - start_time))
+    print_log.message("num_evaluated_this_gen: {0}".format(len(pending)))
+    print_log.message("total_evaluations: {}".format(pop.total_evaluations))

@@ -75,6 +75,14 @@ typedef struct vxh_counters {
     double run_seconds;        /* host wall time of vxh_run incl. upload/download */
     long long launches;        /* step-kernel launches */
     long long max_steps;       /* largest per-robot step count */
+    /* the dominant kernel of the last vxh_run/vxh_step call (the size class holding most voxels on the fused path,
+     * k_bonds on the streaming path): what bench.py prices against the HBM roofline */
+    int dominant_block;             /* workgroup size of k_robot_steps<BLOCK>, 0 = streaming path */
+    int dominant_robots;
+    long long dominant_launches;
+    double dominant_seconds;        /* HIP-event time from its first to its last launch on its own stream */
+    double dominant_alg_bytes;      /* algorithmic bytes its launches processed in that call */
+    double dominant_voxel_steps;
 } vxh_counters;
 
 int  vxh_create(vxh_engine** out, int variant, int device_id);

@@ -104,3 +104,49 @@ if __name__ == "__main__" and "bisect" in sys.argv[1:]:
 
 if __name__ == "__main__" and "prof" in sys.argv[1:]:
     timing(512, (10, 10, 10), 0.01)
+
+
+if __name__ == "__main__" and "prof_nocol" in sys.argv[1:]:
+    timing(512, (10, 10, 10), 0.004, selfcol=False)
+
+
+def timing2(count, shape, sim_time, selfcol, opts):
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    sim = Sim(self_collisions_enabled=selfcol, dt_frac=0.9, simulation_time=sim_time, fitness_eval_init_time=min(0.1, sim_time / 5))
+    env = Env()
+    with engine.Engine(engine.VOXCAD, 0) as eng:
+        for k, val in opts.items():
+            eng.set_option(k, val)
+        for ind in workloads.population(count, shape):
+            write_voxelyze_file(sim, env, ind, tmp, "t")
+            eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "t--id_%05i.vxa" % ind.id))
+        eng.run()
+        c = eng.counters()
+        st = [eng.result(i).status for i in range(count)]
+        cm = np.array([eng.result(i).cur_cm for i in range(count)])
+        print("   mean rebuilds per robot %.1f, mean nvox %.0f" % (np.mean([eng.result(i).col_rebuilds for i in range(count)]), np.mean([eng.result(i).nvox for i in range(count)])))
+        print("batch %d x %s sim %.3fs col=%d %s: max_steps %d kernel %.4fs -> %.3e vox-steps/s, %.1f us/step, alg GB/s %.1f, statuses %s cmsum %.12g" % (
+            count, shape, sim_time, selfcol, opts, c.max_steps, c.kernel_seconds,
+            c.voxel_steps / c.kernel_seconds, 1e6 * c.kernel_seconds / c.max_steps, c.algorithmic_bytes / c.kernel_seconds / 1e9, sorted(set(st)), cm.sum()))
+
+
+if __name__ == "__main__" and "fused" in sys.argv[1:]:
+    for col in (False, True):
+        for opts in ({"fused": 0}, {"fused": 1, "steps_per_launch": 1}, {"fused": 1, "steps_per_launch": 64}):
+            timing2(512, (10, 10, 10), 0.01, col, opts)
+    for opts in ({"fused": 0}, {"fused": 1, "steps_per_launch": 64}):
+        timing2(64, (10, 10, 10), 0.02, True, opts)
+        timing2(64, (6, 6, 6), 0.05, True, opts)
+        timing2(2048, (6, 6, 6), 0.01, True, opts)
+
+
+if __name__ == "__main__" and "col" in sys.argv[1:]:
+    timing2(512, (10, 10, 10), 0.01, True, {"fused": 1, "steps_per_launch": 64})
+    timing2(512, (10, 10, 10), 0.05, True, {"fused": 1, "steps_per_launch": 64})
+    timing2(512, (10, 10, 10), 0.05, False, {"fused": 1, "steps_per_launch": 64})
+
+
+if __name__ == "__main__" and "dbg" in sys.argv[1:]:
+    for d in (0, 1, 2, 3):
+        timing2(512, (10, 10, 10), 0.03, True, {"fused": 1, "steps_per_launch": 64, "dbg": d})
