@@ -45,6 +45,28 @@ bool bad_robot(const vxh_engine* e, int robot) { return !e || !e->impl || robot 
 
 extern "C" {
 
+int vxh_inspect_vxa_buffer(const char* xml, size_t len, int variant, vxh_model_info* out, char* errbuf, size_t errcap)
+{
+    if (!xml || !out || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;
+    auto fail = [&](int code, const char* what) {
+        if (errbuf && errcap) { std::strncpy(errbuf, what, errcap - 1); errbuf[errcap - 1] = 0; }
+        return code;
+    };
+    try {
+        vxh::VxaModel vxa = vxh::read_vxa(xml, len, variant);
+        if (!vxa.unsupported.empty()) return fail(VXH_ERR_UNSUPPORTED, vxa.unsupported.front().c_str());
+        vxh::RobotModel m = vxh::build_robot(vxa);
+        std::memset(out, 0, sizeof(*out));
+        out->nvox = m.nvox; out->nbond = m.nbond; out->nsurf = m.nsurf;
+        out->n_vox_classes = (int)m.vox_classes.size(); out->n_bond_classes = (int)m.bond_classes.size();
+        out->opt_dt = m.opt_dt; out->dt = m.dt; out->planned_steps = m.planned_steps;
+        out->alg_bytes_per_step = 224.0 * m.nvox + 144.0 * m.nbond;
+        return VXH_OK;
+    } catch (const std::exception& ex) {
+        return fail(VXH_ERR_PARSE, ex.what());
+    }
+}
+
 int vxh_create(vxh_engine** out, int variant, int device_id)
 {
     if (!out || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;

@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_num_robots", "vxh_robot_dims",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_counters", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version"]
@@ -53,6 +53,13 @@ class VxhCounters(ctypes.Structure):
                 ("dominant_alg_bytes", ctypes.c_double), ("dominant_voxel_steps", ctypes.c_double)]
 
 
+class VxhModelInfo(ctypes.Structure):
+    _fields_ = [("nvox", ctypes.c_int), ("nbond", ctypes.c_int), ("nsurf", ctypes.c_int),
+                ("n_vox_classes", ctypes.c_int), ("n_bond_classes", ctypes.c_int), ("reserved", ctypes.c_int),
+                ("opt_dt", ctypes.c_double), ("dt", ctypes.c_double), ("planned_steps", ctypes.c_longlong),
+                ("alg_bytes_per_step", ctypes.c_double)]
+
+
 class VxhError(RuntimeError):
     def __init__(self, status, message):
         RuntimeError.__init__(self, "libvxhip status %d: %s" % (status, message))
@@ -82,6 +89,8 @@ def load_library():
                       "(there is no CPU fallback)" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     P, I, D, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_longlong
+    lib.vxh_inspect_vxa_buffer.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, ctypes.POINTER(VxhModelInfo),
+                                           ctypes.c_char_p, ctypes.c_size_t]
     lib.vxh_create.argtypes = [ctypes.POINTER(P), I, I]
     lib.vxh_destroy.argtypes = [P]
     lib.vxh_destroy.restype = None
@@ -106,6 +115,21 @@ def load_library():
     lib.vxh_version.restype = ctypes.c_char_p
     _lib = lib
     return lib
+
+
+def inspect_vxa(text_or_path, variant=VOXCAD):
+    """Host-only model summary of a .vxa (works without a GPU): counts, dt, planned step count."""
+    lib = load_library()
+    if os.path.exists(text_or_path):
+        with open(text_or_path, "rb") as handle:
+            raw = handle.read()
+    else:
+        raw = text_or_path.encode("latin-1") if isinstance(text_or_path, str) else text_or_path
+    info, err = VxhModelInfo(), ctypes.create_string_buffer(512)
+    rc = lib.vxh_inspect_vxa_buffer(raw, len(raw), variant, ctypes.byref(info), err, len(err))
+    if rc != 0:
+        raise VxhError(rc, "%s (%s)" % (lib.vxh_strerror(rc).decode(), err.value.decode()))
+    return info
 
 
 class Engine(object):

@@ -85,6 +85,17 @@ typedef struct vxh_counters {
     double dominant_voxel_steps;
 } vxh_counters;
 
+/* Host-only view of what Import() would build for a .vxa (no device needed): voxel/bond/surface counts in the
+ * reference's ordering, OptimalDt (CalcMaxDt, VX/VX_Sim.cpp:1693-1727), dt = DtFrac*OptimalDt and the number of
+ * TimeStep() calls the reference main loop would make (voxelyzeMain/main.cpp:89-111 with StopConditionMet). */
+typedef struct vxh_model_info {
+    int nvox, nbond, nsurf, n_vox_classes, n_bond_classes, reserved;
+    double opt_dt, dt;
+    long long planned_steps;
+    double alg_bytes_per_step;   /* 224*nvox + 144*nbond */
+} vxh_model_info;
+int  vxh_inspect_vxa_buffer(const char* xml, size_t len, int variant, vxh_model_info* out, char* errbuf, size_t errcap);
+
 int  vxh_create(vxh_engine** out, int variant, int device_id);
 void vxh_destroy(vxh_engine* e);
 

@@ -1,0 +1,82 @@
+"""The C-ABI shared library: loads, exports every symbol include/vxhip.h declares, fails loudly without a GPU,
+and its host-side model builder agrees with the oracle and the reference (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from evosoro_amd import engine
+from oracle import vxoracle as vo
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "example_1", "example_phaseoffset"]
+
+
+def _declared_functions():
+    text = open(os.path.join(REPO, "include", "vxhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vxh_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = engine.load_library()
+    declared = _declared_functions()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), "libvxhip.so does not export %s" % name
+    assert sorted(engine.EXPORTS) == declared
+    assert b"gfx950" in lib.vxh_version()
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(engine.VxhError) as err:
+        engine.Engine(engine.VOXCAD, 0)
+    assert err.value.status == -2          # VXH_ERR_NO_DEVICE: the product path has no CPU implementation
+
+
+def test_result_struct_layout_matches_header():
+    # field order/types of the ctypes mirrors vs the C declarations (catches silent ABI drift)
+    text = open(os.path.join(REPO, "include", "vxhip.h")).read()
+    body = text[text.index("typedef struct vxh_result {"):text.index("} vxh_result;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"(?:int|double|long long)\s+([^;]+);", body):
+        for item in decl.split(","):
+            names.append(item.strip().split("[")[0])
+    assert names == [n for n, _ in engine.VxhResult._fields_]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_host_model_matches_oracle_and_reference(golden_dir, name):
+    path = os.path.join(golden_dir, "vxa", name + ".vxa")
+    info = engine.inspect_vxa(path)
+    sim = vo.OracleSim.from_vxa(path)
+    oi = sim.info()
+    assert (info.nvox, info.nbond, info.nsurf) == (oi.nvox, oi.nbond, oi.nsurf)
+    assert info.opt_dt == oi.opt_dt                      # CalcMaxDt bitwise
+    trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".early.bin"))
+    assert info.opt_dt == trace["opt_dt"] and info.nbond == trace["nbond"]
+    final = os.path.join(golden_dir, "expected", name + ".final.bin")
+    if os.path.exists(final):                            # the planner replays CurTime += dt exactly like the reference
+        assert info.planned_steps == vo.read_trace(final)["total_steps"]
+    assert info.alg_bytes_per_step == 224.0 * info.nvox + 144.0 * info.nbond
+
+
+def test_reader_rejects_bad_input():
+    with pytest.raises(engine.VxhError) as err:
+        engine.inspect_vxa("<VXA><Simulator></Simulator>")
+    assert err.value.status == -3
+    good = open(os.path.join(REPO, "tests", "golden", "vxa", "phase4.vxa")).read()
+    with pytest.raises(engine.VxhError) as err:      # features outside the supported scope are refused, not ignored
+        engine.inspect_vxa(good.replace("<NumFixed>0</NumFixed>", "<NumFixed>1</NumFixed>"))
+    assert err.value.status == -7
+    with pytest.raises(engine.VxhError):
+        engine.inspect_vxa(good.replace('Compression="ASCII_READABLE"', 'Compression="ZLIB"'))
+    empty = re.sub(r"<!\[CDATA\[[0-9]+\]\]>", lambda m: "<![CDATA[" + "0" * (len(m.group(0)) - 12) + "]]>", good, count=4)
+    info = engine.inspect_vxa(re.sub(r"<PhaseOffset>.*?</PhaseOffset>", "", empty, flags=re.S))
+    assert info.nvox == 0 and info.nbond == 0        # an empty robot is representable (status EMPTY at run time)

@@ -1,11 +1,19 @@
-"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle and the reference's golden outputs.
+"""GPU parity (-m gpu): the HIP engine, called through the C ABI, against the CPU oracle (itself bit-exact with
+the reference C++, tests/test_oracle_vs_reference.py) and against the reference's golden outputs.
 
-Tolerances (FP64 on both sides; differences come only from device libm ulps and FMA contraction):
-  * first 200 steps: positions within 1e-9 voxel, quaternions within 1e-9
-  * whole runs (0.2-0.5 s of simulated time, thousands of steps, friction/contact discontinuities amplify
-    ulp noise): CoM displacement within 2e-3 voxel of the reference, result tags to that accuracy
+Stated FP tolerance.  Both sides compute in FP64; the engine differs from the reference only by device-libm ulps,
+FMA contraction and the order of a few sums, i.e. by perturbations of relative size ~1e-16 per operation.  How far
+such perturbations grow is a property of the ROBOT, not of the implementation: most robots are well conditioned
+(errors stay ~1e-14 voxel over thousands of steps) but some amplify any perturbation by ~2x per step through
+stick-slip contact until it saturates around 1e-3 voxel (golden case "phase4": the reference algorithm itself,
+fed a gravity constant changed by ONE ulp, moves its final centre of mass by 2.5e-3 voxel).  The bar is therefore
+    error(engine, oracle)  <=  max(1e-9 voxel, 20 x spread)
+where `spread` is the largest deviation, over the compared horizon (plus a margin: the onset of the exponential
+growth depends on the size of the first perturbation), between the oracle and the oracle with 1-ulp-perturbed
+gravity, measured alongside on the CPU.  Well-conditioned robots thus get the 1e-9 voxel bar at every step.
 """
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -13,6 +21,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4"]
+FLOOR_VOX = 1e-9
 
 
 @pytest.fixture(scope="module")
@@ -21,23 +30,52 @@ def eng_mod():
     return engine
 
 
+def _perturbed(model):
+    twin = dict(model)
+    twin["grav_acc"] = model["grav_acc"] * (1 + 4e-16)
+    return twin
+
+
+def _pos_err(a, b, lat):
+    return np.abs(a[:, 0:3] - b[:, 0:3]).max() / lat
+
+
+def _spread(model, checkpoints):
+    """max position / quaternion deviation of the 1-ulp-perturbed oracle run over the given step counts"""
+    from oracle import vxoracle as vo
+    a, b = vo.OracleSim(model), vo.OracleSim(_perturbed(model))
+    pos = quat = 0.0
+    for upto in checkpoints:
+        a.step(upto - a.info().steps)
+        b.step(upto - b.info().steps)
+        sa, sb = a.state(), b.state()
+        pos = max(pos, _pos_err(sa, sb, model["lattice_dim"]))
+        quat = max(quat, np.abs(sa[:, 3:7] - sb[:, 3:7]).max())
+    return pos, quat
+
+
 def test_early_steps_match_oracle(eng_mod, golden_dir):
     from oracle import vxoracle as vo
+    models = [vo.parse_vxa(os.path.join(golden_dir, "vxa", n + ".vxa")) for n in CASES]
+    sims = [vo.OracleSim(m) for m in models]
+    spreads = [_spread(m, (50, 100, 200, 300, 400)) for m in models]
     with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
-        for name in CASES:
-            eng.add_vxa_file(os.path.join(golden_dir, "vxa", name + ".vxa"))
-        sims = [vo.OracleSim.from_vxa(os.path.join(golden_dir, "vxa", name + ".vxa")) for name in CASES]
+        for n in CASES:
+            eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))
         done = 0
         for upto in (1, 2, 10, 50, 200):
             eng.step(upto - done)
             done = upto
-            for i, (name, sim) in enumerate(zip(CASES, sims)):
-                sim.step(upto - sim.info().steps)
-                want, got = sim.state(), eng.state(i)
-                lat = sim.model["lattice_dim"]
-                assert np.abs(got[:, 0:3] - want[:, 0:3]).max() / lat < 1e-9, (name, upto)
-                assert np.abs(got[:, 3:7] - want[:, 3:7]).max() < 1e-9, (name, upto)
-                assert np.abs(got[:, 7] - want[:, 7]).max() / lat < 1e-12, (name, upto)
+            for i, name in enumerate(CASES):
+                sims[i].step(upto - sims[i].info().steps)
+                want, got = sims[i].state(), eng.state(i)
+                lat = models[i]["lattice_dim"]
+                tol = FLOOR_VOX if upto <= 10 else max(FLOOR_VOX, 20 * spreads[i][0])
+                qtol = 1e-9 if upto <= 10 else max(1e-9, 20 * spreads[i][1])
+                assert _pos_err(got, want, lat) <= tol, (name, upto, _pos_err(got, want, lat), tol)
+                assert np.abs(got[:, 3:7] - want[:, 3:7]).max() <= qtol, (name, upto)
+                assert np.abs(got[:, 7] - want[:, 7]).max() / lat < 1e-12, (name, upto)   # actuation: no chaos involved
+        assert sum(1 for sp in spreads if sp[0] < 1e-10) >= 4     # the strict 1e-9 bar really applied to 4 of 5 robots
 
 
 def test_full_runs_match_reference(eng_mod, golden_dir):
@@ -47,14 +85,126 @@ def test_full_runs_match_reference(eng_mod, golden_dir):
             eng.add_vxa_file(os.path.join(golden_dir, "vxa", name + ".vxa"))
         eng.run()
         for i, name in enumerate(CASES):
+            model = vo.parse_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"))
+            lat = model["lattice_dim"]
+            planned = eng.dims(i)["planned_steps"]
+            spread = _spread(model, sorted(set([planned // 4, planned // 2, 3 * planned // 4, planned])))[0]
+            tol = max(FLOOR_VOX, 20 * spread)
             trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".final.bin"))
             want = vo.read_result_xml(os.path.join(golden_dir, "expected", name + ".xml"))
             res = eng.result(i)
-            lat = vo.parse_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"))["lattice_dim"]
             assert res.status == eng_mod.ROBOT_FINISHED
             assert res.steps == trace["total_steps"], name
-            assert np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / lat < 2e-3, name
-            assert np.abs(np.array(res.ini_cm) - trace["ini_cm"]).max() / lat < 2e-3, name
-            assert abs(res.norm_final_dist - want["NormFinalDist"]) < 2e-3, name
-            assert abs(res.final_dist_y - want["finalDistY"]) < 2e-3, name
+            assert np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / lat <= tol, (name, tol)
+            assert np.abs(np.array(res.ini_cm) - trace["ini_cm"]).max() / lat <= tol, (name, tol)
+            # result tags: 6 significant digits like the reference, up to the robot's own conditioning
+            for tag, val in (("NormFinalDist", res.norm_final_dist), ("finalDistY", res.final_dist_y),
+                             ("AnteriorDist", res.anterior_dist), ("PosteriorY", res.posterior_y)):
+                # (the golden XML carries 6 significant digits: up to 5e-6 relative rounding)
+                assert abs(val - want[tag]) <= 2 * tol + 1e-5 * abs(want[tag]), (name, tag, val, want[tag])
             assert abs(res.lifetime - want["Lifetime"]) < 1e-5, name
+            if tol < 1e-6:
+                assert res.num_touching_floor == want["NumTouchingFloor"], name
+
+
+def test_cli_writes_reference_xml(eng_mod, golden_dir, tmp_path):
+    """`voxelyze -f x.vxa` drop-in: exit code 1, result XML at <FitnessFileName>, same tags, same 6-digit numbers."""
+    from oracle import vxoracle as vo
+    os.makedirs(tmp_path / "golden_run" / "fitnessFiles")
+    names = ["probe6", "rand6_col"]
+    args = []
+    for n in names:
+        args += ["-f", os.path.join(golden_dir, "vxa", n + ".vxa")]
+    proc = subprocess.run([eng_mod.CLI_PATH] + args, cwd=tmp_path, timeout=600)
+    assert proc.returncode == 1                      # the reference's "success" code (main.cpp:132)
+    ids = {"probe6": 0, "rand6_col": 2}
+    for n in names:
+        got_path = tmp_path / "golden_run" / "fitnessFiles" / ("softbotsOutput--id_%05i.xml" % ids[n])
+        got_lines = open(got_path).read().splitlines()
+        want_lines = open(os.path.join(golden_dir, "expected", n + ".xml")).read().splitlines()
+        assert len(got_lines) == len(want_lines)
+        got, want = vo.read_result_xml(str(got_path)), vo.read_result_xml(os.path.join(golden_dir, "expected", n + ".xml"))
+        assert list(got) == list(want)
+        for tag in want:
+            assert abs(got[tag] - want[tag]) <= 1e-5 * max(1.0, abs(want[tag])), (n, tag)
+        # well-conditioned robots: the fitness line is byte-identical
+        assert [l for l in got_lines if "NormFinalDist" in l] == [l for l in want_lines if "NormFinalDist" in l]
+
+
+def test_streaming_path_matches_fused_path(eng_mod, golden_dir):
+    names = ["probe6", "rand6_col", "soft5_init0"]
+    states = {}
+    for fused in (1, 0):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("fused", fused)
+            for n in names:
+                eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))
+            eng.step(300)
+            states[fused] = [eng.state(i) for i in range(len(names))]
+    for a, b in zip(states[1], states[0]):
+        assert np.abs(a[:, :8] - b[:, :8]).max() < 1e-12       # same kernels' math, different force-sum order
+
+
+def test_large_lattice_streaming_vs_oracle(eng_mod, tmp_path):
+    """BASELINE configs[4]: one full 20x20x20 lattice with self-collision (more voxels than a workgroup holds)."""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    ind = workloads.make_individual(0, workloads.full_material(20, 1))
+    write_voxelyze_file(Sim(dt_frac=0.9, simulation_time=0.01, fitness_eval_init_time=0.002), Env(), ind, str(tmp_path), "big")
+    path = str(tmp_path / "voxelyzeFiles" / "big--id_00000.vxa")
+    sim = vo.OracleSim.from_vxa(path)
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.add_vxa_file(path)
+        assert eng.dims(0)["nvox"] == 8000 and eng.dims(0)["nbond"] == 22800
+        for upto in (1, 20, 60):
+            eng.step(upto - sim.info().steps)
+            sim.step(upto - sim.info().steps)
+            assert _pos_err(eng.state(0), sim.state(), 0.01) < 1e-9, upto
+        eng.run()
+        sim.step(-1)
+        res = eng.result(0)
+        assert res.status == eng_mod.ROBOT_FINISHED and res.steps == sim.info().steps == 157
+        assert np.abs(np.array(res.cur_cm) - np.array(sim.info().cur_cm)).max() / 0.01 < 1e-8
+
+
+def test_full_size_batch_properties(eng_mod, tmp_path):
+    """BASELINE configs[1]/[2] sizes: properties that need no CPU reference at scale.
+    (a) a robot's trajectory does not depend on which batch it is in or where (bitwise), (b) reruns are bitwise
+    reproducible, (c) a sample of robots agrees with the oracle, (d) every robot finishes with finite state."""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim, env = Sim(dt_frac=0.9, simulation_time=0.012, fitness_eval_init_time=0.004), Env()
+    paths = []
+    for i, shape in [(k, (6, 6, 6)) for k in range(64)] + [(64 + k, (10, 10, 10)) for k in range(128)]:
+        ind = workloads.random_robot(i, shape, i)
+        write_voxelyze_file(sim, env, ind, str(tmp_path), "p")
+        paths.append(str(tmp_path / "voxelyzeFiles" / ("p--id_%05i.vxa" % i)))
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        for p in paths:
+            eng.add_vxa_file(p)
+        eng.run()
+        batch = {i: eng.state(i) for i in (0, 63, 64, 100, 191)}
+        results = [eng.result(i) for i in range(len(paths))]
+        assert all(r.status == eng_mod.ROBOT_FINISHED for r in results)
+        assert all(np.isfinite(r.cur_cm).all() and np.isfinite(r.norm_final_dist) for r in results)
+        eng.reset()
+        eng.run()
+        for i, st in batch.items():
+            assert np.array_equal(st, eng.state(i)), "rerun differs for robot %d" % i
+    for i, st in batch.items():
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as solo:
+            solo.add_vxa_file(paths[i])
+            solo.run()
+            assert np.array_equal(st, solo.state(0)), "robot %d depends on its batch" % i
+    for i in (0, 64):
+        o = vo.OracleSim.from_vxa(paths[i])
+        o.step(-1)
+        tol = max(FLOOR_VOX, 20 * _spread(o.model, (results[i].steps // 2, results[i].steps))[0])
+        assert _pos_err(batch[i], o.state(), 0.01) <= tol
+        assert results[i].steps == o.info().steps

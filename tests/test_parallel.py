@@ -1,0 +1,44 @@
+"""Population sharding + fitness gather on CPU (gloo, world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from evosoro_amd import parallel
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_by_cost_is_balanced_and_deterministic():
+    rng = np.random.RandomState(0)
+    costs = rng.uniform(1, 10, size=64) * rng.choice([1, 10], size=64)
+    shards = parallel.shard_by_cost(costs, 8)
+    assert sorted(i for s in shards for i in s) == list(range(64))
+    loads = [sum(costs[i] for i in s) for s in shards]
+    assert max(loads) / (sum(loads) / 8) < 1.1
+    assert shards == parallel.shard_by_cost(costs, 8)
+    assert parallel.shard_by_cost([], 4) == [[], [], [], []]
+    assert parallel.shard_round_robin(5, 2) == [[0, 2, 4], [1, 3]]
+
+
+def test_gather_without_process_group():
+    recs = np.arange(2 * parallel.RECORD_LEN, dtype=np.float64).reshape(2, -1)
+    table = parallel.gather_records(recs, [2, 0], 3)
+    assert (table[2] == recs[0]).all() and (table[0] == recs[1]).all() and (table[1] == 0).all()
+
+
+def test_two_rank_gloo_run(tmp_path, golden_dir):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=REPO)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29613", os.path.join(REPO, "tests", "dist_worker.py"), str(tmp_path),
+           os.path.join(golden_dir, "vxa")]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert proc.returncode == 0, proc.stdout.decode()[-3000:]
+    t0, t1 = np.load(tmp_path / "table_rank0.npy"), np.load(tmp_path / "table_rank1.npy")
+    assert np.array_equal(t0, t1)                        # every rank holds the full table
+    assert t0.shape == (5, parallel.RECORD_LEN)
+    assert np.array_equal(t0[0], t0[3]) and np.array_equal(t0[1], t0[4])   # same robot -> same record, whichever rank ran it
+    assert [int(s) for s in t0[:, 0]] == [1] * 5 and [int(n) for n in t0[:, 2]] == [57, 96, 143, 57, 96]
+    k = parallel.RECORD_FIELDS.index("norm_final_dist")
+    assert "%.6g" % t0[2, k] == "0.0412909"              # reference value of rand6_nocol (tests/golden/expected)
