@@ -22,6 +22,7 @@ enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_ST
 struct DRobot {               // constant per robot
     int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr, pad0;
     long long excl_begin;     // first word of this robot's exclusion rows in DBatch::excl
+    int vert_begin, nmv;      // drag-mesh vertices of this robot (fluid robots)
     double dt, lat, bond_z_half, slow_z, col_z, grav_acc;
     double init_cm_time, stop_value, afterlife, temp_period_d;
     double min_temp_fact, growth_amplitude, col_horizon, filter_dist2, drag_coef;
@@ -36,12 +37,13 @@ struct DRobotState {          // mutable per robot
     int steps, status, cm_init, active, diverged, col_overflow, rebuild_now, rebuilds;
 };
 
-enum { VXH_MAXCOL = 64 };     // collision partners kept per surface voxel (overflow -> VXH_ROBOT_COL_OVERFLOW)
+enum { VXH_MAXCOL = 64, VXH_LDS_BCLASS = 32, VXH_LDS_VCLASS = 16 };     // collision partners kept per surface voxel (overflow -> VXH_ROBOT_COL_OVERFLOW)
 
 // all device pointers of a batch; passed to kernels by value
 struct DBatch {
     int n_robots, nv;                 // nv = total padded voxel slots (multiple of 64 per robot)
-    int dbg, pad1;                    // developer switches (scripts/gpu_diag.py), 0 in production
+    int dbg, pad1;
+    int n_vclass, n_bclass;           // entries in the class tables                    // developer switches (scripts/gpu_diag.py), 0 in production
     const DRobot* robot;
     DRobotState* rstate;
     const int* wave_robot;            // [nv/64] robot of each 64-voxel group
@@ -71,6 +73,14 @@ struct DBatch {
     int col_rows, pad2;               // total surface voxels of colliding robots
     int* col_partner;                 // [VXH_MAXCOL][col_rows] (partner-major) global voxel slots
     double* col_a1;                   // same shape: linear stiffness a1 of that collision bond
+    // land_water fluid drag (LW/VX_Sim.cpp:1516-1597): deformable surface mesh of every fluid robot
+    int total_mv, pad3;               // mesh vertices of all fluid robots
+    const int* vert_comp;             // [8][total_mv] contributing (voxel slot * 8 + corner code) or -1
+    const double* vert_v0;            // [3][total_mv] rest position
+    const int* corner_vert;           // [8][nv] robot-local mesh vertex at each corner of the voxel or -1
+    const unsigned char* open_face;   // [nv] exposed faces PX,NX,PY,NY,PZ,NZ
+    double* strain;                   // [6][nv] StrainPosDirsCur xyz, StrainNegDirsCur xyz (fluid robots only)
+    double* dragf;                    // [3][nv] DragForce of the current step
     // constants from Vec3D.h evaluated by the host libm (thresholds of the small-angle logic)
     double small_angle_w, smallish_angle_w, slthresh_acos2sqrt;
 };

@@ -181,6 +181,14 @@ void Engine::prepare()
     std::vector<float> phase(nv, 0.f), amp_damp(nv, 1.f);
     std::vector<double> px(nv, 0), py(nv, 0), pz(nv, 0), sc(nv, 0), qw(nv, 1.0);
     std::vector<unsigned char> small((size_t)3 * nv, 1);
+    // land_water fluid robots: drag mesh
+    int total_mv = 0;
+    std::vector<int> mv_begin(nr, 0);
+    bool any_fluid = false;
+    for (int r = 0; r < nr; ++r) { mv_begin[r] = total_mv; total_mv += robots_[r].nmv; any_fluid = any_fluid || robots_[r].nmv > 0; }
+    std::vector<int> vert_comp((size_t)8 * std::max(total_mv, 1), -1), corner_vert(any_fluid ? (size_t)8 * nv : 8, -1);
+    std::vector<double> vert_v0((size_t)3 * std::max(total_mv, 1), 0.0);
+    std::vector<unsigned char> open_face(any_fluid ? nv : 1, 0);
     std::vector<DRobotState> rstate(nr);
 
     for (int r = 0; r < nr; ++r) {
@@ -245,6 +253,22 @@ void Engine::prepare()
                   ((variant_ == 1 && X.fluid_env) ? RF_FLUID : 0) | (variant_ == 1 ? RF_LW : 0) |
                   ((X.col_system == 2 || X.col_system == 3) ? RF_HORIZON_COL : 0);
         R.stop_type = X.stop_type; R.excl_wpr = wpr; R.excl_begin = excl_begin;
+        R.vert_begin = mv_begin[r]; R.nmv = M.nmv;
+        if (M.nmv > 0) {
+            if (M.nvox > 1024 || !fused_) throw std::invalid_argument("unsupported: fluid drag needs the fused path (robots of at most 1024 voxels)");
+            const size_t tm = (size_t)std::max(total_mv, 1);
+            for (int i = 0; i < M.nmv; ++i) {
+                for (int q = 0; q < 8; ++q) {
+                    const int c = M.vert_comp[(size_t)i * 8 + q];
+                    vert_comp[q * tm + mv_begin[r] + i] = c < 0 ? -1 : (base + (c >> 3)) * 8 + (c & 7);
+                }
+                for (int k = 0; k < 3; ++k) vert_v0[k * tm + mv_begin[r] + i] = M.vert_v0[(size_t)i * 3 + k];
+            }
+            for (int v = 0; v < M.nvox; ++v) {
+                for (int c = 0; c < 8; ++c) corner_vert[(size_t)c * nv + base + v] = M.corner_vert[(size_t)v * 8 + c];
+                open_face[base + v] = M.open_face[v];
+            }
+        }
         R.dt = M.dt; R.lat = X.lattice_dim; R.bond_z_half = 0.5 * X.bond_damping_z; R.slow_z = X.slow_damping_z; R.col_z = X.col_damping_z;
         R.grav_acc = X.grav_acc; R.init_cm_time = X.init_cm_time; R.stop_value = X.stop_value;
         R.afterlife = variant_ == 0 ? X.afterlife_time : 0.0;
@@ -263,6 +287,7 @@ void Engine::prepare()
     B.robot = D.upload(D.h_robot);
     B.rstate = D.upload(rstate);
     B.wave_robot = D.upload(wave_robot);
+    B.n_vclass = (int)vtab.size(); B.n_bclass = (int)btab.size();
     B.vclass_tab = D.upload(vtab);
     B.bclass_tab = D.upload(btab);
     B.vclass = D.upload(vclass);
@@ -287,6 +312,13 @@ void Engine::prepare()
     B.surf = D.upload(surf);
     B.surf_ord = D.upload(surf_ord);
     B.excl = D.upload(excl);
+    B.total_mv = std::max(total_mv, 1);
+    B.vert_comp = D.upload(vert_comp);
+    B.vert_v0 = D.upload(vert_v0);
+    B.corner_vert = D.upload(corner_vert);
+    B.open_face = D.upload(open_face);
+    B.strain = D.alloc_zero<double>(any_fluid ? (size_t)6 * nv : 1);
+    B.dragf = D.alloc_zero<double>(any_fluid ? (size_t)3 * nv : 1);
     B.col_rows = std::max(ns, 1);
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);

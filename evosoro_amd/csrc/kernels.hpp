@@ -103,10 +103,34 @@ __device__ __forceinline__ int robot_of(const DBatch& B, int vslot)
     return __builtin_amdgcn_readfirstlane(B.wave_robot[vslot >> 6]);
 }
 
-struct BondOut { d3 f1, m1, f2, m2; bool diverged; };
+struct BondOut { d3 f1, m1, f2, m2; double strain1, strain2; bool diverged; };
+// history of one bond (_LastPos2, _LastAngle1, _LastAngle2 + the small-angle flag); loaded by the caller BEFORE the
+// arithmetic and stored after it, so that all memory operations of a bond are issued together (the kernels are
+// latency-bound: 70% of wave time was s_waitcnt with loads scattered through the math)
+struct BondHist { d3 pos2, ang1, ang2; bool small; bool store_hist, store_flag; };
 
-// One internal bond between voxel 1 (negative side) and voxel 2, `slot` = axis*nv + voxel-1 slot addresses its history.
-__device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClass& C, int axis, int slot,
+__device__ __forceinline__ BondHist load_bond_hist(const DBatch& B, int slot)
+{
+    BondHist h;
+    h.pos2 = mk3(HIST(0, slot), HIST(1, slot), HIST(2, slot));
+    h.ang1 = mk3(HIST(3, slot), HIST(4, slot), HIST(5, slot));
+    h.ang2 = mk3(HIST(6, slot), HIST(7, slot), HIST(8, slot));
+    h.small = B.small_angle[slot] != 0;
+    h.store_hist = h.store_flag = false;
+    return h;
+}
+__device__ __forceinline__ void store_bond_hist(const DBatch& B, int slot, const BondHist& h)
+{
+    if (h.store_hist) {
+        HIST(0, slot) = h.pos2.x; HIST(1, slot) = h.pos2.y; HIST(2, slot) = h.pos2.z;
+        HIST(3, slot) = h.ang1.x; HIST(4, slot) = h.ang1.y; HIST(5, slot) = h.ang1.z;
+        HIST(6, slot) = h.ang2.x; HIST(7, slot) = h.ang2.y; HIST(8, slot) = h.ang2.z;
+    }
+    if (h.store_flag) B.small_angle[slot] = h.small ? 1 : 0;
+}
+
+// One internal bond between voxel 1 (negative side) and voxel 2: pure arithmetic, `H` in/out.
+__device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClass& C, int axis, BondHist& H,
                                                 d3 p1, dq q1, double s1, d3 p2, dq q2, double s2,
                                                 double dt_prev, double bond_z_half)
 {
@@ -118,12 +142,12 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     dq new2 = qmul(conj(a1), a2);
 
     // small/large-angle switch with hysteresis (VXS_BondInternal.cpp:72-77)
-    bool small = B.small_angle[slot] != 0, changed = false;
+    bool small = H.small, changed = false;
     const double small_turn = (fabs(rel.z) + fabs(rel.y)) / rel.x;
     const double extend = rel.x / nom_dist;
     if (!small && new2.w > B.small_angle_w && small_turn < VXH_SA_BOND_BEND_RAD && extend < VXH_SA_BOND_EXT_PERC) { small = true; changed = true; }
     else if (small && (!(new2.w > B.smallish_angle_w) || small_turn > VXH_HYST * VXH_SA_BOND_BEND_RAD || extend > VXH_HYST * VXH_SA_BOND_EXT_PERC)) { small = false; changed = true; }
-    if (changed) B.small_angle[slot] = small ? 1 : 0;
+    H.small = small; H.store_flag = changed;
 
     d3 pos2, ang1, ang2;
     dq rot;
@@ -143,6 +167,7 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     // axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307; linear materials)
     const double strain = pos2.x / C.L;
     double stress;
+    o.strain1 = o.strain2 = strain;            // CurStrainV1 / CurStrainV2 (SetStrainDir), read by the land_water drag mesh
     if (C.homogeneous) stress = C.stress_E1 * strain;
     else {
         double e1 = strain, e2 = strain, t1 = C.stress_E1 * e1, t2 = C.stress_E2 * e2;
@@ -154,6 +179,7 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
             diff = fabs(t1 - t2); sum = fabs(t1 + t2);
         }
         stress = (t1 + t2) / 2;
+        o.strain1 = e1; o.strain2 = e2;
     }
     o.diverged = strain > 100;                 // VX_Sim.cpp:1775
 
@@ -168,9 +194,7 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     if (!changed) {
         if (dt_prev != 0) {
             const double inv = 1.0 / dt_prev;
-            d3 v = mk3((pos2.x - HIST(0, slot)) * inv, (pos2.y - HIST(1, slot)) * inv, (pos2.z - HIST(2, slot)) * inv);
-            d3 w1 = mk3((ang1.x - HIST(3, slot)) * inv, (ang1.y - HIST(4, slot)) * inv, (ang1.z - HIST(5, slot)) * inv);
-            d3 w2 = mk3((ang2.x - HIST(6, slot)) * inv, (ang2.y - HIST(7, slot)) * inv, (ang2.z - HIST(8, slot)) * inv);
+            d3 v = (pos2 - H.pos2) * inv, w1 = (ang1 - H.ang1) * inv, w2 = (ang2 - H.ang2) * inv;
             const double z = bond_z_half;
             f1 = f1 + mk3(C.sq_a1m1 * v.x, C.sq_b1m1 * v.y - C.sq_b2fm1 * (w1.z + w2.z), C.sq_b1m1 * v.z + C.sq_b2fm1 * (w1.y + w2.y)) * z;
             if (!C.homogeneous)
@@ -178,9 +202,7 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
             m1 = m1 + mk3(-C.sq_a2i1 * (w2.x - w1.x), C.sq_b2fm1 * v.z + C.sq_b3i1 * (2 * w1.y + w2.y), -C.sq_b2fm1 * v.y + C.sq_b3i1 * (2 * w1.z + w2.z)) * (0.5 * z);
             m2 = m2 + mk3(C.sq_a2i2 * (w2.x - w1.x), C.sq_b2fm2 * v.z + C.sq_b3i2 * (w1.y + 2 * w2.y), -C.sq_b2fm2 * v.y + C.sq_b3i2 * (w1.z + 2 * w2.z)) * (0.5 * z);
         }
-        HIST(0, slot) = pos2.x; HIST(1, slot) = pos2.y; HIST(2, slot) = pos2.z;
-        HIST(3, slot) = ang1.x; HIST(4, slot) = ang1.y; HIST(5, slot) = ang1.z;
-        HIST(6, slot) = ang2.x; HIST(7, slot) = ang2.y; HIST(8, slot) = ang2.z;
+        H.pos2 = pos2; H.ang1 = ang1; H.ang2 = ang2; H.store_hist = true;
     }
 
     // back to the global frame (:158-171)
@@ -196,7 +218,7 @@ struct VoxState { d3 pos, lm, am; dq ang; double scale; };
 // Everything of EulerStep after the internal-bond sums: collision bonds, gravity, floor, integration, actuation.
 // F/M arrive holding slow damping + internal bond forces / minus internal bond moments.  Returns |new velocity|^2.
 __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, int cur,
-                                               double t, d3 F, d3 M, d3 vel, VoxState& S, int row, int ccnt)
+                                               double t, d3 F, d3 M, d3 vel, VoxState& S, int row, int ccnt, d3 drag)
 {
     const int flags = R.flags;
     const double dt = R.dt;
@@ -236,6 +258,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
         }
     }
     if ((flags & RF_GRAV) && !fluid) F.z += C.mass * R.grav_acc;
+    if (fluid) F = F + drag;                  // LW/VXS_Voxel.cpp:372-373
 
     if ((flags & RF_FLOOR) && !fluid) {       // CalcFloorEffect, VXS_Voxel.cpp:708-758
         const double pen = 0.5 * S.scale - S.pos.z;
@@ -433,6 +456,76 @@ __device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, D
     }
 }
 
+// land_water fluid drag (LW/VX_Sim.cpp:1516-1597).  Phase 1: every deformable surface vertex = mean over the <= 7 voxels
+// touching that lattice corner of Pos + R(Angle) * corner offset, corner offsets from the bond strains of the PREVIOUS step
+// (CornerPosCur/CornerNegCur, LW/VXS_Voxel.cpp:472-475; GetCurVLoc LW/VX_MeshUtil.cpp:388-428) -> LDS.  Phase 2: every voxel
+// sums the quadratic drag of the two triangles on each of its exposed faces, in the reference's facet order.
+__device__ __forceinline__ d3 rot_fwd(dq q, d3 f)      // CQuat::RotateVec3D, Vec3D.h:293-299
+{
+    double tw = f.x * q.x + f.y * q.y + f.z * q.z;
+    double tx = f.x * q.w - f.y * q.z + f.z * q.y;
+    double ty = f.x * q.z + f.y * q.w - f.z * q.x;
+    double tz = -f.x * q.y + f.y * q.x + f.z * q.w;
+    return mk3(q.w * tx + q.x * tw + q.y * tz - q.z * ty, q.w * ty - q.x * tz + q.y * tw + q.z * tx, q.w * tz + q.x * ty - q.y * tx + q.z * tw);
+}
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 normalized3(d3 a) { const double l = sqrt(len2(a)); return l > 0 ? a * (1.0 / l) : a; }
+
+template <int BLOCK>
+__device__ __forceinline__ void fluid_drag(const DBatch& B, const DRobot& R, int cur, double* sh, bool valid, int v, double mass_inv, double nom)
+{
+    const unsigned nv = B.nv, tm = B.total_mv;
+    for (int i = threadIdx.x; i < R.nmv; i += BLOCK) {
+        const int gi = R.vert_begin + i;
+        d3 avg = mk3(0, 0, 0); double tw = 0;
+        for (int q = 0; q < 8; ++q) {
+            const int comp = B.vert_comp[(unsigned)q * tm + gi];
+            if (comp < 0) break;
+            const int u = comp >> 3, corner = comp & 7;
+            const d3 cp = mk3((1 + B.strain[u]) * nom * 0.5, (1 + B.strain[nv + u]) * nom * 0.5, (1 + B.strain[2 * nv + u]) * nom * 0.5);
+            const d3 cn = mk3(-(1 + B.strain[3 * nv + u]) * nom * 0.5, -(1 + B.strain[4 * nv + u]) * nom * 0.5, -(1 + B.strain[5 * nv + u]) * nom * 0.5);
+            const d3 off = mk3((corner & 4) ? cp.x : cn.x, (corner & 2) ? cp.y : cn.y, (corner & 1) ? cp.z : cn.z);
+            const d3 p = mk3(POS(cur, 0, u), POS(cur, 1, u), POS(cur, 2, u)) + rot_fwd(mkq(QUAT(0, u), QUAT(1, u), QUAT(2, u), QUAT(3, u)), off);
+            avg = avg + p; tw += 1.0;
+        }
+        const double inv = 1.0 / tw;
+        const d3 v0 = mk3(B.vert_v0[gi], B.vert_v0[tm + gi], B.vert_v0[2 * tm + gi]);
+        const d3 np = avg * inv;
+        const d3 now = v0 + (np - v0);                               // v + DrawOffset, as the reference stores it
+        sh[i] = now.x; sh[R.nmv + i] = now.y; sh[2 * R.nmv + i] = now.z;
+    }
+    __syncthreads();
+    if (valid) {
+        d3 drag = mk3(0, 0, 0);
+        const unsigned mask = B.open_face[v];
+        if (mask) {
+            const d3 speed = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v)) * mass_inv;
+            const d3 sdir = normalized3(speed);
+            // corner codes (NNN..PPP) of the two triangles of faces +X,-X,+Y,-Y,+Z,-Z (LW/VX_MeshUtil.cpp:165-189)
+            const unsigned tri[6][2] = {{0x467u, 0x475u}, {0x032u, 0x013u}, {0x237u, 0x276u}, {0x051u, 0x045u}, {0x157u, 0x173u}, {0x064u, 0x026u}};
+            for (int d = 0; d < 6; ++d) {
+                if (!(mask & (1u << d))) continue;
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned code = tri[d][t];
+                    const int ia = B.corner_vert[((code >> 8) & 7u) * nv + v], ib = B.corner_vert[((code >> 4) & 7u) * nv + v], ic = B.corner_vert[(code & 7u) * nv + v];
+                    const d3 A = mk3(sh[ia], sh[R.nmv + ia], sh[2 * R.nmv + ia]);
+                    const d3 AB = mk3(sh[ib], sh[R.nmv + ib], sh[2 * R.nmv + ib]) - A, AC = mk3(sh[ic], sh[R.nmv + ic], sh[2 * R.nmv + ic]) - A;
+                    const d3 cr = cross3(AB, AC);
+                    const double area = fabs(sqrt(len2(cr)) / 2.0);
+                    const d3 n = normalized3(cr);                       // CalcFaceNormals
+                    const float ang = (float)acos(dot3(sdir, normalized3(n)));
+                    if (fabsf(ang) < VXH_PI / 2) {
+                        const d3 proj = normalized3(n) * dot3(speed, n);    // ProjectOnTo
+                        drag = drag + normalized3(proj) * (-R.drag_coef * area * len2(proj));
+                    }
+                }
+            }
+        }
+        B.dragf[v] = drag.x; B.dragf[nv + v] = drag.y; B.dragf[2 * nv + v] = drag.z;
+    }
+}
+
 // ================================================================================================ fused path
 // LDS: exchange buffer ex[axis][component 0..5][BLOCK] doubles (Force2, Moment2 of the bond whose POSITIVE end is
 // voxel `local`), reused as scratch by latch_cm / rebuild_rows.
@@ -453,7 +546,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_steps(DBatch B, co
     const int v = R.vox_begin + tid;
     const int nv = B.nv;
 
-    const DVoxClass& C = B.vclass_tab[valid ? B.vclass[v] : 0];
+    // class-constant tables into LDS (a handful of entries for a whole population): per-lane gathers of ~20 doubles
+    // per bond then cost LDS reads instead of vector-memory loads
+    __shared__ DBondClass s_bct[VXH_LDS_BCLASS];
+    __shared__ DVoxClass s_vct[VXH_LDS_VCLASS];
+    const bool tabs_in_lds = B.n_bclass <= VXH_LDS_BCLASS && B.n_vclass <= VXH_LDS_VCLASS;
+    if (tabs_in_lds) {
+        for (int k = tid; k < B.n_bclass * (int)(sizeof(DBondClass) / 8); k += BLOCK) ((double*)s_bct)[k] = ((const double*)B.bclass_tab)[k];
+        for (int k = tid; k < B.n_vclass * (int)(sizeof(DVoxClass) / 8); k += BLOCK) ((double*)s_vct)[k] = ((const double*)B.vclass_tab)[k];
+    }
+    __syncthreads();
+    const DBondClass* bct = tabs_in_lds ? s_bct : B.bclass_tab;
+    const DVoxClass& C = (tabs_in_lds ? (const DVoxClass*)s_vct : B.vclass_tab)[valid ? B.vclass[v] : 0];
     int row = -1;                              // my row of collision partners (surface voxels of colliding robots)
     if (valid && (R.flags & RF_SELF_COL)) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
 
@@ -469,6 +573,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_steps(DBatch B, co
         if (s_latch || s_eol) latch_cm(B, R, rs, cur, s_latch != 0, s_eol != 0, ex, BLOCK);
         if (s_rebuild) { for (int i0 = 0; i0 < R.nsurf; i0 += BLOCK) rebuild_rows(B, R, rs, cur, i0, ex, 2 * BLOCK); __syncthreads(); }
         const int ccnt = (row >= 0 && !(B.dbg & 1)) ? B.col_cnt[row] : 0;   // issued early, consumed in the voxel phase
+        if (R.flags & RF_FLUID) { fluid_drag<BLOCK>(B, R, cur, ex, valid, v, C.mass_inv, R.lat); __syncthreads(); }
 
         // ---- bond phase: this voxel's +X, +Y, +Z bonds; own-side sums stay in registers, far-side outputs go to LDS
         d3 F = mk3(0, 0, 0), M = mk3(0, 0, 0);
@@ -486,9 +591,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_steps(DBatch B, co
                 const int v2 = B.nbr[(2 * a) * nv + vb];
                 const d3 p2 = mk3(POS(cur, 0, v2), POS(cur, 1, v2), POS(cur, 2, v2));
                 const dq q2 = mkq(QUAT(0, v2), QUAT(1, v2), QUAT(2, v2), QUAT(3, v2));
-                BondOut o = bond_compute(B, B.bclass_tab[bc], a, a * nv + vb, p1, q1, sc1, p2, q2, SCALE(cur, v2), s_dtprev, R.bond_z_half);
+                const double sc2 = SCALE(cur, v2);
+                BondHist H = load_bond_hist(B, a * nv + vb);
+                BondOut o = bond_compute(B, bct[bc], a, H, p1, q1, sc1, p2, q2, sc2, s_dtprev, R.bond_z_half);
+                store_bond_hist(B, a * nv + vb, H);
                 F = F + o.f1; M = M - o.m1;
                 div = div || o.diverged;
+                if (R.flags & RF_FLUID) {     // SetStrainDir (VXS_BondInternal.cpp:300-304): my +a side, the neighbour's -a side
+                    B.strain[(unsigned)a * nv + vb] = o.strain1;
+                    B.strain[(unsigned)(3 + a) * nv + v2] = o.strain2;
+                }
                 double* e = ex + (a * 6) * BLOCK + (v2 - R.vox_begin);
                 e[0] = o.f2.x; e[BLOCK] = o.f2.y; e[2 * BLOCK] = o.f2.z; e[3 * BLOCK] = o.m2.x; e[4 * BLOCK] = o.m2.y; e[5 * BLOCK] = o.m2.z;
             }
@@ -519,7 +631,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_steps(DBatch B, co
             S.am = mk3(ANGMOM(0, vx), ANGMOM(1, vx), ANGMOM(2, vx));
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, vx, cur, s_time, F, M, vel, S, row, ccnt);
+            d3 drag = mk3(0, 0, 0);
+            if (R.flags & RF_FLUID) drag = mk3(B.dragf[vx], B.dragf[(unsigned)nv + vx], B.dragf[2u * nv + vx]);
+            vel2 = voxel_update(B, R, C, vx, cur, s_time, F, M, vel, S, row, ccnt, drag);
             POS(nxt, 0, vx) = S.pos.x; POS(nxt, 1, vx) = S.pos.y; POS(nxt, 2, vx) = S.pos.z;
             SCALE(nxt, vx) = S.scale;
             LINMOM(0, vx) = S.lm.x; LINMOM(1, vx) = S.lm.y; LINMOM(2, vx) = S.lm.z;
@@ -583,7 +697,10 @@ __global__ __launch_bounds__(256) void k_bonds(DBatch B, int bond_blocks, const 
     d3 p2 = mk3(POS(cur, 0, v2), POS(cur, 1, v2), POS(cur, 2, v2));
     dq q1 = mkq(QUAT(0, v1), QUAT(1, v1), QUAT(2, v1), QUAT(3, v1));
     dq q2 = mkq(QUAT(0, v2), QUAT(1, v2), QUAT(2, v2), QUAT(3, v2));
-    BondOut o = bond_compute(B, B.bclass_tab[bc], axis, tid, p1, q1, SCALE(cur, v1), p2, q2, SCALE(cur, v2), rs.dt_prev, R.bond_z_half);
+    const double sc1 = SCALE(cur, v1), sc2 = SCALE(cur, v2);
+    BondHist H = load_bond_hist(B, tid);
+    BondOut o = bond_compute(B, B.bclass_tab[bc], axis, H, p1, q1, sc1, p2, q2, sc2, rs.dt_prev, R.bond_z_half);
+    store_bond_hist(B, tid, H);
     if (o.diverged) atomicOr(&B.rstate[r].diverged, 1);
     BOUT(0, tid) = o.f1.x; BOUT(1, tid) = o.f1.y; BOUT(2, tid) = o.f1.z;
     BOUT(3, tid) = o.m1.x; BOUT(4, tid) = o.m1.y; BOUT(5, tid) = o.m1.z;
@@ -631,7 +748,7 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
         }
         int row = -1, ccnt = 0;
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) { row = R.surf_begin + so; ccnt = B.col_cnt[row]; } }
-        vel2 = voxel_update(B, R, C, v, cur, rs.cur_time, F, M, vel, S, row, ccnt);
+        vel2 = voxel_update(B, R, C, v, cur, rs.cur_time, F, M, vel, S, row, ccnt, mk3(0, 0, 0));
         POS(nxt, 0, v) = S.pos.x; POS(nxt, 1, v) = S.pos.y; POS(nxt, 2, v) = S.pos.z;
         SCALE(nxt, v) = S.scale;
         LINMOM(0, v) = S.lm.x; LINMOM(1, v) = S.lm.y; LINMOM(2, v) = S.lm.z;

@@ -216,6 +216,37 @@ RobotModel build_robot(const VxaModel& vxa)
         r.near_off[v + 1] = (int)r.near_idx.size();
     }
     r.nsurf = (int)r.surf.size();
+
+    if (m.variant == 1 && m.fluid_env) {   // drag mesh topology
+        const int tx = nx + 1, ty = ny + 1, tz = nz + 1;
+        std::vector<std::vector<int>> comps((size_t)tx * ty * tz);
+        auto d3 = [&](int X, int Y, int Z) { return (size_t)Z * tx * ty + (size_t)Y * tx + X; };
+        static const int cdx[8] = {0, 0, 0, 0, 1, 1, 1, 1}, cdy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, cdz[8] = {0, 1, 0, 1, 0, 1, 0, 1};
+        r.open_face.assign(r.nvox, 0);
+        for (int v = 0; v < r.nvox; ++v) {
+            int i = r.struct_index[v];
+            int iz = i / (nx * ny), iy = (i - iz * nx * ny) / nx, ix = i - iz * nx * ny - iy * nx;
+            for (int c = 0; c < 8; ++c) comps[d3(ix + cdx[c], iy + cdy[c], iz + cdz[c])].push_back(v * 8 + c);
+            for (int d = 0; d < 6; ++d) if (r.nbr[(size_t)v * 6 + d] < 0) r.open_face[v] |= (unsigned char)(1u << d);
+        }
+        std::vector<int> map(comps.size(), -1);
+        const double lat = m.lattice_dim, half = (1.0 / 2) * lat, eps = 0.000001;
+        for (int k = 0; k < tz; ++k) for (int j = 0; j < ty; ++j) for (int i = 0; i < tx; ++i) {
+            const auto& c = comps[d3(i, j, k)];
+            if (c.empty() || c.size() == 8) continue;
+            map[d3(i, j, k)] = r.nmv++;
+            for (int q = 0; q < 8; ++q) r.vert_comp.push_back(q < (int)c.size() ? c[q] : -1);
+            r.vert_v0.push_back(lat * (1.0 * (0.5 + i) + eps) - half);   // LW/VX_Object.cpp:521-540, LW/VX_MeshUtil.cpp:231-240
+            r.vert_v0.push_back(lat * (1.0 * (0.5 + j) + eps) - half);
+            r.vert_v0.push_back(lat * 1.0 * (0.5 + k) - half);
+        }
+        r.corner_vert.assign((size_t)r.nvox * 8, -1);
+        for (int v = 0; v < r.nvox; ++v) {
+            int i = r.struct_index[v];
+            int iz = i / (nx * ny), iy = (i - iz * nx * ny) / nx, ix = i - iz * nx * ny - iy * nx;
+            for (int c = 0; c < 8; ++c) r.corner_vert[(size_t)v * 8 + c] = map[d3(ix + cdx[c], iy + cdy[c], iz + cdz[c])];
+        }
+    }
     (void)same_bits;
     return r;
 }

@@ -46,6 +46,13 @@ struct RobotModel {
     // collisions
     std::vector<int> surf;                  // surface voxels, ascending
     std::vector<int> near_off, near_idx;    // CSR over ALL voxels: sorted voxel indices within N hops (self included)
+    // land_water fluid drag mesh (LW/VX_MeshUtil.cpp LinkSimVoxels :110-276): deformable surface vertices = lattice
+    // corners touched by 1..7 voxels; every exposed voxel face carries two triangles owned by that voxel
+    int nmv = 0;
+    std::vector<int> vert_comp;             // [nmv*8] voxel*8 + corner code (NNN..PPP = 0..7) or -1, in voxel order
+    std::vector<double> vert_v0;            // [nmv*3] rest position (incl. the 1e-6 offset hack of GetXYZ)
+    std::vector<int> corner_vert;           // [nvox*8] mesh vertex at each corner of the voxel or -1
+    std::vector<unsigned char> open_face;   // [nvox] bit d set when face PX,NX,PY,NY,PZ,NZ is exposed
     // local class tables (merged batch-wide by the engine)
     std::vector<VoxClass> vox_classes;
     std::vector<BondClass> bond_classes;

@@ -260,7 +260,6 @@ VxaModel read_vxa(const char* data, size_t len, int variant)
     m.sticky_floor = flag(env, "StickyFloor", false);
     m.fluid_env = flag(env, "FluidEnvironment", false);
     m.aggregate_drag_coef = num(env, "AggregateDragCoefficient", 0);
-    if (variant == 1 && m.fluid_env) m.unsupported.push_back("FluidEnvironment (facet drag, SURVEY 8 a-10: next)");
     if (variant == 0) {
         if (flag(env, "NormDistByVol", false)) m.unsupported.push_back("NormDistByVol");
         if (inum(env, "NumTimeStepsInWindow", 0) > 0) m.unsupported.push_back("NumTimeStepsInWindow");

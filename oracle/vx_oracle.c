@@ -111,6 +111,7 @@ typedef struct {
     v3 pos, lin_mom, ang_mom, vel, ang_vel; qt angle; double scale, last_scale; int static_fric;
     v3 strain_pos, strain_neg;   /* StrainPosDirsCur / StrainNegDirsCur */
     v3 drag;                     /* LW DragForce */
+    v3 corner_pos, corner_neg;   /* CornerPosCur / CornerNegCur (only the LW drag mesh reads them) */
     /* collision links in creation order: index into col[] */
     int ncol, capcol; int* col;
     /* nearby voxels (CalcNearby) as a sorted list for the exclusion test */
@@ -132,6 +133,8 @@ typedef struct {
 } ibond;
 
 typedef struct { int v1, v2; double a1; v3 f1, f2; } cbond;
+struct mvert { int nc; int vox[8]; int corner[8]; v3 v0, cur; };   /* lattice corner touched by 1..7 voxels */
+struct mfacet { int vi[3]; int owner; v3 n; };
 
 struct vxo_sim {
     vxo_model m;
@@ -140,6 +143,8 @@ struct vxo_sim {
     double lat, opt_dt, dt, cur_time; int steps, status, cm_init;
     double max_disp_since_update; int col_enable_changed, rebuilds;
     double max_vox_vel; v3 cur_cm, ini_cm; double end_of_life_posterior_y;
+    /* LW fluid drag mesh (LW/VX_MeshUtil.cpp:110-276) */
+    int nmv, nmf; struct mvert* mv; struct mfacet* mf;
 };
 
 static double bond_E(double E1, double E2) { return (E1 * E2 / (E1 + E2)) * 2; }    /* VX/VX_Bond.cpp:87 */
@@ -446,6 +451,9 @@ static v3 total_force(vxo_sim* s, int vi)
         F = vadd(F, floor_effect(s, v, F));
         if (v->static_fric) { F.x = 0; F.y = 0; }
     }
+    /* VXS_Voxel.cpp:641-642 (LW :472-475): consumed by the NEXT step's drag mesh */
+    v->corner_pos = vdiv(vmul(vadd(V(1, 1, 1), v->strain_pos), v->nom_size), 2);
+    v->corner_neg = vdiv(vmul(vneg(vadd(V(1, 1, 1), v->strain_neg)), v->nom_size), 2);
     return F;
 }
 
@@ -541,6 +549,109 @@ static int stop_condition_met(const vxo_sim* s)
     }
 }
 
+static v3 qrot(qt q, v3 f)                                                         /* RotateVec3D Vec3D.h:293-299 */
+{
+    double tw = f.x * q.x + f.y * q.y + f.z * q.z;
+    double tx = f.x * q.w - f.y * q.z + f.z * q.y;
+    double ty = f.x * q.z + f.y * q.w - f.z * q.x;
+    double tz = -f.x * q.y + f.y * q.x + f.z * q.w;
+    return V(q.w * tx + q.x * tw + q.y * tz - q.z * ty, q.w * ty - q.x * tz + q.y * tw + q.z * tx, q.w * tz + q.x * ty - q.y * tx + q.z * tw);
+}
+static v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static double vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 vnormalized(v3 a) { double l = sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return l > 0 ? vdiv(a, l) : a; }   /* Vec3D.h:127 */
+
+/* fluid drag, LW/VX_Sim.cpp:1516-1597 with UpdateMeshPhysicsOnlyNoColors / GetCurVLoc (LW/VX_MeshUtil.cpp:368-428) and
+ * CalcFaceNormals (LW/Utils/Mesh.cpp:659-665) */
+static void fluid_drag(vxo_sim* s)
+{
+    for (int i = 0; i < s->nvox; i++) s->vox[i].drag = V(0, 0, 0);
+    for (int i = 0; i < s->nmv; i++) {
+        struct mvert* m = &s->mv[i];
+        v3 avg = V(0, 0, 0); double tw = 0;
+        for (int j = 0; j < m->nc; j++) {
+            const voxel* v = &s->vox[m->vox[j]];
+            v3 cn = v->corner_neg, cp = v->corner_pos, off;
+            switch (m->corner[j]) {                                                /* NNN..PPP, LW/VX_MeshUtil.h:23-30 */
+            case 0: off = cn; break;
+            case 1: off = V(cn.x, cn.y, cp.z); break;
+            case 2: off = V(cn.x, cp.y, cn.z); break;
+            case 3: off = V(cn.x, cp.y, cp.z); break;
+            case 4: off = V(cp.x, cn.y, cn.z); break;
+            case 5: off = V(cp.x, cn.y, cp.z); break;
+            case 6: off = V(cp.x, cp.y, cn.z); break;
+            default: off = cp; break;
+            }
+            v3 p = vadd(v->pos, qrot(v->angle, off));
+            avg = vadd(avg, vmul(p, 1.0)); tw += 1.0;
+        }
+        v3 np = vdiv(avg, tw);
+        v3 draw = vsub(np, m->v0);                                                 /* DrawOffset */
+        m->cur = vadd(m->v0, draw);                                                /* OffPos() */
+    }
+    for (int i = 0; i < s->nmf; i++) {
+        struct mfacet* f = &s->mf[i];
+        f->n = vnormalized(vcross(vsub(s->mv[f->vi[1]].cur, s->mv[f->vi[0]].cur), vsub(s->mv[f->vi[2]].cur, s->mv[f->vi[0]].cur)));
+    }
+    for (int i = 0; i < s->nmf; i++) {
+        struct mfacet* f = &s->mf[i];
+        v3 A = s->mv[f->vi[0]].cur, B = s->mv[f->vi[1]].cur, C = s->mv[f->vi[2]].cur;
+        v3 AB = vsub(B, A), AC = vsub(C, A);
+        double area = fabs(vlen(vcross(AB, AC)) / 2.0);
+        v3 speed = s->vox[f->owner].vel, n = f->n, proj = V(0, 0, 0);
+        float ang = (float)acos(vdot(vnormalized(speed), vnormalized(n)));
+        if (fabsf(ang) < VX_PI / 2) proj = vmul(vnormalized(n), vdot(speed, n));       /* ProjectOnTo, LW/Utils/Vec3D.h:142 */
+        v3 drag = vmul(vnormalized(proj), -s->m.aggregate_drag_coef * area * vlen2(proj));
+        s->vox[f->owner].drag = vadd(s->vox[f->owner].drag, drag);
+    }
+}
+
+/* LinkSimVoxels, LW/VX_MeshUtil.cpp:110-276: vertices = lattice corners touched by 1..7 voxels, two triangles per
+ * exposed voxel face (owner = that voxel), vertex rest positions with the 1e-6 offset hack of GetXYZ (LW/VX_Object.cpp:521-540) */
+static void build_drag_mesh(vxo_sim* s, const int* x2s)
+{
+    const vxo_model* m = &s->m;
+    int tx = m->nx + 1, ty = m->ny + 1, tz = m->nz + 1, nall = tx * ty * tz;
+    struct mvert* all = (struct mvert*)calloc(nall, sizeof(struct mvert));
+    int* map = (int*)malloc(sizeof(int) * nall);
+    s->mf = (struct mfacet*)calloc((size_t)12 * s->nvox + 1, sizeof(struct mfacet));
+    static const int cdx[8] = {0, 0, 0, 0, 1, 1, 1, 1}, cdy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, cdz[8] = {0, 1, 0, 1, 0, 1, 0, 1};
+#define D3(X, Y, Z) ((Z) * tx * ty + (Y) * tx + (X))
+#define OCC(X, Y, Z) ((X) >= 0 && (Y) >= 0 && (Z) >= 0 && (X) < m->nx && (Y) < m->ny && (Z) < m->nz && m->structure[(X) + m->nx * (Y) + m->nx * m->ny * (Z)] != 0)
+#define FACET(a, b, c) do { struct mfacet* f = &s->mf[s->nmf++]; f->vi[0] = (a); f->vi[1] = (b); f->vi[2] = (c); f->owner = vi; } while (0)
+    int ncell = m->nx * m->ny * m->nz;
+    for (int i = 0, vi = 0; i < ncell; i++) {
+        if (m->structure[i] == 0) continue;
+        int cz = i / (m->nx * m->ny), cy = (i - cz * m->nx * m->ny) / m->nx, cx = i - cz * m->nx * m->ny - cy * m->nx;
+        for (int c = 0; c < 8; c++) { struct mvert* v = &all[D3(cx + cdx[c], cy + cdy[c], cz + cdz[c])]; v->vox[v->nc] = vi; v->corner[v->nc] = c; v->nc++; }
+        if (!OCC(cx + 1, cy, cz)) { FACET(D3(cx + 1, cy, cz), D3(cx + 1, cy + 1, cz), D3(cx + 1, cy + 1, cz + 1)); FACET(D3(cx + 1, cy, cz), D3(cx + 1, cy + 1, cz + 1), D3(cx + 1, cy, cz + 1)); }
+        if (!OCC(cx - 1, cy, cz)) { FACET(D3(cx, cy, cz), D3(cx, cy + 1, cz + 1), D3(cx, cy + 1, cz)); FACET(D3(cx, cy, cz), D3(cx, cy, cz + 1), D3(cx, cy + 1, cz + 1)); }
+        if (!OCC(cx, cy + 1, cz)) { FACET(D3(cx, cy + 1, cz), D3(cx, cy + 1, cz + 1), D3(cx + 1, cy + 1, cz + 1)); FACET(D3(cx, cy + 1, cz), D3(cx + 1, cy + 1, cz + 1), D3(cx + 1, cy + 1, cz)); }
+        if (!OCC(cx, cy - 1, cz)) { FACET(D3(cx, cy, cz), D3(cx + 1, cy, cz + 1), D3(cx, cy, cz + 1)); FACET(D3(cx, cy, cz), D3(cx + 1, cy, cz), D3(cx + 1, cy, cz + 1)); }
+        if (!OCC(cx, cy, cz + 1)) { FACET(D3(cx, cy, cz + 1), D3(cx + 1, cy, cz + 1), D3(cx + 1, cy + 1, cz + 1)); FACET(D3(cx, cy, cz + 1), D3(cx + 1, cy + 1, cz + 1), D3(cx, cy + 1, cz + 1)); }
+        if (!OCC(cx, cy, cz - 1)) { FACET(D3(cx, cy, cz), D3(cx + 1, cy + 1, cz), D3(cx + 1, cy, cz)); FACET(D3(cx, cy, cz), D3(cx, cy + 1, cz), D3(cx + 1, cy + 1, cz)); }
+        vi++;
+    }
+    (void)x2s;
+    s->mv = (struct mvert*)calloc(nall, sizeof(struct mvert));
+    double lat = m->lattice_dim, half = (1.0 / 2) * lat;                            /* GetLatDimEnv()/2 */
+    for (int k = 0, idx = 0; k < tz; k++) for (int j = 0; j < ty; j++) for (int i = 0; i < tx; i++, idx++) {
+        map[idx] = -1;
+        if (all[idx].nc != 0 && all[idx].nc != 8) {
+            double Eps = 0.000001;
+            v3 p = V(lat * (1.0 * (0.5 + i) + Eps), lat * (1.0 * (0.5 + j) + Eps), lat * 1.0 * (0.5 + k));
+            all[idx].v0 = vsub(p, V(half, half, half));
+            s->mv[s->nmv] = all[idx];
+            map[idx] = s->nmv++;
+        }
+    }
+    for (int f = 0; f < s->nmf; f++) for (int j = 0; j < 3; j++) s->mf[f].vi[j] = map[s->mf[f].vi[j]];
+    free(all); free(map);
+#undef D3
+#undef OCC
+#undef FACET
+}
+
 /* CVX_Sim::TimeStep + Integrate + UpdateStats, VX/VX_Sim.cpp:1054-1156,1763-1933,1511-1690 */
 static int time_step(vxo_sim* s)
 {
@@ -555,6 +666,7 @@ static int time_step(vxo_sim* s)
     if (diverged) return 0;
     for (int i = 0; i < s->ncol; i++) col_update(s, &s->col[i]);
     s->dt = s->m.dt_frac * s->opt_dt;
+    if (s->m.variant == 1 && s->m.fluid_env) fluid_drag(s);
     for (int i = 0; i < s->nvox; i++) euler_step(s, i);
     s->cur_time += s->dt;
     s->steps++;
@@ -662,6 +774,7 @@ vxo_sim* vxo_create(const vxo_model* m)
         }
         vi++;
     }
+    if (m->variant == 1 && m->fluid_env) build_drag_mesh(s, x2s);
     free(x2s);
     /* surface list + nearby lists (:649-659) */
     s->surf = (int*)malloc(sizeof(int) * s->nvox);
@@ -679,6 +792,8 @@ vxo_sim* vxo_create(const vxo_model* m)
         voxel* v = &s->vox[i];
         v->pos = v->nom_pos; v->angle = Q(1.0, 0, 0, 0);
         v->scale = v->nom_size; v->last_scale = v->scale;
+        v->corner_pos = V(v->scale / 2, v->scale / 2, v->scale / 2);               /* ResetVoxel VXS_Voxel.cpp:131-132 */
+        v->corner_neg = V(-v->scale / 2, -v->scale / 2, -v->scale / 2);
         v->temp_amplitude = (float)m->temp_amplitude;
         v->temp_period = (float)m->temp_period;
         v->phase_offset = m->phase_offset ? (float)m->phase_offset[i] : (float)0.0;
@@ -694,7 +809,7 @@ void vxo_destroy(vxo_sim* s)
 {
     if (!s) return;
     for (int i = 0; i < s->nvox; i++) { free(s->vox[i].col); free(s->vox[i].near); }
-    free(s->vox); free(s->bond); free(s->surf); free(s->col); free(s);
+    free(s->vox); free(s->bond); free(s->surf); free(s->col); free(s->mv); free(s->mf); free(s);
 }
 
 /* the loop of voxelyzeMain/main.cpp:89-111; a diverged robot would spin forever there, we stop and flag it */

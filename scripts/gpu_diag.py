@@ -150,3 +150,24 @@ if __name__ == "__main__" and "col" in sys.argv[1:]:
 if __name__ == "__main__" and "dbg" in sys.argv[1:]:
     for d in (0, 1, 2, 3):
         timing2(512, (10, 10, 10), 0.03, True, {"fused": 1, "steps_per_launch": 64, "dbg": d})
+
+
+def bisect_lw(name):
+    path = os.path.join(G, "vxa", name + ".vxa")
+    sim = vo.OracleSim.from_vxa(path, 1)
+    with engine.Engine(engine.VOXCAD_LAND_WATER, 0) as eng:
+        eng.add_vxa_file(path)
+        for upto in list(range(1, 12)) + [20, 50]:
+            eng.step(upto - sim.info().steps)
+            sim.step(upto - sim.info().steps)
+            w, g = sim.state(), eng.state(0)
+            lat = sim.model["lattice_dim"]
+            e = np.abs(g[:, :3] - w[:, :3]).max(axis=1) / lat
+            ev = np.abs(g[:, 8:11] - w[:, 8:11]).max(axis=1)
+            print("%s step %4d pos %.3e vox (voxel %d) vel %.3e (voxel %d) scale %.3e ncol %d" % (
+                name, upto, e.max(), int(e.argmax()), ev.max(), int(ev.argmax()), np.abs(g[:, 7] - w[:, 7]).max() / lat, sim.info().ncol))
+
+
+if __name__ == "__main__" and "bisect_lw" in sys.argv[1:]:
+    bisect_lw("lw_hexapus")
+    bisect_lw("lw_swim6")

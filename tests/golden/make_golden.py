@@ -61,6 +61,18 @@ def cases():
     out["phase4"] = dict(variant="land", sim=Sim(dt_frac=0.8, simulation_time=0.3, fitness_eval_init_time=0.05),
                          env=env4, ind=workloads.make_individual(4, workloads.random_material((4, 4, 4), 5, 0.1),
                                                                 OrderedDict([("<PhaseOffset>", phase)])))
+    # ---- _voxcad_land_water semantics (two-sided actuation, float-typed stress modulus, other stop rule/result tags)
+    phase6 = np.round(np.random.RandomState(7).uniform(-1, 1, size=(6, 6, 6)), 3)
+    out["lw_land6"] = dict(variant="lw", sim=Sim(dt_frac=0.9, simulation_time=0.3, fitness_eval_init_time=0.05),
+                           env=Env(), ind=workloads.make_individual(5, workloads.random_material((6, 6, 6), 21),
+                                                                    OrderedDict([("<PhaseOffset>", phase6)])))
+    # BASELINE configs[3] in small: swimmer in fluid (facet drag, no gravity/floor), as evosoro/examples/swimming_basic.py:137-138
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    out["lw_swim6"] = dict(variant="lw", sim=Sim(dt_frac=0.9, simulation_time=0.3, fitness_eval_init_time=0.0),
+                           env=env_w, ind=workloads.make_individual(6, workloads.random_material((6, 6, 6), 22),
+                                                                    OrderedDict([("<PhaseOffset>", phase6)])))
     return out
 
 
@@ -122,10 +134,16 @@ def main():
         # reference reader on the reference XML
         pop = _Pop()
         pop.objective_dict = ObjectiveDict()
-        pop.objective_dict.add_objective(name="fitness", maximize=True, tag="<NormFinalDist>")
-        pop.objective_dict.add_objective(name="age", maximize=False, tag=None)
-        pop.objective_dict.add_objective(name="y", maximize=True, tag="<finalDistY>")
-        pop.objective_dict.add_objective(name="touch", maximize=True, tag="<NumTouchingFloor>")
+        if case["variant"] == "land":
+            pop.objective_dict.add_objective(name="fitness", maximize=True, tag="<NormFinalDist>")
+            pop.objective_dict.add_objective(name="age", maximize=False, tag=None)
+            pop.objective_dict.add_objective(name="y", maximize=True, tag="<finalDistY>")
+            pop.objective_dict.add_objective(name="touch", maximize=True, tag="<NumTouchingFloor>")
+        else:   # objectives of evosoro/examples/swimming_basic.py:147 and land_continuous.py:159
+            pop.objective_dict.add_objective(name="fitness", maximize=True, tag="<normAbsoluteDisplacement>")
+            pop.objective_dict.add_objective(name="age", maximize=False, tag=None)
+            pop.objective_dict.add_objective(name="z", maximize=True, tag="<normDistZ>")
+            pop.objective_dict.add_objective(name="n", maximize=True, tag="<VoxelNumber>")
         values = ref_rw.read_voxlyze_results(pop, None, xml)
         manifest[name] = {"variant": case["variant"], "id": ind.id, "md5": md5,
                           "read_results": {str(k): v for k, v in values.items()},
@@ -134,7 +152,9 @@ def main():
 
     # input files the reference ships next to its simulator (data, not code); expected values from the reference
     shipped = [("land", "evosoro/_voxcad/voxelyzeMain/Example_withPhaseOffset.vxa", "example_phaseoffset"),
-               ("land", "evosoro/_voxcad/voxelyzeMain/Example_1.vxa", "example_1")]
+               ("land", "evosoro/_voxcad/voxelyzeMain/Example_1.vxa", "example_1"),
+               ("lw", "evosoro/_voxcad_land_water/sample_vxa/hexapus.vxa", "lw_hexapus"),
+               ("lw", "evosoro/_voxcad_land_water/sample_vxa/quadruped_land.vxa", "lw_quadruped_land")]
     for variant, rel, name in shipped:
         wd = os.path.join(work, "shipped_" + name)
         os.makedirs(os.path.join(wd, "fitnessFiles"))
@@ -147,8 +167,8 @@ def main():
         shutil.copy(os.path.join(wd, name + ".vxa"), os.path.join(vxa_dir, name + ".vxa"))
         shutil.copy(outs[0], os.path.join(exp_dir, name + ".xml"))
         subprocess.run(["timeout", "900", probe[variant], "-f", name + ".vxa", "-o",
-                        os.path.join(exp_dir, name + ".early.bin"), "-max", "200", "-every", "50", "-noresult"],
-                       check=True)
+                        os.path.join(exp_dir, name + ".early.bin"), "-max", "800" if variant == "lw" else "200",
+                        "-every", "200" if variant == "lw" else "50", "-noresult"], check=True)
         manifest[name] = {"variant": variant, "shipped": rel, "result_path": outs[0]}
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:

@@ -11,7 +11,8 @@ from evosoro_amd import engine
 from oracle import vxoracle as vo
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "example_1", "example_phaseoffset"]
+CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "example_1", "example_phaseoffset",
+         "lw_land6", "lw_swim6", "lw_hexapus", "lw_quadruped_land"]
 
 
 def _declared_functions():
@@ -54,8 +55,9 @@ def test_result_struct_layout_matches_header():
 @pytest.mark.parametrize("name", CASES)
 def test_host_model_matches_oracle_and_reference(golden_dir, name):
     path = os.path.join(golden_dir, "vxa", name + ".vxa")
-    info = engine.inspect_vxa(path)
-    sim = vo.OracleSim.from_vxa(path)
+    variant = 1 if name.startswith("lw_") else 0
+    info = engine.inspect_vxa(path, variant)
+    sim = vo.OracleSim.from_vxa(path, variant)
     oi = sim.info()
     assert (info.nvox, info.nbond, info.nsurf) == (oi.nvox, oi.nbond, oi.nsurf)
     assert info.opt_dt == oi.opt_dt                      # CalcMaxDt bitwise

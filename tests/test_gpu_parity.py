@@ -208,3 +208,40 @@ def test_full_size_batch_properties(eng_mod, tmp_path):
         tol = max(FLOOR_VOX, 20 * _spread(o.model, (results[i].steps // 2, results[i].steps))[0])
         assert _pos_err(batch[i], o.state(), 0.01) <= tol
         assert results[i].steps == o.info().steps
+
+
+LW_CASES = ["lw_land6", "lw_swim6", "lw_hexapus", "lw_quadruped_land"]
+
+
+def test_land_water_variant(eng_mod, golden_dir):
+    """_voxcad_land_water semantics incl. BASELINE configs[3] physics: fluid environment with per-facet drag
+    (lw_swim6, and lw_hexapus = a sample .vxa shipped with the reference), gravity/floor off in fluid."""
+    from oracle import vxoracle as vo
+    models = [vo.parse_vxa(os.path.join(golden_dir, "vxa", n + ".vxa"), 1) for n in LW_CASES]
+    sims = [vo.OracleSim(m) for m in models]
+    spreads = [_spread(m, (100, 300, 600)) for m in models]
+    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+        for n in LW_CASES:
+            eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))
+        for upto in (1, 10, 100, 400):
+            eng.step(upto - sims[0].info().steps)
+            for i, name in enumerate(LW_CASES):
+                sims[i].step(upto - sims[i].info().steps)
+                lat = models[i]["lattice_dim"]
+                tol = FLOOR_VOX if upto <= 10 else max(FLOOR_VOX, 20 * spreads[i][0])
+                assert _pos_err(eng.state(i), sims[i].state(), lat) <= tol, (name, upto, tol)
+    # whole runs of the two generated robots against the reference's result XML
+    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+        for n in LW_CASES[:2]:
+            eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))
+        eng.run()
+        for i, name in enumerate(LW_CASES[:2]):
+            want = vo.read_result_xml(os.path.join(golden_dir, "expected", name + ".xml"))
+            trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".final.bin"))
+            res = eng.result(i)
+            planned = eng.dims(i)["planned_steps"]
+            tol = max(FLOOR_VOX, 20 * _spread(models[i], (planned // 2, planned))[0])
+            assert res.status == eng_mod.ROBOT_FINISHED and res.steps == trace["total_steps"]
+            assert np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / models[i]["lattice_dim"] <= tol, name
+            for tag, val in (("normAbsoluteDisplacement", res.norm_abs_disp), ("normDistZ", res.norm_dist_z)):
+                assert abs(val - want[tag]) <= 2 * tol + 1e-5 * abs(want[tag]), (name, tag, val, want[tag])

@@ -15,6 +15,11 @@ from oracle import vxoracle as vo
 
 LAND_CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4"]
 SHIPPED = ["example_1", "example_phaseoffset"]
+# _voxcad_land_water: generated (land + fluid swimmer with facet drag) and two sample files shipped with the reference
+LW_CASES = ["lw_land6", "lw_swim6"]
+LW_SHIPPED = ["lw_hexapus", "lw_quadruped_land"]
+LW_TAGS = [("normAbsoluteDisplacement", "norm_abs_disp"), ("normDistX", "norm_dist_x"), ("normDistY", "norm_dist_y"),
+           ("normDistZ", "norm_dist_z"), ("VoxelNumber", "nvox")]
 
 RESULT_TAGS = [("NormFinalDist", "norm_final_dist"), ("NormRegimeDist", "norm_regime_dist"),
                ("NormFrozenDist", "norm_frozen_dist"), ("FinalDist", "final_dist"), ("finalDistY", "final_dist_y"),
@@ -25,10 +30,10 @@ RESULT_TAGS = [("NormFinalDist", "norm_final_dist"), ("NormRegimeDist", "norm_re
 
 
 def _sim(golden_dir, name):
-    return vo.OracleSim.from_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"))
+    return vo.OracleSim.from_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"), variant=1 if name.startswith("lw_") else 0)
 
 
-@pytest.mark.parametrize("name", LAND_CASES + SHIPPED)
+@pytest.mark.parametrize("name", LAND_CASES + SHIPPED + LW_CASES + LW_SHIPPED)
 def test_early_trace_bit_exact(golden_dir, name):
     trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".early.bin"))
     sim = _sim(golden_dir, name)
@@ -59,6 +64,21 @@ def test_full_run_final_state_and_result(golden_dir, name):
     expected = vo.read_result_xml(os.path.join(golden_dir, "expected", name + ".xml"))
     result = sim.result()
     for tag, field in RESULT_TAGS:
+        assert "%.6g" % getattr(result, field) == "%.6g" % expected[tag], tag
+
+
+@pytest.mark.parametrize("name", LW_CASES)
+def test_land_water_full_run(golden_dir, name):
+    trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".final.bin"))
+    sim = _sim(golden_dir, name)
+    sim.step(-1)
+    info = sim.info()
+    assert info.status == 1 and info.steps == trace["total_steps"]
+    assert np.array_equal(sim.state(), trace["records"][-1]["state"])
+    assert np.array_equal(np.array(info.ini_cm), trace["ini_cm"]) and np.array_equal(np.array(info.cur_cm), trace["cur_cm"])
+    expected = vo.read_result_xml(os.path.join(golden_dir, "expected", name + ".xml"))
+    result = sim.result()
+    for tag, field in LW_TAGS:
         assert "%.6g" % getattr(result, field) == "%.6g" % expected[tag], tag
 
 
