@@ -23,6 +23,8 @@ struct DRobot {               // constant per robot
     int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr, pad0;
     long long excl_begin;     // first word of this robot's exclusion rows in DBatch::excl
     int vert_begin, nmv;      // drag-mesh vertices of this robot (fluid robots)
+    int vtab_begin, n_vclass; // this robot's rows of DBatch::vclass_tab (class ids stored per voxel are robot-local)
+    int btab_begin, n_bclass; // ... and of DBatch::bclass_tab
     double dt, lat, bond_z_half, slow_z, col_z, grav_acc;
     double init_cm_time, stop_value, afterlife, temp_period_d;
     double min_temp_fact, growth_amplitude, col_horizon, filter_dist2, drag_coef;
@@ -37,21 +39,20 @@ struct DRobotState {          // mutable per robot
     int steps, status, cm_init, active, diverged, col_overflow, rebuild_now, rebuilds;
 };
 
-enum { VXH_MAXCOL = 64, VXH_LDS_BCLASS = 32, VXH_LDS_VCLASS = 16 };     // collision partners kept per surface voxel (overflow -> VXH_ROBOT_COL_OVERFLOW)
+enum { VXH_MAXCOL = 64 };     // collision partners kept per surface voxel (overflow -> VXH_ROBOT_COL_OVERFLOW)
 
 // all device pointers of a batch; passed to kernels by value
 struct DBatch {
     int n_robots, nv;                 // nv = total padded voxel slots (multiple of 64 per robot)
-    int dbg, pad1;
-    int n_vclass, n_bclass;           // entries in the class tables                    // developer switches (scripts/gpu_diag.py), 0 in production
+    int dbg, pad1;                    // developer switches (scripts/gpu_diag.py), 0 in production
     const DRobot* robot;
     DRobotState* rstate;
     const int* wave_robot;            // [nv/64] robot of each 64-voxel group
-    const DVoxClass* vclass_tab;
+    const DVoxClass* vclass_tab;      // per-robot class tables, concatenated (DRobot::vtab_begin / btab_begin)
     const DBondClass* bclass_tab;
     // voxel constants
-    const unsigned short* vclass;     // [nv]
-    const short* bclass;              // [3*nv] axis-major, -1 = no bond
+    const unsigned short* vclass;     // [nv] robot-local class id
+    const short* bclass;              // [3*nv] axis-major, robot-local class id, -1 = no bond
     const int* nbr;                   // [6*nv] direction-major, global voxel slot or -1
     const float* phase;               // [nv]
     const float* amp_damp;            // [nv]
@@ -59,7 +60,11 @@ struct DBatch {
     // (buffer 1; positions/scale are double-buffered because collision forces read OTHER voxels' previous
     // positions), [8..11] quaternion w x y z, [12..14] linear momentum, [15..17] angular momentum
     double* vs;
-    // bond history, 9 planes of 3*nv (axis-major slots): _LastPos2, _LastAngle1, _LastAngle2 ; + small-angle flag
+    // bond history, 6 planes of 3*nv (axis-major slots) + a flag byte per slot.  The reference keeps _LastPos2,
+    // _LastAngle1, _LastAngle2 (9 doubles), but three of them are always exactly zero: after a small-angle step
+    // _LastAngle1 = 0, after a large-angle step _LastPos2.y = _LastPos2.z = _LastAngle1.x = 0.  Planes 0..2 hold
+    // _LastPos2 xyz (small layout) or _LastPos2.x, _LastAngle1.y, _LastAngle1.z (large layout), planes 3..5
+    // _LastAngle2.  Flag byte: bit 0 = SmallAngle, bit 1 = history is in the large layout.
     double* hist;
     unsigned char* small_angle;
     // streaming path only: bond outputs of the current step, 12 planes of 3*nv: F1, M1, F2, M2
@@ -81,6 +86,7 @@ struct DBatch {
     const unsigned char* open_face;   // [nv] exposed faces PX,NX,PY,NY,PZ,NZ
     double* strain;                   // [6][nv] StrainPosDirsCur xyz, StrainNegDirsCur xyz (fluid robots only)
     double* dragf;                    // [3][nv] DragForce of the current step
+    unsigned long long* prof;         // developer builds (-DVXH_PHASE_TIMING): per-wave phase cycle sums, else null
     // constants from Vec3D.h evaluated by the host libm (thresholds of the small-angle logic)
     double small_angle_w, smallish_angle_w, slthresh_acos2sqrt;
 };

@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 
@@ -35,12 +36,22 @@ int intern_bytes(std::vector<T>& table, const T& value)
 struct Engine::Device {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // fused path: robots grouped by workgroup size (256/512/768/1024 threads), one stream per class so that
-    // the classes fill the chip together
-    hipStream_t class_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t class_t0[4] = {nullptr, nullptr, nullptr, nullptr}, class_t1[4] = {nullptr, nullptr, nullptr, nullptr};
-    const int* class_list[4] = {nullptr, nullptr, nullptr, nullptr};
-    int class_count[4] = {0, 0, 0, 0};
+    // fused path: robots grouped by kernel variant (workgroup size 256/512/768/1024, exchange buffers, fluid), one
+    // stream per group so that the groups fill the chip together
+    struct Group {
+        int block = 0, nex = 0, fluid = 0;
+        int count = 0;
+        const int* list = nullptr;
+        size_t lds = 0;                   // dynamic LDS bytes
+        int mesh_off = 0;                 // doubles from the start of dynamic LDS
+        hipStream_t stream = nullptr;
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        std::vector<int> robots;
+    };
+    std::vector<Group> groups;
+    std::vector<hipStream_t> group_streams;   // created on demand, reused across prepare() calls
+    std::vector<hipEvent_t> group_events;
+    bool fused_ok = true;                 // every robot fits the fused kernel's LDS budget
     std::vector<void*> allocs;
     DBatch B{};
     std::vector<DRobot> h_robot;
@@ -97,11 +108,6 @@ Engine::Engine(int variant, int device_id) : variant_(variant), device_id_(devic
     HIP_OK(hipStreamCreateWithFlags(&dev_->stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&dev_->ev0));
     HIP_OK(hipEventCreate(&dev_->ev1));
-    for (int c = 0; c < 4; ++c) {
-        HIP_OK(hipStreamCreateWithFlags(&dev_->class_stream[c], hipStreamNonBlocking));
-        HIP_OK(hipEventCreate(&dev_->class_t0[c]));
-        HIP_OK(hipEventCreate(&dev_->class_t1[c]));
-    }
 }
 
 Engine::~Engine()
@@ -112,7 +118,8 @@ Engine::~Engine()
         if (dev_->ev0) hipEventDestroy(dev_->ev0);
         if (dev_->ev1) hipEventDestroy(dev_->ev1);
         if (dev_->stream) hipStreamDestroy(dev_->stream);
-        for (int c = 0; c < 4; ++c) { if (dev_->class_stream[c]) hipStreamDestroy(dev_->class_stream[c]); if (dev_->class_t0[c]) hipEventDestroy(dev_->class_t0[c]); if (dev_->class_t1[c]) hipEventDestroy(dev_->class_t1[c]); }
+        for (hipStream_t st : dev_->group_streams) hipStreamDestroy(st);
+        for (hipEvent_t ev : dev_->group_events) hipEventDestroy(ev);
     }
 }
 
@@ -133,6 +140,20 @@ int Engine::add_vxa(const char* data, size_t len)
 void Engine::clear()
 {
     HIP_OK(hipSetDevice(device_id_));
+#ifdef VXH_PHASE_TIMING
+    if (dev_->B.prof) {
+        unsigned long long h[16 * 8];
+        HIP_OK(hipMemcpy(h, dev_->B.prof, sizeof(h), hipMemcpyDeviceToHost));
+        static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
+        for (int w = 0; w < 16; ++w) {
+            double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[w * 8 + k];
+            if (tot == 0) continue;
+            fprintf(stderr, "wave %2d:", w);
+            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %5.1f%%", names[k], 100.0 * h[w * 8 + k] / tot);
+            fprintf(stderr, "  total %.3e cycles\n", tot);
+        }
+    }
+#endif
     dev_->free_all();
     robots_.clear();
     host_.clear();
@@ -195,7 +216,7 @@ void Engine::prepare()
         const RobotModel& M = robots_[r];
         const VxaModel& X = M.vxa;
         const int base = D.vox_begin[r];
-        std::vector<int> vmap(M.vox_classes.size()), bmap(M.bond_classes.size());
+        const int vtab_begin = (int)vtab.size(), btab_begin = (int)btab.size();
         for (size_t i = 0; i < M.vox_classes.size(); ++i) {
             const VoxClass& c = M.vox_classes[i];
             DVoxClass d;
@@ -203,7 +224,7 @@ void Engine::prepare()
             d.mass = c.mass; d.mass_inv = c.mass_inv; d.inertia_inv = c.inertia_inv; d.c_lin = c.c_lin; d.c_ang = c.c_ang;
             d.E = c.E; d.k_floor = c.k_floor; d.u_static = c.u_static; d.u_dynamic = c.u_dynamic; d.cte = c.cte;
             d.nom_size = c.nom_size; d.mat = c.mat;
-            vmap[i] = intern_bytes(vtab, d);
+            vtab.push_back(d);
         }
         for (size_t i = 0; i < M.bond_classes.size(); ++i) {
             const BondClass& c = M.bond_classes[i];
@@ -214,19 +235,19 @@ void Engine::prepare()
             d.sq_b1m1 = c.sq_b1m1; d.sq_b1m2 = c.sq_b1m2; d.sq_b2fm1 = c.sq_b2fm1; d.sq_b2fm2 = c.sq_b2fm2;
             d.sq_b3i1 = c.sq_b3i1; d.sq_b3i2 = c.sq_b3i2;
             d.stress_E1 = c.stress_E1; d.stress_E2 = c.stress_E2; d.area_sum = c.area_sum; d.homogeneous = c.homogeneous;
-            bmap[i] = intern_bytes(btab, d);
+            btab.push_back(d);
         }
-        if (vtab.size() > 65535 || btab.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one batch");
+        if (M.vox_classes.size() > 32767 || M.bond_classes.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one robot");
         for (int w = base / 64; w < (base + (M.nvox + 63) / 64 * 64) / 64; ++w) wave_robot[w] = r;
         for (int v = 0; v < M.nvox; ++v) {
             const int g = base + v;
-            vclass[g] = (unsigned short)vmap[M.vox_class[v]];
+            vclass[g] = (unsigned short)M.vox_class[v];
             phase[g] = M.phase_offset[v];
             amp_damp[g] = M.temp_amp_damp[v];
             px[g] = M.nom_pos[3 * v]; py[g] = M.nom_pos[3 * v + 1]; pz[g] = M.nom_pos[3 * v + 2];
             sc[g] = M.vox_classes[M.vox_class[v]].nom_size;
             for (int d = 0; d < 6; ++d) { int o = M.nbr[(size_t)v * 6 + d]; nbr[(size_t)d * nv + g] = o < 0 ? -1 : base + o; }
-            for (int a = 0; a < 3; ++a) { int c = M.bond_class[(size_t)v * 3 + a]; bclass[(size_t)a * nv + g] = c < 0 ? (short)-1 : (short)bmap[c]; }
+            for (int a = 0; a < 3; ++a) { int c = M.bond_class[(size_t)v * 3 + a]; bclass[(size_t)a * nv + g] = c < 0 ? (short)-1 : (short)c; }
         }
         if (X.self_col_enabled)
             for (int i = 0; i < M.nsurf; ++i) { surf[D.surf_begin[r] + i] = base + M.surf[i]; surf_ord[base + M.surf[i]] = i; }
@@ -254,6 +275,7 @@ void Engine::prepare()
                   ((X.col_system == 2 || X.col_system == 3) ? RF_HORIZON_COL : 0);
         R.stop_type = X.stop_type; R.excl_wpr = wpr; R.excl_begin = excl_begin;
         R.vert_begin = mv_begin[r]; R.nmv = M.nmv;
+        R.vtab_begin = vtab_begin; R.n_vclass = (int)M.vox_classes.size(); R.btab_begin = btab_begin; R.n_bclass = (int)M.bond_classes.size();
         if (M.nmv > 0) {
             if (M.nvox > 1024 || !fused_) throw std::invalid_argument("unsupported: fluid drag needs the fused path (robots of at most 1024 voxels)");
             const size_t tm = (size_t)std::max(total_mv, 1);
@@ -287,7 +309,6 @@ void Engine::prepare()
     B.robot = D.upload(D.h_robot);
     B.rstate = D.upload(rstate);
     B.wave_robot = D.upload(wave_robot);
-    B.n_vclass = (int)vtab.size(); B.n_bclass = (int)btab.size();
     B.vclass_tab = D.upload(vtab);
     B.bclass_tab = D.upload(btab);
     B.vclass = D.upload(vclass);
@@ -306,7 +327,7 @@ void Engine::prepare()
         std::copy(qw.begin(), qw.end(), vs.begin() + (size_t)8 * nv);
         B.vs = D.upload(vs);
     }
-    B.hist = D.alloc_zero<double>((size_t)9 * 3 * nv);
+    B.hist = D.alloc_zero<double>((size_t)6 * 3 * nv);
     B.small_angle = D.upload(small);
     B.bout = D.alloc_zero<double>((size_t)12 * 3 * nv);
     B.surf = D.upload(surf);
@@ -323,18 +344,43 @@ void Engine::prepare()
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
     B.col_a1 = D.alloc_zero<double>((size_t)std::max(ns, 1) * VXH_MAXCOL);
-    {   // fused path: size classes, most steps first inside a class
-        std::vector<int> lists[4];
+    {   // fused path: launch groups by kernel variant; inside a group the longest-running robots first.  The variant
+        // is a function of the robot alone (size, fluid, LDS need of its own tables), never of the batch.
+        const size_t lds_max = 160 * 1024 - VXH_FUSED_STATIC_LDS;
+        D.groups.clear();
+        D.fused_ok = true;
         for (int r = 0; r < nr; ++r) {
-            const int n = robots_[r].nvox;
-            if (n == 0 || n > 1024) continue;
-            lists[n <= 256 ? 0 : (n <= 512 ? 1 : (n <= 768 ? 2 : 3))].push_back(r);
+            const RobotModel& M = robots_[r];
+            const int n = M.nvox;
+            if (n == 0) continue;
+            if (n > 1024) { D.fused_ok = false; continue; }
+            const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
+            const int fluid = M.nmv > 0 ? 1 : 0;
+            const size_t extra = M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) + (size_t)24 * M.nmv;
+            int nex = 0;
+            if (block < 1024 && (size_t)(8 + 18) * block * 8 + extra <= lds_max) nex = 3;
+            else if ((size_t)(8 + 6) * block * 8 + extra <= lds_max) nex = 1;
+            if (nex == 0) { D.fused_ok = false; continue; }
+            Device::Group* g = nullptr;
+            for (auto& q : D.groups) if (q.block == block && q.nex == nex && q.fluid == fluid) g = &q;
+            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nex = nex; g->fluid = fluid; }
+            g->robots.push_back(r);
+            g->lds = std::max(g->lds, (size_t)(8 + 6 * nex) * block * 8 + extra);
         }
-        for (int c = 0; c < 4; ++c) {
-            std::stable_sort(lists[c].begin(), lists[c].end(), [&](int a, int b) {
+        size_t gi = 0;
+        for (auto& g : D.groups) {
+            std::stable_sort(g.robots.begin(), g.robots.end(), [&](int a, int b) {
                 return (double)robots_[a].planned_steps * robots_[a].nvox > (double)robots_[b].planned_steps * robots_[b].nvox; });
-            D.class_count[c] = (int)lists[c].size();
-            D.class_list[c] = D.upload(lists[c]);
+            g.count = (int)g.robots.size();
+            g.list = D.upload(g.robots);
+            if (D.group_streams.size() <= gi) {
+                hipStream_t st; hipEvent_t e0, e1;
+                HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+                D.group_streams.push_back(st); D.group_events.push_back(e0); D.group_events.push_back(e1);
+            }
+            g.stream = D.group_streams[gi]; g.t0 = D.group_events[2 * gi]; g.t1 = D.group_events[2 * gi + 1];
+            ++gi;
         }
     }
     {   // streaming path: one rebuild block per 256 surface voxels of every colliding robot
@@ -346,6 +392,9 @@ void Engine::prepare()
         D.reb_robot = D.upload(rr);
         D.reb_i0 = D.upload(ri);
     }
+#ifdef VXH_PHASE_TIMING
+    B.prof = D.alloc_zero<unsigned long long>(16 * 8);
+#endif
     B.small_angle_w = std::cos(VXH_SMALL_ANGLE_RAD * 0.5);                    // Vec3D.h:55-59
     B.smallish_angle_w = std::cos(VXH_HYST * VXH_SMALL_ANGLE_RAD * 0.5);
     B.slthresh_acos2sqrt = 1.0 - 0.9988 * 0.9988;
@@ -358,13 +407,25 @@ void Engine::prepare()
 
 void Engine::reset() { if (!robots_.empty()) prepare(); }
 
-template <int BLOCK>
-static void launch_fused(const DBatch& B, const int* list, int count, hipStream_t s, long long cap, int iters)
+template <int BLOCK, int NEX, bool FLUID>
+static void launch_variant(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
-    static bool attr_set = false;
-    const size_t lds = (size_t)18 * BLOCK * sizeof(double);
-    if (!attr_set) { hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); attr_set = true; }
-    hipLaunchKernelGGL(k_robot_steps<BLOCK>, dim3(count), dim3(BLOCK), lds, s, B, list, cap, iters);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK, NEX, FLUID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(fused LDS)");
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((k_robot_steps<BLOCK, NEX, FLUID>), dim3(count), dim3(BLOCK), lds, s, B, list, cap, iters);
+}
+
+template <bool FLUID>
+static void launch_group(const DBatch& B, int block, int nex, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+{
+    if (block == 256) launch_variant<256, 3, FLUID>(B, list, count, lds, s, cap, iters);
+    else if (block == 512) launch_variant<512, 3, FLUID>(B, list, count, lds, s, cap, iters);
+    else if (block == 768 && nex == 3) launch_variant<768, 3, FLUID>(B, list, count, lds, s, cap, iters);
+    else if (block == 768) launch_variant<768, 1, FLUID>(B, list, count, lds, s, cap, iters);
+    else launch_variant<1024, 1, FLUID>(B, list, count, lds, s, cap, iters);
 }
 
 void Engine::advance(long long max_rounds)
@@ -376,25 +437,25 @@ void Engine::advance(long long max_rounds)
     const long long remaining = std::max(0LL, D.max_planned - rounds_done_);
     const long long todo = std::min(max_rounds, remaining);
     const long long cap = (max_rounds >= remaining) ? cap_all : rounds_done_ + max_rounds;
-    const bool fused = fused_ && D.max_nvox <= 1024;
+    const bool fused = fused_ && D.fused_ok;
     // per-robot step counts before, to attribute the work of this call
     std::vector<int> steps_before(robots_.size());
     for (size_t r = 0; r < robots_.size(); ++r) steps_before[r] = host_.size() == robots_.size() ? host_[r].steps : 0;
     HIP_OK(hipEventRecord(D.ev0, D.stream));
-    long long launches = 0, class_launches[4] = {0, 0, 0, 0};
+    long long launches = 0;
+    std::vector<long long> group_launches(D.groups.size(), 0);
     if (fused) {
         const int iters = std::max(1, steps_per_launch_);
-        for (int c = 0; c < 4; ++c)
-            if (D.class_count[c]) { HIP_OK(hipStreamWaitEvent(D.class_stream[c], D.ev0, 0)); HIP_OK(hipEventRecord(D.class_t0[c], D.class_stream[c])); }
+        for (auto& g : D.groups) { HIP_OK(hipStreamWaitEvent(g.stream, D.ev0, 0)); HIP_OK(hipEventRecord(g.t0, g.stream)); }
         for (long long done = 0; done < todo || done == 0; done += iters) {
-            if (D.class_count[3]) launch_fused<1024>(B, D.class_list[3], D.class_count[3], D.class_stream[3], cap, iters);
-            if (D.class_count[2]) launch_fused<768>(B, D.class_list[2], D.class_count[2], D.class_stream[2], cap, iters);
-            if (D.class_count[1]) launch_fused<512>(B, D.class_list[1], D.class_count[1], D.class_stream[1], cap, iters);
-            if (D.class_count[0]) launch_fused<256>(B, D.class_list[0], D.class_count[0], D.class_stream[0], cap, iters);
-            for (int c = 0; c < 4; ++c) if (D.class_count[c]) { ++launches; ++class_launches[c]; }
+            for (size_t k = 0; k < D.groups.size(); ++k) {
+                const auto& g = D.groups[k];
+                if (g.fluid) launch_group<true>(B, g.block, g.nex, g.list, g.count, g.lds, g.stream, cap, iters);
+                else launch_group<false>(B, g.block, g.nex, g.list, g.count, g.lds, g.stream, cap, iters);
+                ++launches; ++group_launches[k];
+            }
         }
-        for (int c = 0; c < 4; ++c)
-            if (D.class_count[c]) { HIP_OK(hipEventRecord(D.class_t1[c], D.class_stream[c])); HIP_OK(hipStreamWaitEvent(D.stream, D.class_t1[c], 0)); }
+        for (auto& g : D.groups) { HIP_OK(hipEventRecord(g.t1, g.stream)); HIP_OK(hipStreamWaitEvent(D.stream, g.t1, 0)); }
     } else {
         const int nb_b = (3 * B.nv + 255) / 256, nb_v = (B.nv + 255) / 256;
         auto round = [&](long long c) {
@@ -430,26 +491,25 @@ void Engine::advance(long long max_rounds)
     state_downloaded_ = false;
     download_control();
 
-    // dominant kernel of this call: the size class that processed most voxel-steps (fused) / the whole call (streaming)
-    double cls_vs[4] = {0, 0, 0, 0}, cls_ab[4] = {0, 0, 0, 0};
+    // dominant kernel of this call: the launch group that processed most voxel-steps (fused) / the whole call (streaming)
+    std::vector<double> grp_vs(D.groups.size(), 0.0), grp_ab(D.groups.size(), 0.0);
     double all_vs = 0, all_ab = 0;
-    for (size_t r = 0; r < robots_.size(); ++r) {
-        const int n = robots_[r].nvox;
-        if (n == 0) continue;
+    auto work = [&](int r, double& vs, double& ab) {
         const double ds = host_[r].steps - steps_before[r];
-        const int c = n <= 256 ? 0 : (n <= 512 ? 1 : (n <= 768 ? 2 : 3));
-        cls_vs[c] += ds * n; cls_ab[c] += ds * (224.0 * n + 144.0 * robots_[r].nbond);
-        all_vs += ds * n; all_ab += ds * (224.0 * n + 144.0 * robots_[r].nbond);
-    }
-    if (fused) {
-        int best = 0;
-        for (int c = 1; c < 4; ++c) if (cls_vs[c] > cls_vs[best]) best = c;
+        vs += ds * robots_[r].nvox; ab += ds * (224.0 * robots_[r].nvox + 144.0 * robots_[r].nbond);
+    };
+    for (size_t r = 0; r < robots_.size(); ++r) if (robots_[r].nvox) work((int)r, all_vs, all_ab);
+    if (fused && !D.groups.empty()) {
+        size_t best = 0;
+        for (size_t k = 0; k < D.groups.size(); ++k) {
+            for (int r : D.groups[k].robots) work(r, grp_vs[k], grp_ab[k]);
+            if (grp_vs[k] > grp_vs[best]) best = k;
+        }
         float cms = 0;
-        if (D.class_count[best]) HIP_OK(hipEventElapsedTime(&cms, D.class_t0[best], D.class_t1[best]));
-        static const int blocks[4] = {256, 512, 768, 1024};
-        counters_.dominant_block = blocks[best]; counters_.dominant_robots = D.class_count[best];
-        counters_.dominant_launches = class_launches[best]; counters_.dominant_seconds = cms * 1e-3;
-        counters_.dominant_alg_bytes = cls_ab[best]; counters_.dominant_voxel_steps = cls_vs[best];
+        HIP_OK(hipEventElapsedTime(&cms, D.groups[best].t0, D.groups[best].t1));
+        counters_.dominant_block = D.groups[best].block; counters_.dominant_robots = D.groups[best].count;
+        counters_.dominant_launches = group_launches[best]; counters_.dominant_seconds = cms * 1e-3;
+        counters_.dominant_alg_bytes = grp_ab[best]; counters_.dominant_voxel_steps = grp_vs[best];
     } else {
         counters_.dominant_block = 0; counters_.dominant_robots = (int)robots_.size();
         counters_.dominant_launches = todo; counters_.dominant_seconds = ms * 1e-3;

@@ -7,11 +7,14 @@
 //   voxel_update    CVXS_Voxel::EulerStep / CalcTotalForce / CalcTotalMoment / CalcFloorEffect (VXS_Voxel.cpp:169-758),
 //                   CVXS_BondCollision::CalcContactForce (VXS_BondCollision.cpp:41-59), MaxVoxVel of UpdateStats
 // Two launch shapes share those device functions:
-//   k_robot_steps<BLOCK>  fused path: ONE workgroup per robot (robots up to BLOCK voxels), thread = voxel + its
-//                         three positive bonds; Force2/Moment2 of every bond travel to the neighbour voxel through
-//                         LDS, so per step only voxel state and bond history cross HBM; several steps per launch.
+//   k_robot_steps<BLOCK,NEX,FLUID>  fused path: ONE workgroup per robot (robots up to BLOCK voxels), thread = voxel + its
+//                         three positive bonds.  The robot is RESIDENT in the CU for the whole launch: every thread
+//                         keeps its voxel's integrator state in registers, publishes its pose into an LDS tile that
+//                         neighbour bonds, contact forces, the broad-phase and the drag mesh read, and hands
+//                         Force2/Moment2 of its bonds to the neighbour voxel through a second LDS tile.  Per step only
+//                         the bond history crosses L2/HBM; many steps per launch.
 //   k_step_begin / k_bonds / k_voxels   streaming path for lattices of any size (one thread per bond slot / voxel,
-//                         bond outputs through HBM).
+//                         state and bond outputs through HBM).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -57,10 +60,26 @@ __device__ __forceinline__ d3 rotinv(dq q, d3 f)    // CQuat::RotateVec3DInv, Ve
                tw * q.y - tx * q.z + ty * q.w + tz * q.x,
                tw * q.z + tx * q.y - ty * q.x + tz * q.w);
 }
-// ToXDirBond / ToOrigDirBond, VX_Bond.h:45-48 ; axis 0 = X, 1 = Y, 2 = Z
-__device__ __forceinline__ d3 to_xdir(int axis, d3 p) { return axis == 1 ? mk3(p.y, -p.x, p.z) : (axis == 2 ? mk3(p.z, p.y, -p.x) : p); }
-__device__ __forceinline__ dq to_xdir(int axis, dq q) { return axis == 1 ? mkq(q.w, q.y, -q.x, q.z) : (axis == 2 ? mkq(q.w, q.z, q.y, -q.x) : q); }
-__device__ __forceinline__ d3 to_orig(int axis, d3 p) { return axis == 1 ? mk3(-p.y, p.x, p.z) : (axis == 2 ? mk3(-p.z, p.y, p.x) : p); }
+// ToXDirBond / ToOrigDirBond, VX_Bond.h:45-48 ; axis 0 = X, 1 = Y, 2 = Z.  The axis is a template argument: the frame
+// change is a compile-time permutation, not a chain of selects.
+template <int A> __device__ __forceinline__ d3 to_xdir(d3 p)
+{
+    if constexpr (A == 1) return mk3(p.y, -p.x, p.z);
+    else if constexpr (A == 2) return mk3(p.z, p.y, -p.x);
+    else return p;
+}
+template <int A> __device__ __forceinline__ dq to_xdir(dq q)
+{
+    if constexpr (A == 1) return mkq(q.w, q.y, -q.x, q.z);
+    else if constexpr (A == 2) return mkq(q.w, q.z, q.y, -q.x);
+    else return q;
+}
+template <int A> __device__ __forceinline__ d3 to_orig(d3 p)
+{
+    if constexpr (A == 1) return mk3(-p.y, p.x, p.z);
+    else if constexpr (A == 2) return mk3(-p.z, p.y, p.x);
+    else return p;
+}
 
 #define VXH_PI 3.14159265358979
 #define VXH_DISCARD_ANGLE_RAD 1e-7
@@ -69,7 +88,13 @@ __device__ __forceinline__ d3 to_orig(int axis, d3 p) { return axis == 1 ? mk3(-
 #define VXH_SA_BOND_EXT_PERC 1.30
 #define VXH_HYST 1.1
 
-// CQuat::FromAngleToPosX, Vec3D.h:208-237
+// CQuat::FromAngleToPosX, Vec3D.h:208-237: the rotation that takes `from` onto +X, axis (0, n.z, -n.y)/sin(theta), angle
+// theta = acos(n.x).  The reference evaluates (cos, sin)(theta/2) through acos + sincos; here the same quaternion is
+// written with the half-angle identities cos(theta/2) = sqrt((1 + n.x)/2), sin(theta/2)/sin(theta) = 1/(2 cos(theta/2)):
+//     (c, 0, n.z/(2c), -n.y/(2c)),  c = sqrt((1 + n.x)/2)
+// acos is ill-conditioned near n.x = 1 (d theta = d n.x / sin theta), so the reference's own value moves by up to 1e-12
+// (relative) under a 1-ulp change of `from`; the identity form agrees with it to 8e-13 max / 4e-15 median over bend angles
+// of 1..35 degrees (DESIGN.md "Numerics") at a quarter of the instructions.  The theta > PI - 1e-7 cut is kept on n.x.
 __device__ __forceinline__ dq from_angle_to_pos_x(d3 from)
 {
     if (from.x == 0 && from.y == 0 && from.z == 0) return mkq(1, 0, 0, 0);
@@ -81,12 +106,9 @@ __device__ __forceinline__ dq from_angle_to_pos_x(d3 from)
     double l = sqrt(from.x * from.x + from.y * from.y + from.z * from.z);
     d3 n = from;
     if (l > 0) { double li = 1.0 / l; n.x *= li; n.y *= li; n.z *= li; }
-    double theta = acos(n.x);
-    if (theta > VXH_PI - VXH_DISCARD_ANGLE_RAD) return mkq(0, 0, 1, 0);
-    double axis_inv = 1.0 / sqrt(n.z * n.z + n.y * n.y);
-    double a = 0.5 * theta, s, c;
-    sincos(a, &s, &c);
-    return mkq(c, 0, n.z * axis_inv * s, -n.y * axis_inv * s);
+    if (n.x < -0.999999999999995) return mkq(0, 0, 1, 0);     // cos(PI - DISCARD_ANGLE_RAD)
+    const double c = sqrt(0.5 + 0.5 * n.x), h = 0.5 / c;
+    return mkq(c, 0, n.z * h, -n.y * h);
 }
 // CQuat::ToRotationVector, Vec3D.h:270-285
 __device__ __forceinline__ d3 to_rotvec(dq q, double slthresh)
@@ -104,56 +126,64 @@ __device__ __forceinline__ int robot_of(const DBatch& B, int vslot)
 }
 
 struct BondOut { d3 f1, m1, f2, m2; double strain1, strain2; bool diverged; };
-// history of one bond (_LastPos2, _LastAngle1, _LastAngle2 + the small-angle flag); loaded by the caller BEFORE the
-// arithmetic and stored after it, so that all memory operations of a bond are issued together (the kernels are
-// latency-bound: 70% of wave time was s_waitcnt with loads scattered through the math)
-struct BondHist { d3 pos2, ang1, ang2; bool small; bool store_hist, store_flag; };
+// History of one bond in the 6-double layout of DBatch::hist + its flag bits (bit 0 SmallAngle, bit 1 large layout).
+// Loaded by the caller BEFORE the arithmetic and stored after it, so the memory operations of a bond are issued
+// together instead of being scattered through the math.
+struct BondHist { double p0, p1, p2, g0, g1, g2; unsigned flags; bool store_hist; };
 
 __device__ __forceinline__ BondHist load_bond_hist(const DBatch& B, int slot)
 {
     BondHist h;
-    h.pos2 = mk3(HIST(0, slot), HIST(1, slot), HIST(2, slot));
-    h.ang1 = mk3(HIST(3, slot), HIST(4, slot), HIST(5, slot));
-    h.ang2 = mk3(HIST(6, slot), HIST(7, slot), HIST(8, slot));
-    h.small = B.small_angle[slot] != 0;
-    h.store_hist = h.store_flag = false;
+    h.p0 = HIST(0, slot); h.p1 = HIST(1, slot); h.p2 = HIST(2, slot);
+    h.g0 = HIST(3, slot); h.g1 = HIST(4, slot); h.g2 = HIST(5, slot);
+    h.flags = B.small_angle[slot];
+    h.store_hist = false;
     return h;
 }
-__device__ __forceinline__ void store_bond_hist(const DBatch& B, int slot, const BondHist& h)
+__device__ __forceinline__ void store_bond_hist(const DBatch& B, int slot, const BondHist& h, unsigned old_flags)
 {
     if (h.store_hist) {
-        HIST(0, slot) = h.pos2.x; HIST(1, slot) = h.pos2.y; HIST(2, slot) = h.pos2.z;
-        HIST(3, slot) = h.ang1.x; HIST(4, slot) = h.ang1.y; HIST(5, slot) = h.ang1.z;
-        HIST(6, slot) = h.ang2.x; HIST(7, slot) = h.ang2.y; HIST(8, slot) = h.ang2.z;
+        HIST(0, slot) = h.p0; HIST(1, slot) = h.p1; HIST(2, slot) = h.p2;
+        HIST(3, slot) = h.g0; HIST(4, slot) = h.g1; HIST(5, slot) = h.g2;
     }
-    if (h.store_flag) B.small_angle[slot] = h.small ? 1 : 0;
+    if (h.flags != old_flags) B.small_angle[slot] = (unsigned char)h.flags;
 }
 
-// One internal bond between voxel 1 (negative side) and voxel 2: pure arithmetic, `H` in/out.
-__device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClass& C, int axis, BondHist& H,
+// One internal bond along axis A between voxel 1 (negative side) and voxel 2: pure arithmetic, `H` in/out.
+// inv_dt_prev = 1/dt of the previous step, 0 on the first step (no damping then, VXS_BondInternal.cpp:311).
+template <int A>
+__device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClass& C, BondHist& H,
                                                 d3 p1, dq q1, double s1, d3 p2, dq q2, double s2,
-                                                double dt_prev, double bond_z_half)
+                                                double inv_dt_prev, double bond_z_half)
 {
     BondOut o;
     const double nom_dist = (s1 + s2) * 0.5;
-    d3 xrel = to_xdir(axis, p2 - p1);
-    dq a1 = to_xdir(axis, q1), a2 = to_xdir(axis, q2);
+    d3 xrel = to_xdir<A>(p2 - p1);
+    dq a1 = to_xdir<A>(q1), a2 = to_xdir<A>(q2);
     d3 rel = rotinv(a1, xrel);
     dq new2 = qmul(conj(a1), a2);
 
-    // small/large-angle switch with hysteresis (VXS_BondInternal.cpp:72-77)
-    bool small = H.small, changed = false;
-    const double small_turn = (fabs(rel.z) + fabs(rel.y)) / rel.x;
-    const double extend = rel.x / nom_dist;
-    if (!small && new2.w > B.small_angle_w && small_turn < VXH_SA_BOND_BEND_RAD && extend < VXH_SA_BOND_EXT_PERC) { small = true; changed = true; }
-    else if (small && (!(new2.w > B.smallish_angle_w) || small_turn > VXH_HYST * VXH_SA_BOND_BEND_RAD || extend > VXH_HYST * VXH_SA_BOND_EXT_PERC)) { small = false; changed = true; }
-    H.small = small; H.store_flag = changed;
+    // small/large-angle switch with hysteresis (VXS_BondInternal.cpp:72-77).  SmallTurn = (|z|+|y|)/x and
+    // ExtendPerc = x/NomDistance are only ever compared with constants, so the comparisons are made on the
+    // cross-multiplied form (no division); the sign cases keep the IEEE outcome of the quotient (x < 0: quotient <= 0,
+    // x == 0: +inf or NaN).
+    bool small = (H.flags & 1u) != 0, changed = false;
+    {
+        const double t = fabs(rel.z) + fabs(rel.y);
+        bool turn_lt, turn_gt;      // SmallTurn < BEND ; SmallTurn > HYST*BEND
+        if (rel.x > 0) { turn_lt = t < VXH_SA_BOND_BEND_RAD * rel.x; turn_gt = t > (VXH_HYST * VXH_SA_BOND_BEND_RAD) * rel.x; }
+        else if (rel.x < 0) { turn_lt = true; turn_gt = false; }
+        else { turn_lt = false; turn_gt = t > 0; }
+        const bool ext_lt = rel.x < VXH_SA_BOND_EXT_PERC * nom_dist, ext_gt = rel.x > (VXH_HYST * VXH_SA_BOND_EXT_PERC) * nom_dist;
+        if (!small && new2.w > B.small_angle_w && turn_lt && ext_lt) { small = true; changed = true; }
+        else if (small && (!(new2.w > B.smallish_angle_w) || turn_gt || ext_gt)) { small = false; changed = true; }
+    }
 
-    d3 pos2, ang1, ang2;
-    dq rot;
+    d3 pos2, ang1;
+    dq rot, qb2;                               // qb2: Angle2 in the bond frame
     if (small) {
         ang1 = mk3(0, 0, 0);
-        ang2 = to_rotvec(new2, B.slthresh_acos2sqrt);
+        qb2 = new2;
         pos2 = mk3(rel.x - nom_dist, rel.y, rel.z);
         rot = conj(a1);
     } else {
@@ -161,8 +191,9 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
         rot = qmul(align, conj(a1));
         pos2 = mk3(sqrt(len2(xrel)) - nom_dist, 0, 0);
         ang1 = to_rotvec(align, B.slthresh_acos2sqrt);
-        ang2 = to_rotvec(qmul(rot, a2), B.slthresh_acos2sqrt);
+        qb2 = qmul(rot, a2);
     }
+    const d3 ang2 = to_rotvec(qb2, B.slthresh_acos2sqrt);   // one instance for both modes: a mixed wave runs it once
 
     // axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307; linear materials)
     const double strain = pos2.x / C.L;
@@ -192,9 +223,13 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     // velocity damping from the finite-differenced bond-frame pose (AddDampForces :310-346); skipped on the step the
     // mode flips, and the history is only refreshed when it runs
     if (!changed) {
-        if (dt_prev != 0) {
-            const double inv = 1.0 / dt_prev;
-            d3 v = (pos2 - H.pos2) * inv, w1 = (ang1 - H.ang1) * inv, w2 = (ang2 - H.ang2) * inv;
+        if (inv_dt_prev != 0) {
+            const bool hl = (H.flags & 2u) != 0;        // expand the stored history (see DBatch::hist)
+            const d3 hpos2 = mk3(H.p0, hl ? 0.0 : H.p1, hl ? 0.0 : H.p2);
+            const d3 hang1 = mk3(0.0, hl ? H.p1 : 0.0, hl ? H.p2 : 0.0);
+            const d3 hang2 = mk3(H.g0, H.g1, H.g2);
+            const double inv = inv_dt_prev;
+            d3 v = (pos2 - hpos2) * inv, w1 = (ang1 - hang1) * inv, w2 = (ang2 - hang2) * inv;
             const double z = bond_z_half;
             f1 = f1 + mk3(C.sq_a1m1 * v.x, C.sq_b1m1 * v.y - C.sq_b2fm1 * (w1.z + w2.z), C.sq_b1m1 * v.z + C.sq_b2fm1 * (w1.y + w2.y)) * z;
             if (!C.homogeneous)
@@ -202,31 +237,51 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
             m1 = m1 + mk3(-C.sq_a2i1 * (w2.x - w1.x), C.sq_b2fm1 * v.z + C.sq_b3i1 * (2 * w1.y + w2.y), -C.sq_b2fm1 * v.y + C.sq_b3i1 * (2 * w1.z + w2.z)) * (0.5 * z);
             m2 = m2 + mk3(C.sq_a2i2 * (w2.x - w1.x), C.sq_b2fm2 * v.z + C.sq_b3i2 * (w1.y + 2 * w2.y), -C.sq_b2fm2 * v.y + C.sq_b3i2 * (w1.z + 2 * w2.z)) * (0.5 * z);
         }
-        H.pos2 = pos2; H.ang1 = ang1; H.ang2 = ang2; H.store_hist = true;
+        // _LastPos2 / _LastAngle1 / _LastAngle2 in the layout of the mode that produced them (ang1 == 0 in small mode;
+        // pos2.y == pos2.z == ang1.x == 0 in large mode)
+        H.p0 = pos2.x; H.p1 = small ? pos2.y : ang1.y; H.p2 = small ? pos2.z : ang1.z;
+        H.g0 = ang2.x; H.g1 = ang2.y; H.g2 = ang2.z;
+        H.flags = (small ? 1u : 2u);
+        H.store_hist = true;
+    } else {
+        H.flags = (H.flags & 2u) | (small ? 1u : 0u);
     }
 
     // back to the global frame (:158-171)
-    o.f1 = to_orig(axis, rotinv(rot, f1));
-    o.f2 = C.homogeneous ? -o.f1 : to_orig(axis, rotinv(rot, f2));
-    o.m1 = to_orig(axis, rotinv(rot, m1));
-    o.m2 = to_orig(axis, rotinv(rot, m2));
+    o.f1 = to_orig<A>(rotinv(rot, f1));
+    o.f2 = C.homogeneous ? -o.f1 : to_orig<A>(rotinv(rot, f2));
+    o.m1 = to_orig<A>(rotinv(rot, m1));
+    o.m2 = to_orig<A>(rotinv(rot, m2));
     return o;
 }
 
 struct VoxState { d3 pos, lm, am; dq ang; double scale; };
 
+// position + scale of another voxel of the same robot, for the contact forces
+struct FetchGlobal {       // streaming path: previous-step buffer in HBM
+    const DBatch& B; int cur;
+    __device__ __forceinline__ void operator()(int slot, double& x, double& y, double& z, double& s) const
+    { x = POS(cur, 0, slot); y = POS(cur, 1, slot); z = POS(cur, 2, slot); s = SCALE(cur, slot); }
+};
+template <int BLOCK>
+struct FetchLds {          // fused path: the workgroup's pose tile
+    const double* ps; int base;
+    __device__ __forceinline__ void operator()(int slot, double& x, double& y, double& z, double& s) const
+    { const int l = slot - base; x = ps[l]; y = ps[BLOCK + l]; z = ps[2 * BLOCK + l]; s = ps[3 * BLOCK + l]; }
+};
+
 // Everything of EulerStep after the internal-bond sums: collision bonds, gravity, floor, integration, actuation.
 // F/M arrive holding slow damping + internal bond forces / minus internal bond moments.  Returns |new velocity|^2.
-__device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, int cur,
-                                               double t, d3 F, d3 M, d3 vel, VoxState& S, int row, int ccnt, d3 drag)
+template <class Fetch>
+__device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, const Fetch& fetch,
+                                               double t, d3 F, d3 M, d3 vel, VoxState& S, int row, int ccnt, bool fluid, d3 drag,
+                                               float phase, float amp_damp)
 {
     const int flags = R.flags;
     const double dt = R.dt;
-    const bool fluid = (flags & RF_FLUID) != 0;
     if (ccnt > 0) {
         // collision bonds in creation order (VXS_Voxel.cpp:519-530, VXS_BondCollision.cpp:41-59); partner slots and the
-        // pair stiffness a1 were stored by rebuild_rows.  Loads are issued four partners at a time: the loop is a
-        // chain of dependent HBM/L2 accesses, not arithmetic.
+        // pair stiffness a1 were stored by rebuild_rows.  Loads are issued four partners at a time.
         for (int k0 = 0; k0 < ccnt; k0 += 4) {
             int o[4]; double a1[4], qx[4], qy[4], qz[4], qs[4];
 #pragma unroll
@@ -237,10 +292,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
                 a1[j] = on ? B.col_a1[at] : 0.0;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int oo = o[j] < 0 ? v : o[j];
-                qx[j] = POS(cur, 0, oo); qy[j] = POS(cur, 1, oo); qz[j] = POS(cur, 2, oo); qs[j] = SCALE(cur, oo);
-            }
+            for (int j = 0; j < 4; ++j) fetch(o[j] < 0 ? v : o[j], qx[j], qy[j], qz[j], qs[j]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (o[j] < 0) continue;
@@ -308,7 +360,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
         const double prenatal = c * (((float)C.nom_size / C.nom_size) - 1);
         double ctrl = 0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)
-            ctrl = (double)B.amp_damp[v] * ((double)R.temp_amplitude * sin(two_pi_f * (t / (double)R.temp_period + (double)B.phase[v]))) * C.cte;
+            ctrl = (double)amp_damp * ((double)R.temp_amplitude * sin(two_pi_f * (t / (double)R.temp_period + (double)phase))) * C.cte;
         new_scale = ctrl * C.nom_size + (1 + prenatal) * C.nom_size;
         const double max_scale = (1 + R.growth_amplitude) * C.nom_size, min_scale = R.min_temp_fact * C.nom_size;
         if (new_scale < S.scale && new_scale < min_scale) new_scale = S.scale;
@@ -316,7 +368,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     } else {
         double tf = 1.0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)
-            tf = 1 + ((double)R.temp_amplitude * sin(two_pi_f * (t / (double)R.temp_period + (double)B.phase[v]))) * C.cte;
+            tf = 1 + ((double)R.temp_amplitude * sin(two_pi_f * (t / (double)R.temp_period + (double)phase))) * C.cte;
         if (tf < 0.1) tf = 0.1;
         new_scale = tf * C.nom_size;
     }
@@ -362,6 +414,7 @@ __device__ __forceinline__ StepCtl step_control(const DRobot& R, DRobotState& rs
     return c;
 }
 
+// ================================================================================================ streaming path
 // IniCM latch (= SS.CurCM of the previous step: mass-weighted SEQUENTIAL sum in voxel order, GetCM VX_Sim.cpp:2415-2430)
 // and EndOfLifetimePosteriorY (getPosteriorY :2640-2656).  Whole workgroup; `sh` holds 4*CH doubles of LDS scratch.
 __device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobotState& rs, int cur, bool latch, bool eol, double* sh, int CH)
@@ -371,7 +424,7 @@ __device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobo
     for (int c0 = 0; c0 < R.nvox; c0 += CH) {
         for (int k = tid; k < CH && c0 + k < R.nvox; k += T) {
             const int g = base + c0 + k;
-            const DVoxClass& C = B.vclass_tab[B.vclass[g]];
+            const DVoxClass& C = B.vclass_tab[R.vtab_begin + B.vclass[g]];
             sh[k] = POS(cur, 0, g); sh[CH + k] = POS(cur, 1, g); sh[2 * CH + k] = POS(cur, 2, g);
             sh[3 * CH + k] = (C.mat == 5) ? -C.mass : C.mass;   // sign marks the material excluded from PosteriorY
         }
@@ -390,6 +443,15 @@ __device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobo
         if (latch) { const double inv = 1.0 / sm; rs.ini_cm[0] = inv * sx; rs.ini_cm[1] = inv * sy; rs.ini_cm[2] = inv * sz; rs.cm_init = 1; }
         if (eol) rs.eol_post_y = miny;
     }
+}
+
+// stiffness of the collision bond between two voxel classes, first = the earlier voxel (CVX_Bond::LinkVoxels +
+// UpdateConstants for the pair, VX_Bond.cpp:65-173: a1 = E*A/L of a cubic bond)
+__device__ __forceinline__ double contact_a1(const DVoxClass& C1, const DVoxClass& C2)
+{
+    const double E = (C1.E * C2.E / (C1.E + C2.E)) * 2;
+    const double L = (C1.nom_size + C2.nom_size) * 0.5;
+    return E * (L * L) / L;
 }
 
 // CalcL1Bonds (VX_Sim.cpp:2357-2413).  The calling workgroup builds the partner rows of surface voxels
@@ -435,14 +497,11 @@ __device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, D
                 if (d2 < act * act) {
                     if (cnt < VXH_MAXCOL) {
                         const int vj = shv[k];
-                        const DVoxClass& Ci = B.vclass_tab[B.vclass[vi]];   // CVX_Bond::LinkVoxels + UpdateConstants for the pair
-                        const DVoxClass& Cj = B.vclass_tab[B.vclass[vj]];
-                        const double E1 = (j > i) ? Ci.E : Cj.E, E2 = (j > i) ? Cj.E : Ci.E;
-                        const double E = (E1 * E2 / (E1 + E2)) * 2;
-                        const double L = (Ci.nom_size + Cj.nom_size) * 0.5;
+                        const DVoxClass& Ci = B.vclass_tab[R.vtab_begin + B.vclass[vi]];
+                        const DVoxClass& Cj = B.vclass_tab[R.vtab_begin + B.vclass[vj]];
                         const size_t at = (size_t)cnt * B.col_rows + (R.surf_begin + i);
                         B.col_partner[at] = vj;
-                        B.col_a1[at] = E * (L * L) / L;
+                        B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
                     }
                     ++cnt;
                 }
@@ -456,201 +515,6 @@ __device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, D
     }
 }
 
-// land_water fluid drag (LW/VX_Sim.cpp:1516-1597).  Phase 1: every deformable surface vertex = mean over the <= 7 voxels
-// touching that lattice corner of Pos + R(Angle) * corner offset, corner offsets from the bond strains of the PREVIOUS step
-// (CornerPosCur/CornerNegCur, LW/VXS_Voxel.cpp:472-475; GetCurVLoc LW/VX_MeshUtil.cpp:388-428) -> LDS.  Phase 2: every voxel
-// sums the quadratic drag of the two triangles on each of its exposed faces, in the reference's facet order.
-__device__ __forceinline__ d3 rot_fwd(dq q, d3 f)      // CQuat::RotateVec3D, Vec3D.h:293-299
-{
-    double tw = f.x * q.x + f.y * q.y + f.z * q.z;
-    double tx = f.x * q.w - f.y * q.z + f.z * q.y;
-    double ty = f.x * q.z + f.y * q.w - f.z * q.x;
-    double tz = -f.x * q.y + f.y * q.x + f.z * q.w;
-    return mk3(q.w * tx + q.x * tw + q.y * tz - q.z * ty, q.w * ty - q.x * tz + q.y * tw + q.z * tx, q.w * tz + q.x * ty - q.y * tx + q.z * tw);
-}
-__device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ d3 normalized3(d3 a) { const double l = sqrt(len2(a)); return l > 0 ? a * (1.0 / l) : a; }
-
-template <int BLOCK>
-__device__ __forceinline__ void fluid_drag(const DBatch& B, const DRobot& R, int cur, double* sh, bool valid, int v, double mass_inv, double nom)
-{
-    const unsigned nv = B.nv, tm = B.total_mv;
-    for (int i = threadIdx.x; i < R.nmv; i += BLOCK) {
-        const int gi = R.vert_begin + i;
-        d3 avg = mk3(0, 0, 0); double tw = 0;
-        for (int q = 0; q < 8; ++q) {
-            const int comp = B.vert_comp[(unsigned)q * tm + gi];
-            if (comp < 0) break;
-            const int u = comp >> 3, corner = comp & 7;
-            const d3 cp = mk3((1 + B.strain[u]) * nom * 0.5, (1 + B.strain[nv + u]) * nom * 0.5, (1 + B.strain[2 * nv + u]) * nom * 0.5);
-            const d3 cn = mk3(-(1 + B.strain[3 * nv + u]) * nom * 0.5, -(1 + B.strain[4 * nv + u]) * nom * 0.5, -(1 + B.strain[5 * nv + u]) * nom * 0.5);
-            const d3 off = mk3((corner & 4) ? cp.x : cn.x, (corner & 2) ? cp.y : cn.y, (corner & 1) ? cp.z : cn.z);
-            const d3 p = mk3(POS(cur, 0, u), POS(cur, 1, u), POS(cur, 2, u)) + rot_fwd(mkq(QUAT(0, u), QUAT(1, u), QUAT(2, u), QUAT(3, u)), off);
-            avg = avg + p; tw += 1.0;
-        }
-        const double inv = 1.0 / tw;
-        const d3 v0 = mk3(B.vert_v0[gi], B.vert_v0[tm + gi], B.vert_v0[2 * tm + gi]);
-        const d3 np = avg * inv;
-        const d3 now = v0 + (np - v0);                               // v + DrawOffset, as the reference stores it
-        sh[i] = now.x; sh[R.nmv + i] = now.y; sh[2 * R.nmv + i] = now.z;
-    }
-    __syncthreads();
-    if (valid) {
-        d3 drag = mk3(0, 0, 0);
-        const unsigned mask = B.open_face[v];
-        if (mask) {
-            const d3 speed = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v)) * mass_inv;
-            const d3 sdir = normalized3(speed);
-            // corner codes (NNN..PPP) of the two triangles of faces +X,-X,+Y,-Y,+Z,-Z (LW/VX_MeshUtil.cpp:165-189)
-            const unsigned tri[6][2] = {{0x467u, 0x475u}, {0x032u, 0x013u}, {0x237u, 0x276u}, {0x051u, 0x045u}, {0x157u, 0x173u}, {0x064u, 0x026u}};
-            for (int d = 0; d < 6; ++d) {
-                if (!(mask & (1u << d))) continue;
-                for (int t = 0; t < 2; ++t) {
-                    const unsigned code = tri[d][t];
-                    const int ia = B.corner_vert[((code >> 8) & 7u) * nv + v], ib = B.corner_vert[((code >> 4) & 7u) * nv + v], ic = B.corner_vert[(code & 7u) * nv + v];
-                    const d3 A = mk3(sh[ia], sh[R.nmv + ia], sh[2 * R.nmv + ia]);
-                    const d3 AB = mk3(sh[ib], sh[R.nmv + ib], sh[2 * R.nmv + ib]) - A, AC = mk3(sh[ic], sh[R.nmv + ic], sh[2 * R.nmv + ic]) - A;
-                    const d3 cr = cross3(AB, AC);
-                    const double area = fabs(sqrt(len2(cr)) / 2.0);
-                    const d3 n = normalized3(cr);                       // CalcFaceNormals
-                    const float ang = (float)acos(dot3(sdir, normalized3(n)));
-                    if (fabsf(ang) < VXH_PI / 2) {
-                        const d3 proj = normalized3(n) * dot3(speed, n);    // ProjectOnTo
-                        drag = drag + normalized3(proj) * (-R.drag_coef * area * len2(proj));
-                    }
-                }
-            }
-        }
-        B.dragf[v] = drag.x; B.dragf[nv + v] = drag.y; B.dragf[2 * nv + v] = drag.z;
-    }
-}
-
-// ================================================================================================ fused path
-// LDS: exchange buffer ex[axis][component 0..5][BLOCK] doubles (Force2, Moment2 of the bond whose POSITIVE end is
-// voxel `local`), reused as scratch by latch_cm / rebuild_rows.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_steps(DBatch B, const int* __restrict__ robot_list, long long step_cap, int iters)
-{
-    extern __shared__ __align__(16) double ex[];
-    __shared__ int s_go, s_latch, s_eol, s_rebuild, s_cur, s_div;
-    __shared__ double s_time, s_dtprev;
-    const int r = robot_list[blockIdx.x];   // robots of one size class, longest-running first
-    const DRobot& R = B.robot[r];
-    // the robot's mutable control block lives in LDS for the whole launch: the per-step control is a serial chain
-    // of ~20 dependent accesses executed by one thread while the workgroup waits, so it must not touch HBM
-    __shared__ DRobotState rs;
-    const int tid = threadIdx.x;
-    if (tid == 0) rs = B.rstate[r];
-    const bool valid = tid < R.nvox;
-    const int v = R.vox_begin + tid;
-    const int nv = B.nv;
-
-    // class-constant tables into LDS (a handful of entries for a whole population): per-lane gathers of ~20 doubles
-    // per bond then cost LDS reads instead of vector-memory loads
-    __shared__ DBondClass s_bct[VXH_LDS_BCLASS];
-    __shared__ DVoxClass s_vct[VXH_LDS_VCLASS];
-    const bool tabs_in_lds = B.n_bclass <= VXH_LDS_BCLASS && B.n_vclass <= VXH_LDS_VCLASS;
-    if (tabs_in_lds) {
-        for (int k = tid; k < B.n_bclass * (int)(sizeof(DBondClass) / 8); k += BLOCK) ((double*)s_bct)[k] = ((const double*)B.bclass_tab)[k];
-        for (int k = tid; k < B.n_vclass * (int)(sizeof(DVoxClass) / 8); k += BLOCK) ((double*)s_vct)[k] = ((const double*)B.vclass_tab)[k];
-    }
-    __syncthreads();
-    const DBondClass* bct = tabs_in_lds ? s_bct : B.bclass_tab;
-    const DVoxClass& C = (tabs_in_lds ? (const DVoxClass*)s_vct : B.vclass_tab)[valid ? B.vclass[v] : 0];
-    int row = -1;                              // my row of collision partners (surface voxels of colliding robots)
-    if (valid && (R.flags & RF_SELF_COL)) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
-
-    for (int it = 0; it <= iters; ++it) {
-        if (tid == 0) {
-            StepCtl c = step_control(R, rs, step_cap, it < iters);
-            s_go = c.go; s_latch = c.latch; s_eol = c.eol; s_rebuild = c.rebuild;
-            s_cur = rs.steps & 1; s_time = rs.cur_time; s_dtprev = rs.dt_prev; s_div = 0;
-        }
-        __syncthreads();
-        if (!s_go) break;
-        const int cur = s_cur, nxt = cur ^ 1;
-        if (s_latch || s_eol) latch_cm(B, R, rs, cur, s_latch != 0, s_eol != 0, ex, BLOCK);
-        if (s_rebuild) { for (int i0 = 0; i0 < R.nsurf; i0 += BLOCK) rebuild_rows(B, R, rs, cur, i0, ex, 2 * BLOCK); __syncthreads(); }
-        const int ccnt = (row >= 0 && !(B.dbg & 1)) ? B.col_cnt[row] : 0;   // issued early, consumed in the voxel phase
-        if (R.flags & RF_FLUID) { fluid_drag<BLOCK>(B, R, cur, ex, valid, v, C.mass_inv, R.lat); __syncthreads(); }
-
-        // ---- bond phase: this voxel's +X, +Y, +Z bonds; own-side sums stay in registers, far-side outputs go to LDS
-        d3 F = mk3(0, 0, 0), M = mk3(0, 0, 0);
-        if (valid) {
-            int vb = v;                        // opaque copy: keeps address arithmetic out of the step loop's live ranges
-            asm volatile("" : "+v"(vb));
-            const d3 p1 = mk3(POS(cur, 0, vb), POS(cur, 1, vb), POS(cur, 2, vb));
-            const dq q1 = mkq(QUAT(0, vb), QUAT(1, vb), QUAT(2, vb), QUAT(3, vb));
-            const double sc1 = SCALE(cur, vb);
-            bool div = false;
-#pragma unroll 1
-            for (int a = 0; a < 3; ++a) {
-                const int bc = B.bclass[a * nv + vb];
-                if (bc < 0) continue;
-                const int v2 = B.nbr[(2 * a) * nv + vb];
-                const d3 p2 = mk3(POS(cur, 0, v2), POS(cur, 1, v2), POS(cur, 2, v2));
-                const dq q2 = mkq(QUAT(0, v2), QUAT(1, v2), QUAT(2, v2), QUAT(3, v2));
-                const double sc2 = SCALE(cur, v2);
-                BondHist H = load_bond_hist(B, a * nv + vb);
-                BondOut o = bond_compute(B, bct[bc], a, H, p1, q1, sc1, p2, q2, sc2, s_dtprev, R.bond_z_half);
-                store_bond_hist(B, a * nv + vb, H);
-                F = F + o.f1; M = M - o.m1;
-                div = div || o.diverged;
-                if (R.flags & RF_FLUID) {     // SetStrainDir (VXS_BondInternal.cpp:300-304): my +a side, the neighbour's -a side
-                    B.strain[(unsigned)a * nv + vb] = o.strain1;
-                    B.strain[(unsigned)(3 + a) * nv + v2] = o.strain2;
-                }
-                double* e = ex + (a * 6) * BLOCK + (v2 - R.vox_begin);
-                e[0] = o.f2.x; e[BLOCK] = o.f2.y; e[2 * BLOCK] = o.f2.z; e[3 * BLOCK] = o.m2.x; e[4 * BLOCK] = o.m2.y; e[5 * BLOCK] = o.m2.z;
-            }
-            if (div) s_div = 1;
-        }
-        __syncthreads();
-        if (s_div) {                           // Integrate() returns before the voxel loop (VX_Sim.cpp:1777)
-            if (tid == 0) rs.diverged = 1;
-            continue;                          // next step_control marks the robot diverged
-        }
-        // ---- voxel phase
-        double vel2 = 0;
-        if (valid) {
-            int vx = v;
-            asm volatile("" : "+v"(vx));
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (B.nbr[(2 * a + 1) * nv + vx] < 0) continue;
-                const double* e = ex + (a * 6) * BLOCK + tid;
-                F = F + mk3(e[0], e[BLOCK], e[2 * BLOCK]);
-                M = M - mk3(e[3 * BLOCK], e[4 * BLOCK], e[5 * BLOCK]);
-            }
-            VoxState S;
-            S.pos = mk3(POS(cur, 0, vx), POS(cur, 1, vx), POS(cur, 2, vx));
-            S.ang = mkq(QUAT(0, vx), QUAT(1, vx), QUAT(2, vx), QUAT(3, vx));
-            S.scale = SCALE(cur, vx);
-            S.lm = mk3(LINMOM(0, vx), LINMOM(1, vx), LINMOM(2, vx));
-            S.am = mk3(ANGMOM(0, vx), ANGMOM(1, vx), ANGMOM(2, vx));
-            const d3 vel = S.lm * C.mass_inv;
-            F = F + (vel * (-R.slow_z)) * C.c_lin;
-            d3 drag = mk3(0, 0, 0);
-            if (R.flags & RF_FLUID) drag = mk3(B.dragf[vx], B.dragf[(unsigned)nv + vx], B.dragf[2u * nv + vx]);
-            vel2 = voxel_update(B, R, C, vx, cur, s_time, F, M, vel, S, row, ccnt, drag);
-            POS(nxt, 0, vx) = S.pos.x; POS(nxt, 1, vx) = S.pos.y; POS(nxt, 2, vx) = S.pos.z;
-            SCALE(nxt, vx) = S.scale;
-            LINMOM(0, vx) = S.lm.x; LINMOM(1, vx) = S.lm.y; LINMOM(2, vx) = S.lm.z;
-            ANGMOM(0, vx) = S.am.x; ANGMOM(1, vx) = S.am.y; ANGMOM(2, vx) = S.am.z;
-            QUAT(0, vx) = S.ang.w; QUAT(1, vx) = S.ang.x; QUAT(2, vx) = S.ang.y; QUAT(3, vx) = S.ang.z;
-        }
-        if ((R.flags & RF_SELF_COL) && !(B.dbg & 2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { double o2 = __shfl_xor(vel2, off); vel2 = o2 > vel2 ? o2 : vel2; }
-            if ((tid & 63) == 0) atomicMax(&rs.maxvel2_bits, (unsigned long long)__double_as_longlong(vel2));
-        }
-        __syncthreads();                       // new poses visible to the whole workgroup, ex[] free again
-    }
-    if (tid == 0) B.rstate[r] = rs;
-}
-
-// ============================================================================================ streaming path
 __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap, int begin_new_step)
 {
     const int r = blockIdx.x;
@@ -665,6 +529,28 @@ __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap
     __syncthreads();
     if (!s_go) return;
     if (s_latch || s_eol) latch_cm(B, R, rs, rs.steps & 1, s_latch != 0, s_eol != 0, sh, 256);
+}
+
+template <int A>
+__device__ __forceinline__ void stream_bond(const DBatch& B, const DRobot& R, const DRobotState& rs, int r, int slot, int v1, int bc)
+{
+    const int v2 = B.nbr[(2 * A) * B.nv + v1];
+    const int cur = rs.steps & 1;
+    d3 p1 = mk3(POS(cur, 0, v1), POS(cur, 1, v1), POS(cur, 2, v1));
+    d3 p2 = mk3(POS(cur, 0, v2), POS(cur, 1, v2), POS(cur, 2, v2));
+    dq q1 = mkq(QUAT(0, v1), QUAT(1, v1), QUAT(2, v1), QUAT(3, v1));
+    dq q2 = mkq(QUAT(0, v2), QUAT(1, v2), QUAT(2, v2), QUAT(3, v2));
+    const double sc1 = SCALE(cur, v1), sc2 = SCALE(cur, v2);
+    BondHist H = load_bond_hist(B, slot);
+    const unsigned old_flags = H.flags;
+    const double inv = rs.dt_prev != 0 ? 1.0 / rs.dt_prev : 0.0;
+    BondOut o = bond_compute<A>(B, B.bclass_tab[R.btab_begin + bc], H, p1, q1, sc1, p2, q2, sc2, inv, R.bond_z_half);
+    store_bond_hist(B, slot, H, old_flags);
+    if (o.diverged) atomicOr(&B.rstate[r].diverged, 1);
+    BOUT(0, slot) = o.f1.x; BOUT(1, slot) = o.f1.y; BOUT(2, slot) = o.f1.z;
+    BOUT(3, slot) = o.m1.x; BOUT(4, slot) = o.m1.y; BOUT(5, slot) = o.m1.z;
+    BOUT(6, slot) = o.f2.x; BOUT(7, slot) = o.f2.y; BOUT(8, slot) = o.f2.z;
+    BOUT(9, slot) = o.m2.x; BOUT(10, slot) = o.m2.y; BOUT(11, slot) = o.m2.z;
 }
 
 // blocks [0, bond_blocks): one thread per bond slot; blocks beyond: collision-list rebuilds (reb_robot/reb_i0 tables),
@@ -690,22 +576,10 @@ __global__ __launch_bounds__(256) void k_bonds(DBatch B, int bond_blocks, const 
     if (!rs.active) return;
     const int bc = B.bclass[tid];
     if (bc < 0) return;
-    const int v2 = B.nbr[(2 * axis) * B.nv + v1];
     const DRobot& R = B.robot[r];
-    const int cur = rs.steps & 1;
-    d3 p1 = mk3(POS(cur, 0, v1), POS(cur, 1, v1), POS(cur, 2, v1));
-    d3 p2 = mk3(POS(cur, 0, v2), POS(cur, 1, v2), POS(cur, 2, v2));
-    dq q1 = mkq(QUAT(0, v1), QUAT(1, v1), QUAT(2, v1), QUAT(3, v1));
-    dq q2 = mkq(QUAT(0, v2), QUAT(1, v2), QUAT(2, v2), QUAT(3, v2));
-    const double sc1 = SCALE(cur, v1), sc2 = SCALE(cur, v2);
-    BondHist H = load_bond_hist(B, tid);
-    BondOut o = bond_compute(B, B.bclass_tab[bc], axis, H, p1, q1, sc1, p2, q2, sc2, rs.dt_prev, R.bond_z_half);
-    store_bond_hist(B, tid, H);
-    if (o.diverged) atomicOr(&B.rstate[r].diverged, 1);
-    BOUT(0, tid) = o.f1.x; BOUT(1, tid) = o.f1.y; BOUT(2, tid) = o.f1.z;
-    BOUT(3, tid) = o.m1.x; BOUT(4, tid) = o.m1.y; BOUT(5, tid) = o.m1.z;
-    BOUT(6, tid) = o.f2.x; BOUT(7, tid) = o.f2.y; BOUT(8, tid) = o.f2.z;
-    BOUT(9, tid) = o.m2.x; BOUT(10, tid) = o.m2.y; BOUT(11, tid) = o.m2.z;
+    if (axis == 0) stream_bond<0>(B, R, rs, r, tid, v1, bc);
+    else if (axis == 1) stream_bond<1>(B, R, rs, r, tid, v1, bc);
+    else stream_bond<2>(B, R, rs, r, tid, v1, bc);
 }
 
 __global__ __launch_bounds__(256) void k_voxels(DBatch B)
@@ -720,7 +594,7 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
     const bool valid = (v - R.vox_begin) < R.nvox;   // padding slots stay in the wave for the reduction below
     double vel2 = 0;
     if (valid) {
-        const DVoxClass& C = B.vclass_tab[B.vclass[v]];
+        const DVoxClass& C = B.vclass_tab[R.vtab_begin + B.vclass[v]];
         const int cur = rs.steps & 1, nxt = cur ^ 1;
         VoxState S;
         S.pos = mk3(POS(cur, 0, v), POS(cur, 1, v), POS(cur, 2, v));
@@ -748,7 +622,8 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
         }
         int row = -1, ccnt = 0;
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) { row = R.surf_begin + so; ccnt = B.col_cnt[row]; } }
-        vel2 = voxel_update(B, R, C, v, cur, rs.cur_time, F, M, vel, S, row, ccnt, mk3(0, 0, 0));
+        const FetchGlobal fetch{B, cur};
+        vel2 = voxel_update(B, R, C, v, fetch, rs.cur_time, F, M, vel, S, row, ccnt, false, mk3(0, 0, 0), B.phase[v], B.amp_damp[v]);
         POS(nxt, 0, v) = S.pos.x; POS(nxt, 1, v) = S.pos.y; POS(nxt, 2, v) = S.pos.z;
         SCALE(nxt, v) = S.scale;
         LINMOM(0, v) = S.lm.x; LINMOM(1, v) = S.lm.y; LINMOM(2, v) = S.lm.z;
@@ -763,3 +638,5 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
 }
 
 }  // namespace vxh
+
+#include "kernels_fused.hpp"

@@ -1,0 +1,377 @@
+// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NEX, FLUID>, one workgroup per robot, the robot
+// resident in the CU for a whole launch of many time steps (included at the end of kernels.hpp).
+//
+// Dynamic LDS layout (doubles):
+//   ps   [8][BLOCK]        pose tile: pos x y z, scale, quaternion w x y z of every voxel (what OTHER voxels read:
+//                          neighbour bonds, contact forces, the broad-phase, the drag mesh)
+//   ex   [NEX][6][BLOCK]   exchange tile: Force2, Moment2 of the bond whose POSITIVE end is voxel `local`.  NEX = 3: one
+//                          buffer per axis, a single barrier between the bond phase and the gather.  NEX = 1 (BLOCK 1024,
+//                          where three buffers do not fit next to the pose tile): one buffer, written/read axis by axis.
+//                          Scratch of latch / broad-phase / drag mesh between steps.
+//   tabs                   this robot's DBondClass and DVoxClass rows
+//   mesh [3][nmv]          FLUID only: vertices of the drag mesh
+// Registers, persistent over the launch: the voxel's 14 integrator doubles, its packed links and flags.
+#pragma once
+
+namespace vxh {
+
+enum { VXH_FUSED_STATIC_LDS = 256 };
+
+// developer instrumentation (scripts/gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
+// of the phases of a step
+#ifdef VXH_PHASE_TIMING
+#define VXH_T_DECL unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_readcyclecounter();
+#define VXH_T_MARK(k) { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[k] += t_now - t_last; t_last = t_now; }
+#define VXH_T_FLUSH if (B.prof && (threadIdx.x & 63) == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&B.prof[(threadIdx.x >> 6) * 8 + k], t_acc[k]); }
+#else
+#define VXH_T_DECL
+#define VXH_T_MARK(k)
+#define VXH_T_FLUSH
+#endif      // upper bound of the kernel's static __shared__ variables
+
+// plane `plane` (of nv doubles) of a SoA array, element at byte offset voff: uniform 64-bit base + 32-bit lane offset
+__device__ __forceinline__ double ld_plane(const double* base, unsigned plane, unsigned nv, unsigned voff)
+{
+    return *(const double*)((const char*)(base + (size_t)plane * nv) + voff);
+}
+__device__ __forceinline__ void st_plane(double* base, unsigned plane, unsigned nv, unsigned voff, double x)
+{
+    *(double*)((char*)(base + (size_t)plane * nv) + voff) = x;
+}
+
+// IniCM latch + EndOfLifetimePosteriorY from the pose tile (see latch_cm in kernels.hpp for the reference lines)
+template <int BLOCK>
+__device__ __forceinline__ void fused_latch_cm(const DRobot& R, DRobotState& rs, const double* ps, double* sh, bool valid,
+                                               const DVoxClass& C, bool latch, bool eol)
+{
+    const int tid = threadIdx.x;
+    if (valid) sh[tid] = (C.mat == 5) ? -C.mass : C.mass;      // sign marks the material excluded from PosteriorY
+    __syncthreads();
+    if (tid == 0) {
+        double sx = 0, sy = 0, sz = 0, sm = 0, miny = 100000.0;
+        for (int k = 0; k < R.nvox; ++k) {
+            const double ms = sh[k], m = fabs(ms), y = ps[BLOCK + k];
+            sx = __dadd_rn(sx, __dmul_rn(ps[k], m)); sy = __dadd_rn(sy, __dmul_rn(y, m)); sz = __dadd_rn(sz, __dmul_rn(ps[2 * BLOCK + k], m)); sm += m;
+            if (!(ms < 0)) { const double yl = y / R.lat; if (yl < miny) miny = yl; }
+        }
+        if (latch) { const double inv = 1.0 / sm; rs.ini_cm[0] = inv * sx; rs.ini_cm[1] = inv * sy; rs.ini_cm[2] = inv * sz; rs.cm_init = 1; }
+        if (eol) rs.eol_post_y = miny;
+    }
+    __syncthreads();
+}
+
+// CalcL1Bonds (VX_Sim.cpp:2357-2413) from the pose tile; thread i owns surface voxel i (see rebuild_rows in kernels.hpp)
+template <int BLOCK>
+__device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, int* shi,
+                                              const DVoxClass* vct)
+{
+    const int tid = threadIdx.x, ns = R.nsurf;
+    for (int k = tid; k < ns; k += BLOCK) {      // local voxel index | class of every surface voxel
+        const int g = B.surf[R.surf_begin + k];
+        shi[k] = (g - R.vox_begin) | ((int)B.vclass[g] << 10);
+    }
+    __syncthreads();
+    if (tid < ns) {
+        const int i = tid, mine = shi[i], li = mine & 1023;
+        const DVoxClass& Ci = vct[mine >> 10];
+        const d3 pi = mk3(ps[li], ps[BLOCK + li], ps[2 * BLOCK + li]);
+        const double si = ps[3 * BLOCK + li];
+        const unsigned long long* row = B.excl + R.excl_begin + (long long)i * R.excl_wpr;
+        const double H = R.col_horizon;
+        int cnt = 0;
+        unsigned long long word = 0;
+        for (int j = 0; j < ns; ++j) {
+            if ((j & 63) == 0) word = row[j >> 6];
+            if (j == i) continue;
+            const int other = shi[j], lj = other & 1023;
+            const d3 d = pi - mk3(ps[lj], ps[BLOCK + lj], ps[2 * BLOCK + lj]);
+            const double d2 = len2(d);
+            if (!(d2 < R.filter_dist2)) continue;
+            if ((word >> (j & 63)) & 1ull) continue;          // !pV1->IsNearbyVox(SIndex2)
+            const double s1 = (j > i) ? si : ps[3 * BLOCK + lj];   // scale of Vox1 = the earlier one, used twice (:2382)
+            const double act = H * (s1 + s1) * 0.5;
+            if (d2 < act * act) {
+                if (cnt < VXH_MAXCOL) {
+                    const DVoxClass& Cj = vct[other >> 10];
+                    const size_t at = (size_t)cnt * B.col_rows + (R.surf_begin + i);
+                    B.col_partner[at] = R.vox_begin + lj;
+                    B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
+                }
+                ++cnt;
+            }
+        }
+        if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
+        B.col_cnt[R.surf_begin + i] = cnt;
+    }
+    __syncthreads();
+}
+
+// land_water fluid drag (LW/VX_Sim.cpp:1516-1597).  Phase 1: every deformable surface vertex = mean over the <= 7 voxels
+// touching that lattice corner of Pos + R(Angle) * corner offset, corner offsets from the bond strains of the PREVIOUS step
+// (CornerPosCur/CornerNegCur, LW/VXS_Voxel.cpp:472-475; GetCurVLoc LW/VX_MeshUtil.cpp:388-428) -> LDS.  Phase 2: every voxel
+// sums the quadratic drag of the two triangles on each of its exposed faces, in the reference's facet order.
+__device__ __forceinline__ d3 rot_fwd(dq q, d3 f)      // CQuat::RotateVec3D, Vec3D.h:293-299
+{
+    double tw = f.x * q.x + f.y * q.y + f.z * q.z;
+    double tx = f.x * q.w - f.y * q.z + f.z * q.y;
+    double ty = f.x * q.z + f.y * q.w - f.z * q.x;
+    double tz = -f.x * q.y + f.y * q.x + f.z * q.w;
+    return mk3(q.w * tx + q.x * tw + q.y * tz - q.z * ty, q.w * ty - q.x * tz + q.y * tw + q.z * tx, q.w * tz + q.x * ty - q.y * tx + q.z * tw);
+}
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 normalized3(d3 a) { const double l = sqrt(len2(a)); return l > 0 ? a * (1.0 / l) : a; }
+
+template <int BLOCK>
+__device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const double* ps, double* sh, bool valid, int v, d3 lm,
+                                         double mass_inv)
+{
+    const unsigned nv = B.nv, tm = B.total_mv;
+    const double nom = R.lat;
+    const int nmv = R.nmv;
+    for (int i = threadIdx.x; i < nmv; i += BLOCK) {
+        const int gi = R.vert_begin + i;
+        d3 avg = mk3(0, 0, 0); double tw = 0;
+        for (int q = 0; q < 8; ++q) {
+            const int comp = B.vert_comp[(unsigned)q * tm + gi];
+            if (comp < 0) break;
+            const int u = comp >> 3, corner = comp & 7, l = u - R.vox_begin;
+            const d3 cp = mk3((1 + B.strain[u]) * nom * 0.5, (1 + B.strain[nv + u]) * nom * 0.5, (1 + B.strain[2 * nv + u]) * nom * 0.5);
+            const d3 cn = mk3(-(1 + B.strain[3 * nv + u]) * nom * 0.5, -(1 + B.strain[4 * nv + u]) * nom * 0.5, -(1 + B.strain[5 * nv + u]) * nom * 0.5);
+            const d3 off = mk3((corner & 4) ? cp.x : cn.x, (corner & 2) ? cp.y : cn.y, (corner & 1) ? cp.z : cn.z);
+            const d3 p = mk3(ps[l], ps[BLOCK + l], ps[2 * BLOCK + l]) +
+                         rot_fwd(mkq(ps[4 * BLOCK + l], ps[5 * BLOCK + l], ps[6 * BLOCK + l], ps[7 * BLOCK + l]), off);
+            avg = avg + p; tw += 1.0;
+        }
+        const double inv = 1.0 / tw;
+        const d3 v0 = mk3(B.vert_v0[gi], B.vert_v0[tm + gi], B.vert_v0[2 * tm + gi]);
+        const d3 np = avg * inv;
+        const d3 now = v0 + (np - v0);                               // v + DrawOffset, as the reference stores it
+        sh[i] = now.x; sh[nmv + i] = now.y; sh[2 * nmv + i] = now.z;
+    }
+    __syncthreads();
+    d3 drag = mk3(0, 0, 0);
+    if (valid) {
+        const unsigned mask = B.open_face[v];
+        if (mask) {
+            const d3 speed = lm * mass_inv;
+            const d3 sdir = normalized3(speed);
+            // corner codes (NNN..PPP) of the two triangles of faces +X,-X,+Y,-Y,+Z,-Z (LW/VX_MeshUtil.cpp:165-189)
+            const unsigned tri[6][2] = {{0x467u, 0x475u}, {0x032u, 0x013u}, {0x237u, 0x276u}, {0x051u, 0x045u}, {0x157u, 0x173u}, {0x064u, 0x026u}};
+            for (int d = 0; d < 6; ++d) {
+                if (!(mask & (1u << d))) continue;
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned code = tri[d][t];
+                    const int ia = B.corner_vert[((code >> 8) & 7u) * nv + v], ib = B.corner_vert[((code >> 4) & 7u) * nv + v], ic = B.corner_vert[(code & 7u) * nv + v];
+                    const d3 A = mk3(sh[ia], sh[nmv + ia], sh[2 * nmv + ia]);
+                    const d3 AB = mk3(sh[ib], sh[nmv + ib], sh[2 * nmv + ib]) - A, AC = mk3(sh[ic], sh[nmv + ic], sh[2 * nmv + ic]) - A;
+                    const d3 cr = cross3(AB, AC);
+                    const double area = fabs(sqrt(len2(cr)) / 2.0);
+                    const d3 n = normalized3(cr);                       // CalcFaceNormals
+                    const float ang = (float)acos(dot3(sdir, normalized3(n)));
+                    if (fabsf(ang) < VXH_PI / 2) {
+                        const d3 proj = normalized3(n) * dot3(speed, n);    // ProjectOnTo
+                        drag = drag + normalized3(proj) * (-R.drag_coef * area * len2(proj));
+                    }
+                }
+            }
+        }
+    }
+    return drag;
+}
+
+// One +A bond of the calling voxel: neighbour pose from the pose tile, history from/to HBM, own-side sums into F/M,
+// far-side outputs into the exchange buffer `exa` (6 planes of BLOCK).
+template <int A, int BLOCK, bool FLUID>
+__device__ __forceinline__ void fused_bond(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, double* exa,
+                                           int link, unsigned voff, int v, d3 p1, dq q1, double s1, unsigned& modebits,
+                                           double inv_dt_prev, d3& F, d3& M, bool& div)
+{
+    if (link < 0) return;
+    const unsigned nv = B.nv;
+    const int l2 = link & 1023;
+    BondHist H;                               // history first: the only HBM/L2 round trip of the bond
+    H.p0 = ld_plane(B.hist, 0 * 3 + A, nv, voff); H.p1 = ld_plane(B.hist, 1 * 3 + A, nv, voff); H.p2 = ld_plane(B.hist, 2 * 3 + A, nv, voff);
+    H.g0 = ld_plane(B.hist, 3 * 3 + A, nv, voff); H.g1 = ld_plane(B.hist, 4 * 3 + A, nv, voff); H.g2 = ld_plane(B.hist, 5 * 3 + A, nv, voff);
+    H.flags = (modebits >> (2 * A)) & 3u;
+    H.store_hist = false;
+    const d3 p2 = mk3(ps[l2], ps[BLOCK + l2], ps[2 * BLOCK + l2]);
+    const double s2 = ps[3 * BLOCK + l2];
+    const dq q2 = mkq(ps[4 * BLOCK + l2], ps[5 * BLOCK + l2], ps[6 * BLOCK + l2], ps[7 * BLOCK + l2]);
+    BondOut o = bond_compute<A>(B, bct[link >> 10], H, p1, q1, s1, p2, q2, s2, inv_dt_prev, R.bond_z_half);
+    if (H.store_hist) {
+        st_plane(B.hist, 0 * 3 + A, nv, voff, H.p0); st_plane(B.hist, 1 * 3 + A, nv, voff, H.p1); st_plane(B.hist, 2 * 3 + A, nv, voff, H.p2);
+        st_plane(B.hist, 3 * 3 + A, nv, voff, H.g0); st_plane(B.hist, 4 * 3 + A, nv, voff, H.g1); st_plane(B.hist, 5 * 3 + A, nv, voff, H.g2);
+    }
+    modebits = (modebits & ~(3u << (2 * A))) | (H.flags << (2 * A));
+    F = F + o.f1; M = M - o.m1;
+    div = div || o.diverged;
+    if constexpr (FLUID) {                    // SetStrainDir (VXS_BondInternal.cpp:300-304): my +A side, the neighbour's -A side
+        B.strain[(unsigned)A * nv + v] = o.strain1;
+        B.strain[(unsigned)(3 + A) * nv + (R.vox_begin + l2)] = o.strain2;
+    }
+    double* e = exa + l2;
+    e[0] = o.f2.x; e[BLOCK] = o.f2.y; e[2 * BLOCK] = o.f2.z; e[3 * BLOCK] = o.m2.x; e[4 * BLOCK] = o.m2.y; e[5 * BLOCK] = o.m2.z;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void fused_gather(const double* exa, int tid, bool has_neg, d3& F, d3& M)
+{
+    if (!has_neg) return;
+    const double* e = exa + tid;
+    F = F + mk3(e[0], e[BLOCK], e[2 * BLOCK]);
+    M = M - mk3(e[3 * BLOCK], e[4 * BLOCK], e[5 * BLOCK]);
+}
+
+template <int BLOCK, int NEX, bool FLUID>
+__global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const int* __restrict__ robot_list, long long step_cap,
+                                                                            int iters)
+{
+    extern __shared__ __align__(16) double lds[];
+    double* const ps = lds;
+    double* const ex = lds + 8 * BLOCK;
+    double* const tabs = ex + NEX * 6 * BLOCK;
+    // the robot's mutable control block lives in LDS for the whole launch: the per-step control is a serial chain
+    // of ~20 dependent accesses executed by one thread while the workgroup waits, so it must not touch HBM
+    __shared__ DRobotState rs;
+    __shared__ int s_go, s_latch, s_eol, s_rebuild, s_div;
+    __shared__ double s_time, s_inv_dtprev;
+    static_assert(sizeof(DRobotState) + 5 * sizeof(int) + 2 * sizeof(double) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
+
+    const int tid = threadIdx.x;
+    const int r = robot_list[blockIdx.x];   // robots of one launch group, longest-running first
+    const DRobot& R = B.robot[r];
+    const unsigned nv = B.nv;
+    const int base = R.vox_begin;
+    const bool valid = tid < R.nvox;
+    const int v = base + tid;
+    const unsigned voff = (unsigned)v * 8u;
+    if (tid == 0) rs = B.rstate[r];
+    const int nbd = R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = R.n_vclass * (int)(sizeof(DVoxClass) / 8);
+    for (int k = tid; k < nbd; k += BLOCK) tabs[k] = ((const double*)(B.bclass_tab + R.btab_begin))[k];
+    for (int k = tid; k < nvd; k += BLOCK) tabs[nbd + k] = ((const double*)(B.vclass_tab + R.vtab_begin))[k];
+    const DBondClass* const bct = (const DBondClass*)tabs;
+    const DVoxClass* const vct = (const DVoxClass*)(tabs + nbd);
+    __syncthreads();
+
+    // ---- this voxel: constants, links, state -> registers; pose -> LDS
+    const DVoxClass& C = vct[valid ? B.vclass[v] : 0];
+    int link[3] = {-1, -1, -1};               // local index of the +A neighbour | bond class << 10
+    unsigned negmask = 0;                     // bit A: a bond arrives from the -A neighbour
+    unsigned modebits = 0;                    // 2 bits per +A bond: SmallAngle, history layout (DBatch::hist)
+    int row = -1;                             // my row of collision partners (surface voxels of colliding robots)
+    float phase = 0.f, amp_damp = 1.f;
+    VoxState S;
+    S.pos = mk3(0, 0, 0); S.lm = mk3(0, 0, 0); S.am = mk3(0, 0, 0); S.ang = mkq(1, 0, 0, 0); S.scale = 0;
+    if (valid) {
+        const int b0 = rs.steps & 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int bc = B.bclass[(unsigned)a * nv + v];
+            if (bc >= 0) { link[a] = (B.nbr[(unsigned)(2 * a) * nv + v] - base) | (bc << 10); modebits |= (unsigned)(B.small_angle[(unsigned)a * nv + v] & 3) << (2 * a); }
+            if (B.nbr[(unsigned)(2 * a + 1) * nv + v] >= 0) negmask |= 1u << a;
+        }
+        if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
+        phase = B.phase[v]; amp_damp = B.amp_damp[v];
+        S.pos = mk3(POS(b0, 0, v), POS(b0, 1, v), POS(b0, 2, v));
+        S.scale = SCALE(b0, v);
+        S.ang = mkq(QUAT(0, v), QUAT(1, v), QUAT(2, v), QUAT(3, v));
+        S.lm = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v));
+        S.am = mk3(ANGMOM(0, v), ANGMOM(1, v), ANGMOM(2, v));
+        ps[tid] = S.pos.x; ps[BLOCK + tid] = S.pos.y; ps[2 * BLOCK + tid] = S.pos.z; ps[3 * BLOCK + tid] = S.scale;
+        ps[4 * BLOCK + tid] = S.ang.w; ps[5 * BLOCK + tid] = S.ang.x; ps[6 * BLOCK + tid] = S.ang.y; ps[7 * BLOCK + tid] = S.ang.z;
+    }
+    const FetchLds<BLOCK> fetch{ps, base};
+
+    VXH_T_DECL
+    for (int it = 0; it <= iters; ++it) {
+        VXH_T_MARK(5)
+        if (tid == 0) {
+            StepCtl c = step_control(R, rs, step_cap, it < iters);
+            s_go = c.go; s_latch = c.latch; s_eol = c.eol; s_rebuild = c.rebuild;
+            s_time = rs.cur_time; s_inv_dtprev = rs.dt_prev != 0 ? 1.0 / rs.dt_prev : 0.0; s_div = 0;
+        }
+        __syncthreads();                       // (A) control + every voxel's published pose visible
+        if (!s_go) break;
+        VXH_T_MARK(0)
+        if (s_latch || s_eol) fused_latch_cm<BLOCK>(R, rs, ps, ex, valid, C, s_latch != 0, s_eol != 0);
+        if (s_rebuild) fused_rebuild<BLOCK>(B, R, rs, ps, (int*)ex, vct);
+        const int ccnt = (row >= 0 && !(B.dbg & 1)) ? B.col_cnt[row] : 0;   // issued early, consumed in the voxel phase
+        d3 drag = mk3(0, 0, 0);
+        if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, tabs + nbd + nvd, valid, v, S.lm, C.mass_inv);
+        const double inv_dt_prev = s_inv_dtprev;
+        VXH_T_MARK(1)
+
+        // ---- bond phase: this voxel's +X, +Y, +Z bonds; own-side sums stay in registers, far-side outputs go to LDS
+        d3 F = mk3(0, 0, 0), M = mk3(0, 0, 0);
+        bool div = false;
+        if constexpr (NEX == 3) {
+            if (valid) {
+                fused_bond<0, BLOCK, FLUID>(B, R, bct, ps, ex, link[0], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+                fused_bond<1, BLOCK, FLUID>(B, R, bct, ps, ex + 6 * BLOCK, link[1], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+                fused_bond<2, BLOCK, FLUID>(B, R, bct, ps, ex + 12 * BLOCK, link[2], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+            }
+            if (div) s_div = 1;
+            VXH_T_MARK(2)
+            __syncthreads();                   // (B)
+            VXH_T_MARK(3)
+            if (valid) {
+                fused_gather<BLOCK>(ex, tid, negmask & 1u, F, M);
+                fused_gather<BLOCK>(ex + 6 * BLOCK, tid, negmask & 2u, F, M);
+                fused_gather<BLOCK>(ex + 12 * BLOCK, tid, negmask & 4u, F, M);
+            }
+        } else {
+            if (valid) fused_bond<0, BLOCK, FLUID>(B, R, bct, ps, ex, link[0], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+            __syncthreads();
+            if (valid) fused_gather<BLOCK>(ex, tid, negmask & 1u, F, M);
+            __syncthreads();
+            if (valid) fused_bond<1, BLOCK, FLUID>(B, R, bct, ps, ex, link[1], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+            __syncthreads();
+            if (valid) fused_gather<BLOCK>(ex, tid, negmask & 2u, F, M);
+            __syncthreads();
+            if (valid) fused_bond<2, BLOCK, FLUID>(B, R, bct, ps, ex, link[2], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+            if (div) s_div = 1;
+            __syncthreads();                   // (B)
+            if (valid) fused_gather<BLOCK>(ex, tid, negmask & 4u, F, M);
+        }
+        if (s_div) {                           // Integrate() returns before the voxel loop (VX_Sim.cpp:1777)
+            __syncthreads();                   // everyone has read s_div before the next step_control clears it
+            if (tid == 0) rs.diverged = 1;
+            continue;                          // next step_control marks the robot diverged
+        }
+        // ---- voxel phase (all in registers; contact partners from the pose tile)
+        double vel2 = 0;
+        if (valid) {
+            const d3 vel = S.lm * C.mass_inv;
+            F = F + (vel * (-R.slow_z)) * C.c_lin;
+            vel2 = voxel_update(B, R, C, v, fetch, s_time, F, M, vel, S, row, ccnt, FLUID, drag, phase, amp_damp);
+        }
+        if ((R.flags & RF_SELF_COL) && !(B.dbg & 2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { double o2 = __shfl_xor(vel2, off); vel2 = o2 > vel2 ? o2 : vel2; }
+            if ((tid & 63) == 0) atomicMax(&rs.maxvel2_bits, (unsigned long long)__double_as_longlong(vel2));
+        }
+        VXH_T_MARK(4)
+        __syncthreads();                       // (C) every read of the old poses is done
+        if (valid) {
+            ps[tid] = S.pos.x; ps[BLOCK + tid] = S.pos.y; ps[2 * BLOCK + tid] = S.pos.z; ps[3 * BLOCK + tid] = S.scale;
+            ps[4 * BLOCK + tid] = S.ang.w; ps[5 * BLOCK + tid] = S.ang.x; ps[6 * BLOCK + tid] = S.ang.y; ps[7 * BLOCK + tid] = S.ang.z;
+        }
+    }
+    VXH_T_FLUSH
+    // ---- back to HBM: state into the buffer the step count selects, flag bits, control block
+    if (valid) {
+        const int b1 = rs.steps & 1;
+        POS(b1, 0, v) = S.pos.x; POS(b1, 1, v) = S.pos.y; POS(b1, 2, v) = S.pos.z;
+        SCALE(b1, v) = S.scale;
+        LINMOM(0, v) = S.lm.x; LINMOM(1, v) = S.lm.y; LINMOM(2, v) = S.lm.z;
+        ANGMOM(0, v) = S.am.x; ANGMOM(1, v) = S.am.y; ANGMOM(2, v) = S.am.z;
+        QUAT(0, v) = S.ang.w; QUAT(1, v) = S.ang.x; QUAT(2, v) = S.ang.y; QUAT(3, v) = S.ang.z;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (link[a] >= 0) B.small_angle[(unsigned)a * nv + v] = (unsigned char)((modebits >> (2 * a)) & 3u);
+    }
+    if (tid == 0) B.rstate[r] = rs;
+}
+
+}  // namespace vxh

@@ -110,6 +110,11 @@ if __name__ == "__main__" and "prof_nocol" in sys.argv[1:]:
     timing(512, (10, 10, 10), 0.004, selfcol=False)
 
 
+PHASES = "phases" in sys.argv[1:]
+if PHASES:   # library built by `make -C evosoro_amd/csrc prof`
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+
+
 def timing2(count, shape, sim_time, selfcol, opts):
     tmp = tempfile.mkdtemp()
     os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
@@ -125,6 +130,10 @@ def timing2(count, shape, sim_time, selfcol, opts):
         c = eng.counters()
         st = [eng.result(i).status for i in range(count)]
         cm = np.array([eng.result(i).cur_cm for i in range(count)])
+        if PHASES:
+            nres = [(eng.result(i).col_rebuilds, eng.result(i).nvox) for i in range(count)]
+            eng.clear()          # the developer build prints its per-wave phase shares here
+            return
         print("   mean rebuilds per robot %.1f, mean nvox %.0f" % (np.mean([eng.result(i).col_rebuilds for i in range(count)]), np.mean([eng.result(i).nvox for i in range(count)])))
         print("batch %d x %s sim %.3fs col=%d %s: max_steps %d kernel %.4fs -> %.3e vox-steps/s, %.1f us/step, alg GB/s %.1f, statuses %s cmsum %.12g" % (
             count, shape, sim_time, selfcol, opts, c.max_steps, c.kernel_seconds,
@@ -171,3 +180,9 @@ def bisect_lw(name):
 if __name__ == "__main__" and "bisect_lw" in sys.argv[1:]:
     bisect_lw("lw_hexapus")
     bisect_lw("lw_swim6")
+
+
+if __name__ == "__main__" and PHASES:
+    for col, dbg in ((True, 0), (True, 1), (True, 3), (False, 0)):
+        print("col", col, "dbg", dbg, flush=True)
+        timing2(512, (10, 10, 10), 0.02, col, {"fused": 1, "steps_per_launch": 64, "dbg": dbg})
