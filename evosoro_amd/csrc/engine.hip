@@ -415,7 +415,7 @@ static void launch_variant(const DBatch& B, const int* list, int count, size_t l
         hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK, NEX, FLUID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(fused LDS)");
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((k_robot_steps<BLOCK, NEX, FLUID>), dim3(count), dim3(BLOCK), lds, s, B, list, cap, iters);
+    hipLaunchKernelGGL((k_robot_steps<BLOCK, NEX, FLUID>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters);
 }
 
 template <bool FLUID>

@@ -224,8 +224,8 @@ __device__ __forceinline__ void fused_gather(const double* exa, int tid, bool ha
 }
 
 template <int BLOCK, int NEX, bool FLUID>
-__global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const int* __restrict__ robot_list, long long step_cap,
-                                                                            int iters)
+__global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const DRobot* __restrict__ robots,
+                                                                            const int* __restrict__ robot_list, long long step_cap, int iters)
 {
     extern __shared__ __align__(16) double lds[];
     double* const ps = lds;
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     static_assert(sizeof(DRobotState) + 5 * sizeof(int) + 2 * sizeof(double) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
-    const int r = robot_list[blockIdx.x];   // robots of one launch group, longest-running first
-    const DRobot& R = B.robot[r];
+    const int r = __builtin_amdgcn_readfirstlane(robot_list[blockIdx.x]);   // robots of one launch group, longest-running first; uniform -> scalar loads of R
+    const DRobot& R = robots[r];            // separate noalias argument: its loads stay scalar although the kernel stores to HBM
     const unsigned nv = B.nv;
     const int base = R.vox_begin;
     const bool valid = tid < R.nvox;
@@ -293,12 +293,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         }
         __syncthreads();                       // (A) control + every voxel's published pose visible
         if (!s_go) break;
+        // opaque per-step copies: keeps the compiler from hoisting every address of the step out of the loop (dozens of
+        // loop-invariant 64-bit pointers, which it then spills)
+        unsigned vo = voff; int vv = v, rowv = row;
+        asm volatile("" : "+v"(vo), "+v"(vv), "+v"(rowv));
         VXH_T_MARK(0)
         if (s_latch || s_eol) fused_latch_cm<BLOCK>(R, rs, ps, ex, valid, C, s_latch != 0, s_eol != 0);
         if (s_rebuild) fused_rebuild<BLOCK>(B, R, rs, ps, (int*)ex, vct);
-        const int ccnt = (row >= 0 && !(B.dbg & 1)) ? B.col_cnt[row] : 0;   // issued early, consumed in the voxel phase
+        const int ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;   // issued early, consumed in the voxel phase
         d3 drag = mk3(0, 0, 0);
-        if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, tabs + nbd + nvd, valid, v, S.lm, C.mass_inv);
+        if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, tabs + nbd + nvd, valid, vv, S.lm, C.mass_inv);
         const double inv_dt_prev = s_inv_dtprev;
         VXH_T_MARK(1)
 
@@ -307,9 +311,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         bool div = false;
         if constexpr (NEX == 3) {
             if (valid) {
-                fused_bond<0, BLOCK, FLUID>(B, R, bct, ps, ex, link[0], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
-                fused_bond<1, BLOCK, FLUID>(B, R, bct, ps, ex + 6 * BLOCK, link[1], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
-                fused_bond<2, BLOCK, FLUID>(B, R, bct, ps, ex + 12 * BLOCK, link[2], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+                fused_bond<0, BLOCK, FLUID>(B, R, bct, ps, ex, link[0], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+                fused_bond<1, BLOCK, FLUID>(B, R, bct, ps, ex + 6 * BLOCK, link[1], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+                fused_bond<2, BLOCK, FLUID>(B, R, bct, ps, ex + 12 * BLOCK, link[2], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
             }
             if (div) s_div = 1;
             VXH_T_MARK(2)
@@ -321,15 +325,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
                 fused_gather<BLOCK>(ex + 12 * BLOCK, tid, negmask & 4u, F, M);
             }
         } else {
-            if (valid) fused_bond<0, BLOCK, FLUID>(B, R, bct, ps, ex, link[0], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+            if (valid) fused_bond<0, BLOCK, FLUID>(B, R, bct, ps, ex, link[0], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
             __syncthreads();
             if (valid) fused_gather<BLOCK>(ex, tid, negmask & 1u, F, M);
             __syncthreads();
-            if (valid) fused_bond<1, BLOCK, FLUID>(B, R, bct, ps, ex, link[1], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+            if (valid) fused_bond<1, BLOCK, FLUID>(B, R, bct, ps, ex, link[1], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
             __syncthreads();
             if (valid) fused_gather<BLOCK>(ex, tid, negmask & 2u, F, M);
             __syncthreads();
-            if (valid) fused_bond<2, BLOCK, FLUID>(B, R, bct, ps, ex, link[2], voff, v, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
+            if (valid) fused_bond<2, BLOCK, FLUID>(B, R, bct, ps, ex, link[2], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
             if (div) s_div = 1;
             __syncthreads();                   // (B)
             if (valid) fused_gather<BLOCK>(ex, tid, negmask & 4u, F, M);
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (valid) {
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, v, fetch, s_time, F, M, vel, S, row, ccnt, FLUID, drag, phase, amp_damp);
+            vel2 = voxel_update(B, R, C, vv, fetch, s_time, F, M, vel, S, rowv, ccnt, FLUID, drag, phase, amp_damp);
         }
         if ((R.flags & RF_SELF_COL) && !(B.dbg & 2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
 #pragma unroll
