@@ -81,6 +81,42 @@ template <int A> __device__ __forceinline__ d3 to_orig(d3 p)
     else return p;
 }
 
+
+// FP64 sqrt / divide / reciprocal as the instruction sequences the device library emits for them, minus the operand
+// range scaling (v_div_scale / v_ldexp) and the special-value fix-up (v_div_fixup, v_cmp_class): for finite, normal,
+// non-zero operands -- everything on this path, which works in metres, newtons and unit quaternions -- the results are
+// bit-identical to sqrt(), a / b and 1.0 / b at 10, 8 and 7 instead of 18, 11 and 11 instructions.  The *_nn variant
+// also returns 0 for a zero argument.
+__device__ __forceinline__ double vsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double vsqrt_nn(double x) { const double s = vsqrt(x); return x == 0 ? 0.0 : s; }
+__device__ __forceinline__ double vrcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(e, r, r);
+}
+__device__ __forceinline__ double vdiv(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    double q = a * r;
+    e = __builtin_fma(-b, q, a);
+    return __builtin_fma(e, r, q);
+}
+
 #define VXH_PI 3.14159265358979
 #define VXH_DISCARD_ANGLE_RAD 1e-7
 #define VXH_SMALL_ANGLE_RAD 1.732e-2
@@ -98,16 +134,16 @@ template <int A> __device__ __forceinline__ d3 to_orig(d3 p)
 __device__ __forceinline__ dq from_angle_to_pos_x(d3 from)
 {
     if (from.x == 0 && from.y == 0 && from.z == 0) return mkq(1, 0, 0, 0);
-    double yox = from.y / from.x, zox = from.z / from.x;
+    double yox = vdiv(from.y, from.x), zox = vdiv(from.z, from.x);
     if (yox < VXH_SMALL_ANGLE_RAD && yox > -VXH_SMALL_ANGLE_RAD && zox < VXH_SMALL_ANGLE_RAD && zox > -VXH_SMALL_ANGLE_RAD) {
         double y = 0.5 * zox, z = -0.5 * yox;
         return mkq(1 + 0.5 * (-y * y - z * z), 0, y, z);
     }
-    double l = sqrt(from.x * from.x + from.y * from.y + from.z * from.z);
+    double l = vsqrt(from.x * from.x + from.y * from.y + from.z * from.z);
     d3 n = from;
-    if (l > 0) { double li = 1.0 / l; n.x *= li; n.y *= li; n.z *= li; }
+    if (l > 0) { double li = vrcp(l); n.x *= li; n.y *= li; n.z *= li; }
     if (n.x < -0.999999999999995) return mkq(0, 0, 1, 0);     // cos(PI - DISCARD_ANGLE_RAD)
-    const double c = sqrt(0.5 + 0.5 * n.x), h = 0.5 / c;
+    const double c = vsqrt(0.5 + 0.5 * n.x), h = vdiv(0.5, c);
     return mkq(c, 0, n.z * h, -n.y * h);
 }
 // CQuat::ToRotationVector, Vec3D.h:270-285
@@ -116,7 +152,7 @@ __device__ __forceinline__ d3 to_rotvec(dq q, double slthresh)
     double sl = 1.0 - q.w * q.w;
     if (sl <= 0) return mk3(0, 0, 0);
     double wc = q.w > 1 ? 1 : q.w;
-    double f = (sl < slthresh) ? sqrt((2 - 2 * wc) / sl) : acos(wc) / sqrt(sl);
+    double f = (sl < slthresh) ? vsqrt_nn(vdiv(2 - 2 * wc, sl)) : vdiv(acos(wc), vsqrt(sl));
     return mk3(2.0 * q.x * f, 2.0 * q.y * f, 2.0 * q.z * f);
 }
 
@@ -189,14 +225,14 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     } else {
         dq align = from_angle_to_pos_x(rel);
         rot = qmul(align, conj(a1));
-        pos2 = mk3(sqrt(len2(xrel)) - nom_dist, 0, 0);
+        pos2 = mk3(vsqrt(len2(xrel)) - nom_dist, 0, 0);
         ang1 = to_rotvec(align, B.slthresh_acos2sqrt);
         qb2 = qmul(rot, a2);
     }
     const d3 ang2 = to_rotvec(qb2, B.slthresh_acos2sqrt);   // one instance for both modes: a mixed wave runs it once
 
     // axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307; linear materials)
-    const double strain = pos2.x / C.L;
+    const double strain = vdiv(pos2.x, C.L);
     double stress;
     o.strain1 = o.strain2 = strain;            // CurStrainV1 / CurStrainV2 (SetStrainDir), read by the land_water drag mesh
     if (C.homogeneous) stress = C.stress_E1 * strain;
@@ -204,8 +240,8 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
         double e1 = strain, e2 = strain, t1 = C.stress_E1 * e1, t2 = C.stress_E2 * e2;
         double diff = fabs(t1 - t2), sum = fabs(t1 + t2);
         for (int it = 0; it < 3 && diff > sum * .0005; ++it) {
-            e1 = 2 * t2 / (t1 + t2) * e1;
-            e2 = 2 * t1 / (t1 + t2) * e2;
+            e1 = vdiv(2 * t2, t1 + t2) * e1;
+            e2 = vdiv(2 * t1, t1 + t2) * e2;
             t1 = C.stress_E1 * e1; t2 = C.stress_E2 * e2;
             diff = fabs(t1 - t2); sum = fabs(t1 + t2);
         }
@@ -274,8 +310,8 @@ struct FetchLds {          // fused path: the workgroup's pose tile
 // F/M arrive holding slow damping + internal bond forces / minus internal bond moments.  Returns |new velocity|^2.
 template <class Fetch>
 __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, const Fetch& fetch,
-                                               double t, d3 F, d3 M, d3 vel, VoxState& S, int row, int ccnt, bool fluid, d3 drag,
-                                               float phase, float amp_damp)
+                                               double t, double t_over_period, double prenatal_c, d3 F, d3 M, d3 vel, VoxState& S,
+                                               int row, int ccnt, bool fluid, d3 drag, float phase, float amp_damp)
 {
     const int flags = R.flags;
     const double dt = R.dt;
@@ -300,11 +336,14 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
                 d3 d = mk3(qx[j] - S.pos.x, qy[j] - S.pos.y, qz[j] - S.pos.z);   // partner - me
                 if (second) d = -d;                                    // Pos2 = pVox2 - pVox1
                 const double nom = second ? (qs[j] + S.scale) * 0.75 : (S.scale + qs[j]) * 0.75;
-                const double l = sqrt(len2(d));
-                const double reld = nom - l;
-                if (reld > 0) {
-                    d3 f2 = ((d * (1.0 / l)) * a1[j]) * reld;          // force on Vox2
-                    F = second ? F + f2 : F - f2;
+                const double d2 = len2(d);
+                if (d2 < nom * nom) {                                  // cheap reject: most listed partners are out of reach
+                    const double l = vsqrt_nn(d2);
+                    const double reld = nom - l;
+                    if (reld > 0) {
+                        d3 f2 = ((d * vrcp(l)) * a1[j]) * reld;        // force on Vox2
+                        F = second ? F + f2 : F - f2;
+                    }
                 }
             }
         }
@@ -318,8 +357,8 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
         if (pen > 0) {
             const double normal = C.k_floor * pen;
             const double fz = normal - R.col_z * C.c_lin * vel.z;
-            const double surf_vel = sqrt(vel.x * vel.x + vel.y * vel.y);
-            const double surf_force = sqrt(F.x * F.x + F.y * F.y);
+            const double surf_vel = vsqrt_nn(vel.x * vel.x + vel.y * vel.y);
+            const double surf_force = vsqrt_nn(F.x * F.x + F.y * F.y);
             const double fric = C.u_dynamic * normal;
             double fx = 0, fy = 0;
             bool stopped = (vel.x == 0 && vel.y == 0);
@@ -328,7 +367,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
                 if (surf_force < C.u_static * normal) static_fric = true;
             } else if (fric * dt < C.mass * surf_vel) {
                 // -(cos, sin)(atan2(vy, vx)) * fric == -(vx, vy)/|v| * fric
-                const double inv = fric / surf_vel;
+                const double inv = vdiv(fric, surf_vel);
                 fx = -vel.x * inv; fy = -vel.y * inv;
             } else { static_fric = true; S.lm.x = 0; S.lm.y = 0; }
             F.x += fx; F.y += fy; F.z += fz;
@@ -346,8 +385,8 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     dq spin = qmul(mkq(0, w.x * 0.5, w.y * 0.5, w.z * 0.5), S.ang);
     dq ang = mkq(S.ang.w + spin.w * dt, S.ang.x + spin.x * dt, S.ang.y + spin.y * dt, S.ang.z + spin.z * dt);
     {
-        const double l = sqrt(ang.x * ang.x + ang.y * ang.y + ang.z * ang.z + ang.w * ang.w);
-        if (l != 0) { const double li = 1.0 / l; ang.w *= li; ang.x *= li; ang.y *= li; ang.z *= li; }
+        const double l = vsqrt_nn(ang.x * ang.x + ang.y * ang.y + ang.z * ang.z + ang.w * ang.w);
+        if (l != 0) { const double li = vrcp(l); ang.w *= li; ang.x *= li; ang.y *= li; ang.z *= li; }
         if (ang.w >= 1.0) ang = mkq(1.0, 0, 0, 0);
     }
     S.ang = ang;
@@ -356,11 +395,10 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     double new_scale;
     const double two_pi_f = (double)(2 * 3.1415926f);
     if (!(flags & RF_LW)) {
-        const double c = (t >= 0.5 * R.init_cm_time) ? 1.0 : 2 * t / R.init_cm_time;
-        const double prenatal = c * (((float)C.nom_size / C.nom_size) - 1);
+        const double prenatal = prenatal_c * (((float)C.nom_size / C.nom_size) - 1);
         double ctrl = 0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)
-            ctrl = (double)amp_damp * ((double)R.temp_amplitude * sin(two_pi_f * (t / (double)R.temp_period + (double)phase))) * C.cte;
+            ctrl = (double)amp_damp * ((double)R.temp_amplitude * sin(two_pi_f * (t_over_period + (double)phase))) * C.cte;
         new_scale = ctrl * C.nom_size + (1 + prenatal) * C.nom_size;
         const double max_scale = (1 + R.growth_amplitude) * C.nom_size, min_scale = R.min_temp_fact * C.nom_size;
         if (new_scale < S.scale && new_scale < min_scale) new_scale = S.scale;
@@ -368,13 +406,17 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     } else {
         double tf = 1.0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)
-            tf = 1 + ((double)R.temp_amplitude * sin(two_pi_f * (t / (double)R.temp_period + (double)phase))) * C.cte;
+            tf = 1 + ((double)R.temp_amplitude * sin(two_pi_f * (t_over_period + (double)phase))) * C.cte;
         if (tf < 0.1) tf = 0.1;
         new_scale = tf * C.nom_size;
     }
     S.scale = new_scale;
     return len2(S.lm * C.mass_inv);
 }
+
+// uniform per-step factors of the actuation, evaluated once per robot and step instead of once per voxel
+__device__ __forceinline__ double actuation_t_over_period(const DRobot& R, double t) { return t / (double)R.temp_period; }
+__device__ __forceinline__ double actuation_prenatal_c(const DRobot& R, double t) { return (t >= 0.5 * R.init_cm_time) ? 1.0 : 2 * t / R.init_cm_time; }
 
 // ------------------------------------------------------------------------------------- per-robot step control
 struct StepCtl { int go, latch, eol, rebuild; };
@@ -623,7 +665,8 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
         int row = -1, ccnt = 0;
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) { row = R.surf_begin + so; ccnt = B.col_cnt[row]; } }
         const FetchGlobal fetch{B, cur};
-        vel2 = voxel_update(B, R, C, v, fetch, rs.cur_time, F, M, vel, S, row, ccnt, false, mk3(0, 0, 0), B.phase[v], B.amp_damp[v]);
+        vel2 = voxel_update(B, R, C, v, fetch, rs.cur_time, actuation_t_over_period(R, rs.cur_time), actuation_prenatal_c(R, rs.cur_time), F, M, vel, S, row, ccnt, false,
+                             mk3(0, 0, 0), B.phase[v], B.amp_damp[v]);
         POS(nxt, 0, v) = S.pos.x; POS(nxt, 1, v) = S.pos.y; POS(nxt, 2, v) = S.pos.z;
         SCALE(nxt, v) = S.scale;
         LINMOM(0, v) = S.lm.x; LINMOM(1, v) = S.lm.y; LINMOM(2, v) = S.lm.z;

@@ -235,8 +235,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // of ~20 dependent accesses executed by one thread while the workgroup waits, so it must not touch HBM
     __shared__ DRobotState rs;
     __shared__ int s_go, s_latch, s_eol, s_rebuild, s_div;
-    __shared__ double s_time, s_inv_dtprev;
-    static_assert(sizeof(DRobotState) + 5 * sizeof(int) + 2 * sizeof(double) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
+    __shared__ double s_time, s_inv_dtprev, s_t_over_period, s_prenatal_c;
+    static_assert(sizeof(DRobotState) + 5 * sizeof(int) + 4 * sizeof(double) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
     const int r = __builtin_amdgcn_readfirstlane(robot_list[blockIdx.x]);   // robots of one launch group, longest-running first; uniform -> scalar loads of R
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             StepCtl c = step_control(R, rs, step_cap, it < iters);
             s_go = c.go; s_latch = c.latch; s_eol = c.eol; s_rebuild = c.rebuild;
             s_time = rs.cur_time; s_inv_dtprev = rs.dt_prev != 0 ? 1.0 / rs.dt_prev : 0.0; s_div = 0;
+            s_t_over_period = actuation_t_over_period(R, rs.cur_time); s_prenatal_c = actuation_prenatal_c(R, rs.cur_time);
         }
         __syncthreads();                       // (A) control + every voxel's published pose visible
         if (!s_go) break;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (valid) {
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, vv, fetch, s_time, F, M, vel, S, rowv, ccnt, FLUID, drag, phase, amp_damp);
+            vel2 = voxel_update(B, R, C, vv, fetch, s_time, s_t_over_period, s_prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, phase, amp_damp);
         }
         if ((R.flags & RF_SELF_COL) && !(B.dbg & 2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
 #pragma unroll
