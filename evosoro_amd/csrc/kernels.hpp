@@ -422,8 +422,9 @@ __device__ __forceinline__ double actuation_prenatal_c(const DRobot& R, double t
 struct StepCtl { int go, latch, eol, rebuild; };
 
 // Executed by ONE thread per robot before every step (and once after the last): completes the previous step's
-// accounting, evaluates the stop condition and decides what this step needs.
-__device__ __forceinline__ StepCtl step_control(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step)
+// accounting, evaluates the stop condition and decides what this step needs.  Two parts: step_control_begin needs
+// nothing of the previous step's voxel phase; step_control_horizon consumes its MaxVoxVel.
+__device__ __forceinline__ StepCtl step_control_begin(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step)
 {
     StepCtl c; c.go = c.latch = c.eol = c.rebuild = 0;
     if (rs.status != 0) return c;
@@ -445,14 +446,23 @@ __device__ __forceinline__ StepCtl step_control(const DRobot& R, DRobotState& rs
     c.go = 1;
     if (!rs.cm_init && t > R.init_cm_time) c.latch = 1;                          // VX_Sim.cpp:1064
     if (!(R.flags & RF_LW) && t >= R.stop_value && rs.eol_post_y == 0) c.eol = 1;   // :1078
-    if (R.flags & RF_SELF_COL) {                                                 // UpdateCollisions :1729-1755
+    rs.active = 1;
+    return c;
+}
+__device__ __forceinline__ void step_control_horizon(const DRobot& R, DRobotState& rs, StepCtl& c)
+{
+    if (c.go && (R.flags & RF_SELF_COL)) {                                       // UpdateCollisions :1729-1755
         const double mv = sqrt(__longlong_as_double((long long)rs.maxvel2_bits));
         rs.max_disp += fabs(mv * rs.dt_prev / R.lat);
         rs.maxvel2_bits = 0ull;
         if (!(R.flags & RF_HORIZON_COL) || rs.max_disp > (R.col_horizon - 1.0) / 2) { c.rebuild = 1; rs.max_disp = 0.0; rs.rebuilds += 1; }
     }
     rs.rebuild_now = c.rebuild;
-    rs.active = 1;
+}
+__device__ __forceinline__ StepCtl step_control(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step)
+{
+    StepCtl c = step_control_begin(R, rs, step_cap, begin_new_step);
+    step_control_horizon(R, rs, c);
     return c;
 }
 

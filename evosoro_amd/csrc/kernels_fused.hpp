@@ -223,6 +223,22 @@ __device__ __forceinline__ void fused_gather(const double* exa, int tid, bool ha
     M = M - mk3(e[3 * BLOCK], e[4 * BLOCK], e[5 * BLOCK]);
 }
 
+struct FusedCtl { double time, inv_dt_prev, t_over_period, prenatal_c; int go, latch, eol, rebuild; };
+
+__device__ __forceinline__ void fused_control_begin(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step, FusedCtl& K)
+{
+    const StepCtl c = step_control_begin(R, rs, step_cap, begin_new_step);
+    K.go = c.go; K.latch = c.latch; K.eol = c.eol; K.rebuild = 0;
+    K.time = rs.cur_time; K.inv_dt_prev = rs.dt_prev != 0 ? 1.0 / rs.dt_prev : 0.0;
+    K.t_over_period = actuation_t_over_period(R, rs.cur_time); K.prenatal_c = actuation_prenatal_c(R, rs.cur_time);
+}
+__device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K)
+{
+    StepCtl c; c.go = K.go; c.latch = c.eol = c.rebuild = 0;
+    step_control_horizon(R, rs, c);
+    K.rebuild = c.rebuild;
+}
+
 template <int BLOCK, int NEX, bool FLUID>
 __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const DRobot* __restrict__ robots,
                                                                             const int* __restrict__ robot_list, long long step_cap, int iters)
@@ -234,9 +250,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // the robot's mutable control block lives in LDS for the whole launch: the per-step control is a serial chain
     // of ~20 dependent accesses executed by one thread while the workgroup waits, so it must not touch HBM
     __shared__ DRobotState rs;
-    __shared__ int s_go, s_latch, s_eol, s_rebuild, s_div;
-    __shared__ double s_time, s_inv_dtprev, s_t_over_period, s_prenatal_c;
-    static_assert(sizeof(DRobotState) + 5 * sizeof(int) + 4 * sizeof(double) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
+    // per-step control words, double-buffered by step parity: thread 0 prepares step n+1 while the slower waves are
+    // still in the voxel phase of step n (it idles at the barrier otherwise); only the collision-horizon decision,
+    // which needs every voxel's new velocity, stays between the barriers
+    __shared__ FusedCtl s_ctl[2];
+    __shared__ int s_div;
+    static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + sizeof(int) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
     const int r = __builtin_amdgcn_readfirstlane(robot_list[blockIdx.x]);   // robots of one launch group, longest-running first; uniform -> scalar loads of R
@@ -283,28 +302,26 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     }
     const FetchLds<BLOCK> fetch{ps, base};
 
+    // the control thread sits in the LAST wave: the one with the fewest (often no) voxels, so its serial work hides
+    // behind the other waves' voxel phase
+    const bool ctl_thread = tid == BLOCK - 64;
+    if (ctl_thread) { fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]); fused_control_horizon(R, rs, s_ctl[0]); s_div = 0; }
+    __syncthreads();                           // control of the first step + every voxel's pose visible
     VXH_T_DECL
-    for (int it = 0; it <= iters; ++it) {
-        VXH_T_MARK(5)
-        if (tid == 0) {
-            StepCtl c = step_control(R, rs, step_cap, it < iters);
-            s_go = c.go; s_latch = c.latch; s_eol = c.eol; s_rebuild = c.rebuild;
-            s_time = rs.cur_time; s_inv_dtprev = rs.dt_prev != 0 ? 1.0 / rs.dt_prev : 0.0; s_div = 0;
-            s_t_over_period = actuation_t_over_period(R, rs.cur_time); s_prenatal_c = actuation_prenatal_c(R, rs.cur_time);
-        }
-        __syncthreads();                       // (A) control + every voxel's published pose visible
-        if (!s_go) break;
+    for (int it = 0;; ++it) {
+        const FusedCtl& K = s_ctl[it & 1];
+        FusedCtl& Knext = s_ctl[(it + 1) & 1];
+        if (!K.go) break;
         // opaque per-step copies: keeps the compiler from hoisting every address of the step out of the loop (dozens of
         // loop-invariant 64-bit pointers, which it then spills)
         unsigned vo = voff; int vv = v, rowv = row;
         asm volatile("" : "+v"(vo), "+v"(vv), "+v"(rowv));
-        VXH_T_MARK(0)
-        if (s_latch || s_eol) fused_latch_cm<BLOCK>(R, rs, ps, ex, valid, C, s_latch != 0, s_eol != 0);
-        if (s_rebuild) fused_rebuild<BLOCK>(B, R, rs, ps, (int*)ex, vct);
+        if (K.latch || K.eol) fused_latch_cm<BLOCK>(R, rs, ps, ex, valid, C, K.latch != 0, K.eol != 0);
+        if (K.rebuild) fused_rebuild<BLOCK>(B, R, rs, ps, (int*)ex, vct);
         const int ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;   // issued early, consumed in the voxel phase
         d3 drag = mk3(0, 0, 0);
         if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, tabs + nbd + nvd, valid, vv, S.lm, C.mass_inv);
-        const double inv_dt_prev = s_inv_dtprev;
+        const double inv_dt_prev = K.inv_dt_prev;
         VXH_T_MARK(1)
 
         // ---- bond phase: this voxel's +X, +Y, +Z bonds; own-side sums stay in registers, far-side outputs go to LDS
@@ -340,17 +357,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             if (valid) fused_gather<BLOCK>(ex, tid, negmask & 4u, F, M);
         }
         if (s_div) {                           // Integrate() returns before the voxel loop (VX_Sim.cpp:1777)
-            __syncthreads();                   // everyone has read s_div before the next step_control clears it
-            if (tid == 0) rs.diverged = 1;
-            continue;                          // next step_control marks the robot diverged
+            __syncthreads();                   // everyone has read s_div
+            if (ctl_thread) { rs.diverged = 1; fused_control_begin(R, rs, step_cap, 0, Knext); s_div = 0; }   // -> status diverged, go = 0
+            __syncthreads();
+            continue;
         }
         // ---- voxel phase (all in registers; contact partners from the pose tile)
         double vel2 = 0;
         if (valid) {
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, vv, fetch, s_time, s_t_over_period, s_prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, phase, amp_damp);
+            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.t_over_period, K.prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, phase, amp_damp);
         }
+        if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
         if ((R.flags & RF_SELF_COL) && !(B.dbg & 2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { double o2 = __shfl_xor(vel2, off); vel2 = o2 > vel2 ? o2 : vel2; }
@@ -362,6 +381,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             ps[tid] = S.pos.x; ps[BLOCK + tid] = S.pos.y; ps[2 * BLOCK + tid] = S.pos.z; ps[3 * BLOCK + tid] = S.scale;
             ps[4 * BLOCK + tid] = S.ang.w; ps[5 * BLOCK + tid] = S.ang.x; ps[6 * BLOCK + tid] = S.ang.y; ps[7 * BLOCK + tid] = S.ang.z;
         }
+        VXH_T_MARK(5)
+        if (ctl_thread) { fused_control_horizon(R, rs, Knext); s_div = 0; }
+        __syncthreads();                       // (A) control + every voxel's published pose visible
+        VXH_T_MARK(0)
     }
     VXH_T_FLUSH
     // ---- back to HBM: state into the buffer the step count selects, flag bits, control block
