@@ -35,6 +35,7 @@ struct DRobotState {          // mutable per robot
     double cur_time, dt_prev, max_disp;
     double ini_cm[3];
     double eol_post_y;
+    double act_sin, act_cos;      // streaming path: sincos of the actuation phase of the current step (actuation_sincos)
     unsigned long long maxvel2_bits;
     int steps, status, cm_init, active, diverged, col_overflow, rebuild_now, rebuilds;
 };
@@ -54,7 +55,8 @@ struct DBatch {
     const unsigned short* vclass;     // [nv] robot-local class id
     const short* bclass;              // [3*nv] axis-major, robot-local class id, -1 = no bond
     const int* nbr;                   // [6*nv] direction-major, global voxel slot or -1
-    const float* phase;               // [nv]
+    const double* act_sb;             // [nv] sin / cos of 2 pi' * PhaseOffset of the voxel (pi' = 3.1415926f)
+    const double* act_cb;
     const float* amp_damp;            // [nv]
     // voxel state, 18 component planes of nv doubles each: [0..3] pos xyz + scale (buffer 0), [4..7] the same
     // (buffer 1; positions/scale are double-buffered because collision forces read OTHER voxels' previous

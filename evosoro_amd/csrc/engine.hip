@@ -199,7 +199,8 @@ void Engine::prepare()
     std::vector<unsigned long long> excl;
     std::vector<unsigned short> vclass(nv, 0);
     std::vector<short> bclass((size_t)3 * nv, -1);
-    std::vector<float> phase(nv, 0.f), amp_damp(nv, 1.f);
+    std::vector<float> amp_damp(nv, 1.f);
+    std::vector<double> act_sb(nv, 0.0), act_cb(nv, 1.0);
     std::vector<double> px(nv, 0), py(nv, 0), pz(nv, 0), sc(nv, 0), qw(nv, 1.0);
     std::vector<unsigned char> small((size_t)3 * nv, 1);
     // land_water fluid robots: drag mesh
@@ -242,7 +243,7 @@ void Engine::prepare()
         for (int v = 0; v < M.nvox; ++v) {
             const int g = base + v;
             vclass[g] = (unsigned short)M.vox_class[v];
-            phase[g] = M.phase_offset[v];
+            { const double b = (double)(2 * 3.1415926f) * (double)M.phase_offset[v]; act_sb[g] = std::sin(b); act_cb[g] = std::cos(b); }
             amp_damp[g] = M.temp_amp_damp[v];
             px[g] = M.nom_pos[3 * v]; py[g] = M.nom_pos[3 * v + 1]; pz[g] = M.nom_pos[3 * v + 2];
             sc[g] = M.vox_classes[M.vox_class[v]].nom_size;
@@ -314,7 +315,8 @@ void Engine::prepare()
     B.vclass = D.upload(vclass);
     B.bclass = D.upload(bclass);
     B.nbr = D.upload(nbr);
-    B.phase = D.upload(phase);
+    B.act_sb = D.upload(act_sb);
+    B.act_cb = D.upload(act_cb);
     B.amp_damp = D.upload(amp_damp);
     {
         std::vector<double> vs((size_t)18 * nv, 0.0);

@@ -117,6 +117,37 @@ __device__ __forceinline__ double vdiv(double a, double b)
     return __builtin_fma(e, r, q);
 }
 
+// acos for |x| <= 1, <= 1 ulp: the usual reduction (|x| < 0.5: pi/2 - asin x; else 2 asin sqrt((1 - |x|)/2)) with
+// asin(s) = s + s z R(z), z = s^2 in [0, 1/4], R a degree-11 polynomial (Chebyshev-node interpolant of
+// (asin(sqrt z) - sqrt z)/(z sqrt z), relative error 6e-17).  The coefficients are pinned to scalar registers: as
+// literals the compiler moves each of them into a vector register pair per evaluation (FP64 has no 64-bit literals).
+__device__ __forceinline__ double sconst(double c) { asm volatile("" : "+s"(c)); return c; }
+__device__ __forceinline__ double vacos(double x)
+{
+    const double ax = fabs(x);
+    const bool big = ax >= 0.5;
+    const double z = big ? __builtin_fma(ax, -0.5, 0.5) : x * x;
+    double p = sconst(0.028169218060881414);
+    p = __builtin_fma(p, z, sconst(-0.010749050339697808));
+    p = __builtin_fma(p, z, sconst(0.01603551434914882));
+    p = __builtin_fma(p, z, sconst(0.0078029494773533175));
+    p = __builtin_fma(p, z, sconst(0.011875494382636922));
+    p = __builtin_fma(p, z, sconst(0.013929652902326633));
+    p = __builtin_fma(p, z, sconst(0.017355259955786323));
+    p = __builtin_fma(p, z, sconst(0.02237204763174451));
+    p = __builtin_fma(p, z, sconst(0.03038194736709848));
+    p = __builtin_fma(p, z, sconst(0.044642857103423646));
+    p = __builtin_fma(p, z, sconst(0.07500000000020764));
+    p = __builtin_fma(p, z, sconst(0.1666666666666665));
+    p *= z;
+    if (big) {
+        const double s = vsqrt_nn(z);
+        const double r = 2.0 * __builtin_fma(s, p, s);
+        return x > 0 ? r : 3.141592653589793 - (r - 1.2246467991473532e-16);
+    }
+    return 1.5707963267948966 - (x + __builtin_fma(x, p, -6.123233995736766e-17));
+}
+
 #define VXH_PI 3.14159265358979
 #define VXH_DISCARD_ANGLE_RAD 1e-7
 #define VXH_SMALL_ANGLE_RAD 1.732e-2
@@ -152,7 +183,7 @@ __device__ __forceinline__ d3 to_rotvec(dq q, double slthresh)
     double sl = 1.0 - q.w * q.w;
     if (sl <= 0) return mk3(0, 0, 0);
     double wc = q.w > 1 ? 1 : q.w;
-    double f = (sl < slthresh) ? vsqrt_nn(vdiv(2 - 2 * wc, sl)) : vdiv(acos(wc), vsqrt(sl));
+    double f = (sl < slthresh) ? vsqrt_nn(vdiv(2 - 2 * wc, sl)) : vdiv(vacos(wc), vsqrt(sl));
     return mk3(2.0 * q.x * f, 2.0 * q.y * f, 2.0 * q.z * f);
 }
 
@@ -240,8 +271,9 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
         double e1 = strain, e2 = strain, t1 = C.stress_E1 * e1, t2 = C.stress_E2 * e2;
         double diff = fabs(t1 - t2), sum = fabs(t1 + t2);
         for (int it = 0; it < 3 && diff > sum * .0005; ++it) {
-            e1 = vdiv(2 * t2, t1 + t2) * e1;
-            e2 = vdiv(2 * t1, t1 + t2) * e2;
+            const double rs12 = vrcp(t1 + t2);      // one reciprocal for both quotients of the reference (<= 1 ulp apart)
+            e1 = ((2 * t2) * rs12) * e1;
+            e2 = ((2 * t1) * rs12) * e2;
             t1 = C.stress_E1 * e1; t2 = C.stress_E2 * e2;
             diff = fabs(t1 - t2); sum = fabs(t1 + t2);
         }
@@ -310,8 +342,8 @@ struct FetchLds {          // fused path: the workgroup's pose tile
 // F/M arrive holding slow damping + internal bond forces / minus internal bond moments.  Returns |new velocity|^2.
 template <class Fetch>
 __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, const Fetch& fetch,
-                                               double t, double t_over_period, double prenatal_c, d3 F, d3 M, d3 vel, VoxState& S,
-                                               int row, int ccnt, bool fluid, d3 drag, float phase, float amp_damp)
+                                               double t, double act_sin, double act_cos, double prenatal_c, d3 F, d3 M, d3 vel,
+                                               VoxState& S, int row, int ccnt, bool fluid, d3 drag, double ph_sin, double ph_cos, float amp_damp)
 {
     const int flags = R.flags;
     const double dt = R.dt;
@@ -332,18 +364,16 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (o[j] < 0) continue;
-                const bool second = o[j] < v;                          // Vox1 = the earlier surface voxel; am I Vox2?
-                d3 d = mk3(qx[j] - S.pos.x, qy[j] - S.pos.y, qz[j] - S.pos.z);   // partner - me
-                if (second) d = -d;                                    // Pos2 = pVox2 - pVox1
-                const double nom = second ? (qs[j] + S.scale) * 0.75 : (S.scale + qs[j]) * 0.75;
+                // CalcContactForce: Force2 = unit(p2 - p1) * a1 * overlap on Vox2 (the later surface voxel), -Force2 on
+                // Vox1.  Seen from this voxel that is -unit(partner - me) * a1 * overlap in both roles, bit for bit
+                // (negation is exact, the sums commute).
+                const d3 d = mk3(qx[j] - S.pos.x, qy[j] - S.pos.y, qz[j] - S.pos.z);
+                const double nom = (qs[j] + S.scale) * 0.75;
                 const double d2 = len2(d);
                 if (d2 < nom * nom) {                                  // cheap reject: most listed partners are out of reach
                     const double l = vsqrt_nn(d2);
                     const double reld = nom - l;
-                    if (reld > 0) {
-                        d3 f2 = ((d * vrcp(l)) * a1[j]) * reld;        // force on Vox2
-                        F = second ? F + f2 : F - f2;
-                    }
+                    if (reld > 0) F = F - ((d * vrcp(l)) * a1[j]) * reld;
                 }
             }
         }
@@ -392,13 +422,15 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     S.ang = ang;
 
     // thermal actuation -> new scale (VXS_Voxel.cpp:224-340 without development; LW/VXS_Voxel.cpp:211-235)
+    // sin(2 pi' (t/T + phase)) of the reference = sin(a + b) with a = 2 pi' t/T, the same for every voxel (sincos once
+    // per robot and step, actuation_sincos), and b = 2 pi' phase, fixed per voxel (DBatch::act_sb / act_cb)
     double new_scale;
-    const double two_pi_f = (double)(2 * 3.1415926f);
+    const double act = act_sin * ph_cos + act_cos * ph_sin;
     if (!(flags & RF_LW)) {
         const double prenatal = prenatal_c * (((float)C.nom_size / C.nom_size) - 1);
         double ctrl = 0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)
-            ctrl = (double)amp_damp * ((double)R.temp_amplitude * sin(two_pi_f * (t_over_period + (double)phase))) * C.cte;
+            ctrl = (double)amp_damp * ((double)R.temp_amplitude * act) * C.cte;
         new_scale = ctrl * C.nom_size + (1 + prenatal) * C.nom_size;
         const double max_scale = (1 + R.growth_amplitude) * C.nom_size, min_scale = R.min_temp_fact * C.nom_size;
         if (new_scale < S.scale && new_scale < min_scale) new_scale = S.scale;
@@ -406,7 +438,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     } else {
         double tf = 1.0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)
-            tf = 1 + ((double)R.temp_amplitude * sin(two_pi_f * (t_over_period + (double)phase))) * C.cte;
+            tf = 1 + ((double)R.temp_amplitude * act) * C.cte;
         if (tf < 0.1) tf = 0.1;
         new_scale = tf * C.nom_size;
     }
@@ -415,7 +447,11 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
 }
 
 // uniform per-step factors of the actuation, evaluated once per robot and step instead of once per voxel
-__device__ __forceinline__ double actuation_t_over_period(const DRobot& R, double t) { return t / (double)R.temp_period; }
+__device__ __forceinline__ void actuation_sincos(const DRobot& R, double t, double& s, double& c)
+{
+    s = 0; c = 0;
+    if ((R.flags & RF_TEMP) && t >= R.init_cm_time) sincos((double)(2 * 3.1415926f) * (t / (double)R.temp_period), &s, &c);
+}
 __device__ __forceinline__ double actuation_prenatal_c(const DRobot& R, double t) { return (t >= 0.5 * R.init_cm_time) ? 1.0 : 2 * t / R.init_cm_time; }
 
 // ------------------------------------------------------------------------------------- per-robot step control
@@ -577,6 +613,7 @@ __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap
     if (threadIdx.x == 0) {
         StepCtl c = step_control(R, rs, step_cap, begin_new_step);
         s_go = c.go; s_latch = c.latch; s_eol = c.eol;
+        if (c.go) actuation_sincos(R, rs.cur_time, rs.act_sin, rs.act_cos);
     }
     __syncthreads();
     if (!s_go) return;
@@ -675,8 +712,8 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
         int row = -1, ccnt = 0;
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) { row = R.surf_begin + so; ccnt = B.col_cnt[row]; } }
         const FetchGlobal fetch{B, cur};
-        vel2 = voxel_update(B, R, C, v, fetch, rs.cur_time, actuation_t_over_period(R, rs.cur_time), actuation_prenatal_c(R, rs.cur_time), F, M, vel, S, row, ccnt, false,
-                             mk3(0, 0, 0), B.phase[v], B.amp_damp[v]);
+        vel2 = voxel_update(B, R, C, v, fetch, rs.cur_time, rs.act_sin, rs.act_cos, actuation_prenatal_c(R, rs.cur_time), F, M, vel, S, row, ccnt, false,
+                             mk3(0, 0, 0), B.act_sb[v], B.act_cb[v], B.amp_damp[v]);
         POS(nxt, 0, v) = S.pos.x; POS(nxt, 1, v) = S.pos.y; POS(nxt, 2, v) = S.pos.z;
         SCALE(nxt, v) = S.scale;
         LINMOM(0, v) = S.lm.x; LINMOM(1, v) = S.lm.y; LINMOM(2, v) = S.lm.z;

@@ -15,7 +15,7 @@
 
 namespace vxh {
 
-enum { VXH_FUSED_STATIC_LDS = 256 };
+enum { VXH_FUSED_STATIC_LDS = 320 };
 
 // developer instrumentation (scripts/gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
 // of the phases of a step
@@ -223,14 +223,16 @@ __device__ __forceinline__ void fused_gather(const double* exa, int tid, bool ha
     M = M - mk3(e[3 * BLOCK], e[4 * BLOCK], e[5 * BLOCK]);
 }
 
-struct FusedCtl { double time, inv_dt_prev, t_over_period, prenatal_c; int go, latch, eol, rebuild; };
+struct FusedCtl { double time, inv_dt_prev, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild; };
 
 __device__ __forceinline__ void fused_control_begin(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step, FusedCtl& K)
 {
     const StepCtl c = step_control_begin(R, rs, step_cap, begin_new_step);
     K.go = c.go; K.latch = c.latch; K.eol = c.eol; K.rebuild = 0;
     K.time = rs.cur_time; K.inv_dt_prev = rs.dt_prev != 0 ? 1.0 / rs.dt_prev : 0.0;
-    K.t_over_period = actuation_t_over_period(R, rs.cur_time); K.prenatal_c = actuation_prenatal_c(R, rs.cur_time);
+    K.prenatal_c = actuation_prenatal_c(R, rs.cur_time);
+    K.act_sin = K.act_cos = 0;
+    if (c.go) actuation_sincos(R, rs.cur_time, K.act_sin, K.act_cos);
 }
 __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K)
 {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     unsigned negmask = 0;                     // bit A: a bond arrives from the -A neighbour
     unsigned modebits = 0;                    // 2 bits per +A bond: SmallAngle, history layout (DBatch::hist)
     int row = -1;                             // my row of collision partners (surface voxels of colliding robots)
-    float phase = 0.f, amp_damp = 1.f;
+    float amp_damp = 1.f;
     VoxState S;
     S.pos = mk3(0, 0, 0); S.lm = mk3(0, 0, 0); S.am = mk3(0, 0, 0); S.ang = mkq(1, 0, 0, 0); S.scale = 0;
     if (valid) {
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             if (B.nbr[(unsigned)(2 * a + 1) * nv + v] >= 0) negmask |= 1u << a;
         }
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
-        phase = B.phase[v]; amp_damp = B.amp_damp[v];
+        amp_damp = B.amp_damp[v];
         S.pos = mk3(POS(b0, 0, v), POS(b0, 1, v), POS(b0, 2, v));
         S.scale = SCALE(b0, v);
         S.ang = mkq(QUAT(0, v), QUAT(1, v), QUAT(2, v), QUAT(3, v));
@@ -319,6 +321,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (K.latch || K.eol) fused_latch_cm<BLOCK>(R, rs, ps, ex, valid, C, K.latch != 0, K.eol != 0);
         if (K.rebuild) fused_rebuild<BLOCK>(B, R, rs, ps, (int*)ex, vct);
         const int ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;   // issued early, consumed in the voxel phase
+        double ph_sin = 0, ph_cos = 0;
+        if (valid) { ph_sin = ld_plane(B.act_sb, 0, nv, vo); ph_cos = ld_plane(B.act_cb, 0, nv, vo); }
         d3 drag = mk3(0, 0, 0);
         if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, tabs + nbd + nvd, valid, vv, S.lm, C.mass_inv);
         const double inv_dt_prev = K.inv_dt_prev;
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (valid) {
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.t_over_period, K.prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, phase, amp_damp);
+            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, ph_sin, ph_cos, amp_damp);
         }
         if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
         if ((R.flags & RF_SELF_COL) && !(B.dbg & 2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
