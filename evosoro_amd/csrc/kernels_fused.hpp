@@ -188,7 +188,9 @@ __device__ __forceinline__ void fused_bond(const DBatch& B, const DRobot& R, con
                                            double inv_dt_prev, d3& F, d3& M, bool& div)
 {
     if (link < 0) return;
-    const unsigned nv = B.nv;
+    unsigned nv = B.nv;
+    asm volatile("" : "+s"(nv));              // plane addresses are rebuilt here by the scalar unit: hoisted out of the step
+                                              // loop they cost 36 scalar registers and come back as v_readlane spills
     const int l2 = link & 1023;
     BondHist H;                               // history first: the only HBM/L2 round trip of the bond
     H.p0 = ld_plane(B.hist, 0 * 3 + A, nv, voff); H.p1 = ld_plane(B.hist, 1 * 3 + A, nv, voff); H.p2 = ld_plane(B.hist, 2 * 3 + A, nv, voff);
