@@ -1,8 +1,11 @@
 """GPU parity (-m gpu): the HIP engine, called through the C ABI, against the CPU oracle (itself bit-exact with
 the reference C++, tests/test_oracle_vs_reference.py) and against the reference's golden outputs.
 
-Stated FP tolerance.  Both sides compute in FP64; the engine differs from the reference only by device-libm ulps,
-FMA contraction and the order of a few sums, i.e. by perturbations of relative size ~1e-16 per operation.  How far
+Stated FP tolerance.  Both sides compute in FP64; the engine differs from the reference by device-libm ulps, FMA
+contraction, the order of a few sums and three algebraic rewrites (half-angle form of FromAngleToPosX, angle-addition
+form of the actuation sine, one reciprocal for the two quotients of the stress split; DESIGN.md "Numerics"), i.e. by
+perturbations of relative size 1e-16 .. 1e-12 per operation, the upper end where the reference's own acos is
+ill-conditioned to the same degree.  How far
 such perturbations grow is a property of the ROBOT, not of the implementation: most robots are well conditioned
 (errors stay ~1e-14 voxel over thousands of steps) but some amplify any perturbation by ~2x per step through
 stick-slip contact until it saturates around 1e-3 voxel (golden case "phase4": the reference algorithm itself,
@@ -245,3 +248,58 @@ def test_land_water_variant(eng_mod, golden_dir):
             assert np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / models[i]["lattice_dim"] <= tol, name
             for tag, val in (("normAbsoluteDisplacement", res.norm_abs_disp), ("normDistZ", res.norm_dist_z)):
                 assert abs(val - want[tag]) <= 2 * tol + 1e-5 * abs(want[tag]), (name, tag, val, want[tag])
+
+
+def _write_robot(tmp_path, ident, material, sim, env, name):
+    from evosoro_amd import workloads
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    os.makedirs(tmp_path / "voxelyzeFiles", exist_ok=True)
+    write_voxelyze_file(sim, env, workloads.make_individual(ident, material), str(tmp_path), name)
+    return str(tmp_path / "voxelyzeFiles" / ("%s--id_%05i.vxa" % (name, ident)))
+
+
+def test_every_fused_kernel_variant_vs_oracle(eng_mod, tmp_path):
+    """One robot per workgroup size of the fused kernel (256 / 512 / 768 / 1024 threads; the last one exchanges bond
+    forces axis by axis through a single LDS buffer) against the oracle, self-collision on, in ONE batch."""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from oracle import vxoracle as vo
+    sim, env = Sim(dt_frac=0.9, simulation_time=0.02, fitness_eval_init_time=0.002), Env()
+    mats = [workloads.random_material((6, 6, 6), 3), workloads.random_material((8, 8, 8), 4),
+            workloads.random_material((10, 10, 10), 5), workloads.full_material(10, 2)]
+    paths = [_write_robot(tmp_path, k, m, sim, env, "v") for k, m in enumerate(mats)]
+    sims = [vo.OracleSim.from_vxa(p) for p in paths]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        for p in paths:
+            eng.add_vxa_file(p)
+        nv = [eng.dims(i)["nvox"] for i in range(4)]
+        assert nv[0] <= 256 < nv[1] <= 512 < nv[2] <= 768 < nv[3] == 1000
+        for upto in (1, 3, 40, 120):
+            eng.step(upto - sims[0].info().steps)
+            for i, o in enumerate(sims):
+                o.step(upto - o.info().steps)
+                assert _pos_err(eng.state(i), o.state(), 0.01) < FLOOR_VOX, (i, upto)
+                assert np.abs(eng.state(i)[:, 3:14] - o.state()[:, 3:14]).max() < 1e-7, (i, upto)   # quat, scale, vel, angvel
+
+
+def test_diverging_robot_is_reported_like_the_reference(eng_mod, tmp_path):
+    """DtFrac far above the stability limit: the reference's Integrate() stops at the first bond stretched past 100x
+    (VX_Sim.cpp:1775) and the run ends 'diverged'; same step, same verdict, and the rest of the batch is unaffected."""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from oracle import vxoracle as vo
+    env = Env()
+    bad = _write_robot(tmp_path, 0, workloads.random_material((6, 6, 6), 9), Sim(dt_frac=6.0, simulation_time=0.05, fitness_eval_init_time=0.0), env, "d")
+    good = _write_robot(tmp_path, 1, workloads.random_material((6, 6, 6), 9), Sim(dt_frac=0.9, simulation_time=0.01, fitness_eval_init_time=0.0), env, "d")
+    o = vo.OracleSim.from_vxa(bad)
+    o.step(-1)
+    assert o.info().status == 2
+    for fused in (1, 0):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("fused", fused)
+            eng.add_vxa_file(bad)
+            eng.add_vxa_file(good)
+            eng.run()
+            assert eng.result(0).status == eng_mod.ROBOT_DIVERGED
+            assert eng.result(0).steps == o.info().steps
+            assert eng.result(1).status == eng_mod.ROBOT_FINISHED and np.isfinite(eng.result(1).cur_cm).all()
