@@ -94,6 +94,28 @@ def cpu_baseline(shape, sim_time=0.25):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def measured_traffic(robots_per_gpu, lattice):
+    """HBM bytes the dominant kernel really moved, from the newest rocprofv3 counter summary under profiles/
+    (scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes over this same command; FETCH_SIZE is
+    doubled, as the 8-byte-per-lane calibration kernels of the same passes show it counts half the bytes).  PMC
+    counters cannot be read from inside this process, so the figure is only reported for the profiled workload."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
+    if not files or robots_per_gpu != 512 or lattice != 10:
+        return {}
+    with open(files[-1]) as f:
+        t = json.load(f)
+    if not t.get("avg_launch_ns"):
+        return {}
+    fetch_scale = t["calib_true_bytes"] / (t["calib_fetch_raw"] * 1024.0) if t.get("calib_fetch_raw") else 2.0
+    write_scale = t["calib_true_bytes"] / (t["calib_write_raw"] * 1024.0) if t.get("calib_write_raw") else 1.0
+    nbytes = t["fetch_raw_per_launch"] * 1024.0 * fetch_scale + t["write_raw_per_launch"] * 1024.0 * write_scale
+    return {"traffic": nbytes / t["avg_launch_ns"],      # bytes / ns = GB/s, per launch like `achieved`
+            "traffic_bytes_per_launch": nbytes,
+            "traffic_source": os.path.relpath(files[-1], REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "command; FETCH x%.2f, WRITE x%.2f from the calibration kernels)" % (fetch_scale, write_scale)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,7 +198,7 @@ def main():
                            "parallelism": "population sharded %d-way, no data-path collective" % world},
                 "roofline": {"bound": "hbm", "achieved": roof_bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": roof_bw / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": ("k_robot_steps<%d>" % c1.dominant_block) if c1.dominant_block else "k_bonds+k_voxels",
+                             "kernel": ("k_robot_steps<%d,...>" % c1.dominant_block) if c1.dominant_block else "k_bonds+k_voxels",
                              "launches": int(c1.dominant_launches),
                              "avg_launch_ms": dom_seconds / max(1, c1.dominant_launches) * 1e3,
                              "alg_bytes_per_launch": c1.dominant_alg_bytes / max(1, c1.dominant_launches),
@@ -185,6 +207,7 @@ def main():
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,
             }
+            out["roofline"].update(measured_traffic(n_local, args.lattice))
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(shape)
             print(json.dumps(out))

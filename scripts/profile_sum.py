@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 CSVs written by scripts/profile_bench.sh into the small files kept under profiles/:
+<tag>_bench_kernel_stats.csv (per-kernel calls / total / average duration) and <tag>_hbm_traffic.json (FETCH_SIZE,
+WRITE_SIZE per launch of the dominant kernel, with the calibration factors of the 8-byte-per-lane streaming kernels)."""
+import csv, glob, json, os, sys, collections
+
+out_root, tag = sys.argv[1], sys.argv[2]
+
+
+def rows(sub, suffix):
+    for f in glob.glob(os.path.join(out_root, "prof_%s_%s" % (tag, sub), "**", "*" + suffix), recursive=True):
+        for r in csv.DictReader(open(f)):
+            yield r
+
+
+def counter_per_kernel(sub):
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    for r in rows(sub, "counter_collection.csv"):
+        tot[r["Kernel_Name"]] += float(r["Counter_Value"]); n[r["Kernel_Name"]] += 1
+    return tot, n
+
+
+dur, cnt = collections.defaultdict(float), collections.defaultdict(int)
+for r in rows("stats", "kernel_trace.csv"):
+    dur[r["Kernel_Name"]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); cnt[r["Kernel_Name"]] += 1
+prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+os.makedirs(prof_dir, exist_ok=True)
+total = sum(dur.values()) or 1.0
+with open(os.path.join(prof_dir, "%s_bench_kernel_stats.csv" % tag), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (N=1); durations in ns\n")
+    f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+    for k in sorted(dur, key=dur.get, reverse=True):
+        f.write('"%s",%d,%.0f,%.1f,%.2f\n' % (k, cnt[k], dur[k], dur[k] / cnt[k], 100 * dur[k] / total))
+dom = max(dur, key=dur.get) if dur else None
+fetch, fn = counter_per_kernel("fetch")
+write, wn = counter_per_kernel("write")
+cf, _ = counter_per_kernel("calfetch")
+cw, _ = counter_per_kernel("calwrite")
+cal_bytes = float((1 << 28) * 8)
+info = {"command": "python bench.py --no-cpu-baseline", "dominant_kernel": dom,
+        "units_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-like units of 1024 B per count on this image; "
+                      "raw counter sums are stored, bytes = raw * 1024"}
+if dom:
+    info["launches"] = cnt[dom]; info["avg_launch_ns"] = dur[dom] / cnt[dom]
+    info["fetch_raw_per_launch"] = fetch.get(dom, 0.0) / max(1, fn.get(dom, 1))
+    info["write_raw_per_launch"] = write.get(dom, 0.0) / max(1, wn.get(dom, 1))
+for name, table, key in (("calib_read8", cf, "calib_fetch_raw"), ("calib_write8", cw, "calib_write_raw")):
+    for k, v in table.items():
+        if name in k:
+            info[key] = v
+info["calib_true_bytes"] = cal_bytes
+with open(os.path.join(prof_dir, "%s_hbm_traffic.json" % tag), "w") as f:
+    json.dump(info, f, indent=1)
+print(json.dumps(info, indent=1))
+print(open(os.path.join(prof_dir, "%s_bench_kernel_stats.csv" % tag)).read())
