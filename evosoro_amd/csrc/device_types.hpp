@@ -55,6 +55,9 @@ struct DBatch {
     const unsigned short* vclass;     // [nv] robot-local class id
     const short* bclass;              // [3*nv] axis-major, robot-local class id, -1 = no bond
     const int* nbr;                   // [6*nv] direction-major, global voxel slot or -1
+    const int* blist;                 // [3*nv] fused path: per robot and axis the COMPACTED list of its bonds, entry t of axis a at
+                                      // [a*nv + vox_begin + t] = local negative-end voxel | local positive-end voxel << 10 |
+                                      // bond class << 20, -1 past the end of the list
     const double* act_sb;             // [nv] sin / cos of 2 pi' * PhaseOffset of the voxel (pi' = 3.1415926f)
     const double* act_cb;
     const float* amp_damp;            // [nv]

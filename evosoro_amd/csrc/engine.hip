@@ -199,6 +199,7 @@ void Engine::prepare()
     std::vector<unsigned long long> excl;
     std::vector<unsigned short> vclass(nv, 0);
     std::vector<short> bclass((size_t)3 * nv, -1);
+    std::vector<int> blist((size_t)3 * nv, -1);
     std::vector<float> amp_damp(nv, 1.f);
     std::vector<double> act_sb(nv, 0.0), act_cb(nv, 1.0);
     std::vector<double> px(nv, 0), py(nv, 0), pz(nv, 0), sc(nv, 0), qw(nv, 1.0);
@@ -250,6 +251,14 @@ void Engine::prepare()
             for (int d = 0; d < 6; ++d) { int o = M.nbr[(size_t)v * 6 + d]; nbr[(size_t)d * nv + g] = o < 0 ? -1 : base + o; }
             for (int a = 0; a < 3; ++a) { int c = M.bond_class[(size_t)v * 3 + a]; bclass[(size_t)a * nv + g] = c < 0 ? (short)-1 : (short)c; }
         }
+        if (M.nvox <= 1024 && M.bond_classes.size() <= 2047)
+            for (int a = 0; a < 3; ++a) {
+                int t = 0;
+                for (int v = 0; v < M.nvox; ++v) {
+                    const int c = M.bond_class[(size_t)v * 3 + a];
+                    if (c >= 0) blist[(size_t)a * nv + base + t++] = v | (M.nbr[(size_t)v * 6 + 2 * a] << 10) | (c << 20);
+                }
+            }
         if (X.self_col_enabled)
             for (int i = 0; i < M.nsurf; ++i) { surf[D.surf_begin[r] + i] = base + M.surf[i]; surf_ord[base + M.surf[i]] = i; }
         // CalcNearby exclusion lists as bit rows over surface ordinals
@@ -315,6 +324,7 @@ void Engine::prepare()
     B.vclass = D.upload(vclass);
     B.bclass = D.upload(bclass);
     B.nbr = D.upload(nbr);
+    B.blist = D.upload(blist);
     B.act_sb = D.upload(act_sb);
     B.act_cb = D.upload(act_cb);
     B.amp_damp = D.upload(amp_damp);
@@ -355,14 +365,12 @@ void Engine::prepare()
             const RobotModel& M = robots_[r];
             const int n = M.nvox;
             if (n == 0) continue;
-            if (n > 1024) { D.fused_ok = false; continue; }
+            if (n > 1024 || M.bond_classes.size() > 2047) { D.fused_ok = false; continue; }
             const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
             const int fluid = M.nmv > 0 ? 1 : 0;
             const size_t extra = M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) + (size_t)24 * M.nmv;
-            int nex = 0;
-            if (block < 1024 && (size_t)(8 + 18) * block * 8 + extra <= lds_max) nex = 3;
-            else if ((size_t)(8 + 6) * block * 8 + extra <= lds_max) nex = 1;
-            if (nex == 0) { D.fused_ok = false; continue; }
+            const int nex = block < 1024 ? 2 : 1;     // accumulator tiles (NACC of k_robot_steps): a function of the robot's size only
+            if ((size_t)(8 + 6 * nex) * block * 8 + extra > lds_max) { D.fused_ok = false; continue; }
             Device::Group* g = nullptr;
             for (auto& q : D.groups) if (q.block == block && q.nex == nex && q.fluid == fluid) g = &q;
             if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nex = nex; g->fluid = fluid; }
@@ -423,10 +431,9 @@ static void launch_variant(const DBatch& B, const int* list, int count, size_t l
 template <bool FLUID>
 static void launch_group(const DBatch& B, int block, int nex, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
-    if (block == 256) launch_variant<256, 3, FLUID>(B, list, count, lds, s, cap, iters);
-    else if (block == 512) launch_variant<512, 3, FLUID>(B, list, count, lds, s, cap, iters);
-    else if (block == 768 && nex == 3) launch_variant<768, 3, FLUID>(B, list, count, lds, s, cap, iters);
-    else if (block == 768) launch_variant<768, 1, FLUID>(B, list, count, lds, s, cap, iters);
+    if (block == 256) launch_variant<256, 2, FLUID>(B, list, count, lds, s, cap, iters);
+    else if (block == 512) launch_variant<512, 2, FLUID>(B, list, count, lds, s, cap, iters);
+    else if (block == 768) launch_variant<768, 2, FLUID>(B, list, count, lds, s, cap, iters);
     else launch_variant<1024, 1, FLUID>(B, list, count, lds, s, cap, iters);
 }
 

@@ -1,16 +1,23 @@
-// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NEX, FLUID>, one workgroup per robot, the robot
+// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NACC, FLUID>, one workgroup per robot, the robot
 // resident in the CU for a whole launch of many time steps (included at the end of kernels.hpp).
 //
+// A step has two kinds of work items mapped onto the same threads:
+//   voxels  thread t owns voxel t: its momenta stay in registers for the whole launch, its pose is published in LDS;
+//   bonds   three rounds, one per axis; in round A thread t owns the t-th bond of that axis (per-robot COMPACTED bond
+//           lists, DBatch::blist), so a sparse robot keeps only ceil(bonds_A / 64) wavefronts busy per round instead
+//           of one lane per voxel whether it has that bond or not.  The axis is a compile-time constant per round.
 // Dynamic LDS layout (doubles):
-//   ps   [8][BLOCK]        pose tile: pos x y z, scale, quaternion w x y z of every voxel (what OTHER voxels read:
-//                          neighbour bonds, contact forces, the broad-phase, the drag mesh)
-//   ex   [NEX][6][BLOCK]   exchange tile: Force2, Moment2 of the bond whose POSITIVE end is voxel `local`.  NEX = 3: one
-//                          buffer per axis, a single barrier between the bond phase and the gather.  NEX = 1 (BLOCK 1024,
-//                          where three buffers do not fit next to the pose tile): one buffer, written/read axis by axis.
-//                          Scratch of latch / broad-phase / drag mesh between steps.
+//   ps   [8][BLOCK]        pose tile: pos x y z, scale, quaternion w x y z of every voxel (read by bonds, contact forces,
+//                          the broad-phase, the drag mesh)
+//   acc  [NACC][6][BLOCK]  force / minus-moment accumulators of every voxel.  NACC = 2: tile 0 collects the bonds in
+//                          which the voxel is the negative end (Force1/Moment1), tile 1 those in which it is the
+//                          positive end; every (axis, tile, voxel) entry has exactly one writer, rounds are separated
+//                          by a barrier.  NACC = 1 (BLOCK 1024, where two tiles do not fit next to the pose tile): one
+//                          tile, the two ends of a round are added in two barrier-separated sub-steps, which gives
+//                          the reference's summation order +X -X +Y -Y +Z -Z.
+//                          Also scratch of latch / broad-phase between steps (re-zeroed by the voxel phase).
 //   tabs                   this robot's DBondClass and DVoxClass rows
 //   mesh [3][nmv]          FLUID only: vertices of the drag mesh
-// Registers, persistent over the launch: the voxel's 14 integrator doubles, its packed links and flags.
 #pragma once
 
 namespace vxh {
@@ -180,49 +187,63 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
     return drag;
 }
 
-// One +A bond of the calling voxel: neighbour pose from the pose tile, history from/to HBM, own-side sums into F/M,
-// far-side outputs into the exchange buffer `exa` (6 planes of BLOCK).
+// Bond t of axis A (packed entry of DBatch::blist: negative-end voxel | positive-end voxel << 10 | class << 20):
+// both poses from the pose tile, history from/to HBM.  Returns the outputs; the caller adds them to the accumulators.
 template <int A, int BLOCK, bool FLUID>
-__device__ __forceinline__ void fused_bond(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, double* exa,
-                                           int link, unsigned voff, int v, d3 p1, dq q1, double s1, unsigned& modebits,
-                                           double inv_dt_prev, d3& F, d3& M, bool& div)
+__device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, int entry,
+                                              unsigned& modebits, double inv_dt_prev)
 {
-    if (link < 0) return;
     unsigned nv = B.nv;
     asm volatile("" : "+s"(nv));              // plane addresses are rebuilt here by the scalar unit: hoisted out of the step
                                               // loop they cost 36 scalar registers and come back as v_readlane spills
-    const int l2 = link & 1023;
+    const int l1 = entry & 1023, l2 = (entry >> 10) & 1023;
+    const unsigned voff = (unsigned)(R.vox_begin + l1) * 8u;
     BondHist H;                               // history first: the only HBM/L2 round trip of the bond
     H.p0 = ld_plane(B.hist, 0 * 3 + A, nv, voff); H.p1 = ld_plane(B.hist, 1 * 3 + A, nv, voff); H.p2 = ld_plane(B.hist, 2 * 3 + A, nv, voff);
     H.g0 = ld_plane(B.hist, 3 * 3 + A, nv, voff); H.g1 = ld_plane(B.hist, 4 * 3 + A, nv, voff); H.g2 = ld_plane(B.hist, 5 * 3 + A, nv, voff);
     H.flags = (modebits >> (2 * A)) & 3u;
     H.store_hist = false;
+    const d3 p1 = mk3(ps[l1], ps[BLOCK + l1], ps[2 * BLOCK + l1]);
+    const double s1 = ps[3 * BLOCK + l1];
+    const dq q1 = mkq(ps[4 * BLOCK + l1], ps[5 * BLOCK + l1], ps[6 * BLOCK + l1], ps[7 * BLOCK + l1]);
     const d3 p2 = mk3(ps[l2], ps[BLOCK + l2], ps[2 * BLOCK + l2]);
     const double s2 = ps[3 * BLOCK + l2];
     const dq q2 = mkq(ps[4 * BLOCK + l2], ps[5 * BLOCK + l2], ps[6 * BLOCK + l2], ps[7 * BLOCK + l2]);
-    BondOut o = bond_compute<A>(B, bct[link >> 10], H, p1, q1, s1, p2, q2, s2, inv_dt_prev, R.bond_z_half);
+    BondOut o = bond_compute<A>(B, bct[entry >> 20], H, p1, q1, s1, p2, q2, s2, inv_dt_prev, R.bond_z_half);
     if (H.store_hist) {
         st_plane(B.hist, 0 * 3 + A, nv, voff, H.p0); st_plane(B.hist, 1 * 3 + A, nv, voff, H.p1); st_plane(B.hist, 2 * 3 + A, nv, voff, H.p2);
         st_plane(B.hist, 3 * 3 + A, nv, voff, H.g0); st_plane(B.hist, 4 * 3 + A, nv, voff, H.g1); st_plane(B.hist, 5 * 3 + A, nv, voff, H.g2);
     }
     modebits = (modebits & ~(3u << (2 * A))) | (H.flags << (2 * A));
-    F = F + o.f1; M = M - o.m1;
-    div = div || o.diverged;
-    if constexpr (FLUID) {                    // SetStrainDir (VXS_BondInternal.cpp:300-304): my +A side, the neighbour's -A side
-        B.strain[(unsigned)A * nv + v] = o.strain1;
+    if constexpr (FLUID) {                    // SetStrainDir (VXS_BondInternal.cpp:300-304): +A side of voxel 1, -A side of voxel 2
+        B.strain[(unsigned)A * nv + (R.vox_begin + l1)] = o.strain1;
         B.strain[(unsigned)(3 + A) * nv + (R.vox_begin + l2)] = o.strain2;
     }
-    double* e = exa + l2;
-    e[0] = o.f2.x; e[BLOCK] = o.f2.y; e[2 * BLOCK] = o.f2.z; e[3 * BLOCK] = o.m2.x; e[4 * BLOCK] = o.m2.y; e[5 * BLOCK] = o.m2.z;
+    return o;
 }
 
+// acc[.][l] += (f, -m): the calling thread is the only writer of voxel l's entry between two barriers
 template <int BLOCK>
-__device__ __forceinline__ void fused_gather(const double* exa, int tid, bool has_neg, d3& F, d3& M)
+__device__ __forceinline__ void fused_accumulate(double* acc, int l, d3 f, d3 m)
 {
-    if (!has_neg) return;
-    const double* e = exa + tid;
-    F = F + mk3(e[0], e[BLOCK], e[2 * BLOCK]);
-    M = M - mk3(e[3 * BLOCK], e[4 * BLOCK], e[5 * BLOCK]);
+    double* e = acc + l;
+    e[0] += f.x; e[BLOCK] += f.y; e[2 * BLOCK] += f.z; e[3 * BLOCK] -= m.x; e[4 * BLOCK] -= m.y; e[5 * BLOCK] -= m.z;
+}
+
+// one axis round: bond, then both ends into the accumulators
+template <int A, int BLOCK, int NACC, bool FLUID>
+__device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, double* acc, int entry,
+                                            unsigned& modebits, double inv_dt_prev, bool& div)
+{
+    const bool has = entry >= 0;
+    BondOut o;
+    if (has) {
+        o = fused_bond<A, BLOCK, FLUID>(B, R, bct, ps, entry, modebits, inv_dt_prev);
+        div = div || o.diverged;
+        fused_accumulate<BLOCK>(acc, entry & 1023, o.f1, o.m1);
+    }
+    if constexpr (NACC == 1) __syncthreads();
+    if (has) fused_accumulate<BLOCK>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
 }
 
 struct FusedCtl { double time, inv_dt_prev, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild; };
@@ -243,14 +264,14 @@ __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotSta
     K.rebuild = c.rebuild;
 }
 
-template <int BLOCK, int NEX, bool FLUID>
+template <int BLOCK, int NACC, bool FLUID>
 __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const DRobot* __restrict__ robots,
                                                                             const int* __restrict__ robot_list, long long step_cap, int iters)
 {
     extern __shared__ __align__(16) double lds[];
     double* const ps = lds;
-    double* const ex = lds + 8 * BLOCK;
-    double* const tabs = ex + NEX * 6 * BLOCK;
+    double* const acc = lds + 8 * BLOCK;
+    double* const tabs = acc + NACC * 6 * BLOCK;
     // the robot's mutable control block lives in LDS for the whole launch: the per-step control is a serial chain
     // of ~20 dependent accesses executed by one thread while the workgroup waits, so it must not touch HBM
     __shared__ DRobotState rs;
@@ -268,7 +289,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     const int base = R.vox_begin;
     const bool valid = tid < R.nvox;
     const int v = base + tid;
-    const unsigned voff = (unsigned)v * 8u;
     if (tid == 0) rs = B.rstate[r];
     const int nbd = R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = R.n_vclass * (int)(sizeof(DVoxClass) / 8);
     for (int k = tid; k < nbd; k += BLOCK) tabs[k] = ((const double*)(B.bclass_tab + R.btab_begin))[k];
@@ -277,33 +297,29 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     const DVoxClass* const vct = (const DVoxClass*)(tabs + nbd);
     __syncthreads();
 
-    // ---- this voxel: constants, links, state -> registers; pose -> LDS
+    // ---- this thread's voxel (momenta -> registers, pose -> LDS, accumulators zeroed) and its three bonds
     const DVoxClass& C = vct[valid ? B.vclass[v] : 0];
-    int link[3] = {-1, -1, -1};               // local index of the +A neighbour | bond class << 10
-    unsigned negmask = 0;                     // bit A: a bond arrives from the -A neighbour
-    unsigned modebits = 0;                    // 2 bits per +A bond: SmallAngle, history layout (DBatch::hist)
+    int entry[3];                             // my bond of each axis round (DBatch::blist), -1 = none
+    unsigned modebits = 0;                    // 2 bits per bond: SmallAngle, history layout (DBatch::hist)
     int row = -1;                             // my row of collision partners (surface voxels of colliding robots)
     float amp_damp = 1.f;
-    VoxState S;
-    S.pos = mk3(0, 0, 0); S.lm = mk3(0, 0, 0); S.am = mk3(0, 0, 0); S.ang = mkq(1, 0, 0, 0); S.scale = 0;
+    d3 lm = mk3(0, 0, 0), am = mk3(0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        entry[a] = valid ? B.blist[(unsigned)a * nv + v] : -1;
+        if (entry[a] >= 0) modebits |= (unsigned)(B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] & 3) << (2 * a);
+    }
     if (valid) {
         const int b0 = rs.steps & 1;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int bc = B.bclass[(unsigned)a * nv + v];
-            if (bc >= 0) { link[a] = (B.nbr[(unsigned)(2 * a) * nv + v] - base) | (bc << 10); modebits |= (unsigned)(B.small_angle[(unsigned)a * nv + v] & 3) << (2 * a); }
-            if (B.nbr[(unsigned)(2 * a + 1) * nv + v] >= 0) negmask |= 1u << a;
-        }
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
         amp_damp = B.amp_damp[v];
-        S.pos = mk3(POS(b0, 0, v), POS(b0, 1, v), POS(b0, 2, v));
-        S.scale = SCALE(b0, v);
-        S.ang = mkq(QUAT(0, v), QUAT(1, v), QUAT(2, v), QUAT(3, v));
-        S.lm = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v));
-        S.am = mk3(ANGMOM(0, v), ANGMOM(1, v), ANGMOM(2, v));
-        ps[tid] = S.pos.x; ps[BLOCK + tid] = S.pos.y; ps[2 * BLOCK + tid] = S.pos.z; ps[3 * BLOCK + tid] = S.scale;
-        ps[4 * BLOCK + tid] = S.ang.w; ps[5 * BLOCK + tid] = S.ang.x; ps[6 * BLOCK + tid] = S.ang.y; ps[7 * BLOCK + tid] = S.ang.z;
+        lm = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v));
+        am = mk3(ANGMOM(0, v), ANGMOM(1, v), ANGMOM(2, v));
+        ps[tid] = POS(b0, 0, v); ps[BLOCK + tid] = POS(b0, 1, v); ps[2 * BLOCK + tid] = POS(b0, 2, v); ps[3 * BLOCK + tid] = SCALE(b0, v);
+        ps[4 * BLOCK + tid] = QUAT(0, v); ps[5 * BLOCK + tid] = QUAT(1, v); ps[6 * BLOCK + tid] = QUAT(2, v); ps[7 * BLOCK + tid] = QUAT(3, v);
     }
+#pragma unroll
+    for (int k = 0; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;
     const FetchLds<BLOCK> fetch{ps, base};
 
     // the control thread sits in the LAST wave: the one with the fewest (often no) voxels, so its serial work hides
@@ -318,62 +334,57 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (!K.go) break;
         // opaque per-step copies: keeps the compiler from hoisting every address of the step out of the loop (dozens of
         // loop-invariant 64-bit pointers, which it then spills)
-        unsigned vo = voff; int vv = v, rowv = row;
-        asm volatile("" : "+v"(vo), "+v"(vv), "+v"(rowv));
-        if (K.latch || K.eol) fused_latch_cm<BLOCK>(R, rs, ps, ex, valid, C, K.latch != 0, K.eol != 0);
-        if (K.rebuild) fused_rebuild<BLOCK>(B, R, rs, ps, (int*)ex, vct);
+        int vv = v, rowv = row;
+        asm volatile("" : "+v"(vv), "+v"(rowv));
+        const unsigned vo = (unsigned)vv * 8u;
+        bool scratch_used = false;            // latch / broad-phase borrow the accumulator tile
+        if (K.latch || K.eol) { fused_latch_cm<BLOCK>(R, rs, ps, acc, valid, C, K.latch != 0, K.eol != 0); scratch_used = true; }
+        if (K.rebuild) { fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct); scratch_used = true; }
+        if (scratch_used) { acc[tid] = 0.0; __syncthreads(); }
         const int ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;   // issued early, consumed in the voxel phase
         double ph_sin = 0, ph_cos = 0;
         if (valid) { ph_sin = ld_plane(B.act_sb, 0, nv, vo); ph_cos = ld_plane(B.act_cb, 0, nv, vo); }
         d3 drag = mk3(0, 0, 0);
-        if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, tabs + nbd + nvd, valid, vv, S.lm, C.mass_inv);
+        if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, tabs + nbd + nvd, valid, vv, lm, C.mass_inv);
         const double inv_dt_prev = K.inv_dt_prev;
         VXH_T_MARK(1)
 
-        // ---- bond phase: this voxel's +X, +Y, +Z bonds; own-side sums stay in registers, far-side outputs go to LDS
-        d3 F = mk3(0, 0, 0), M = mk3(0, 0, 0);
+        // ---- bond phase: three axis rounds over the compacted bond lists
         bool div = false;
-        if constexpr (NEX == 3) {
-            if (valid) {
-                fused_bond<0, BLOCK, FLUID>(B, R, bct, ps, ex, link[0], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
-                fused_bond<1, BLOCK, FLUID>(B, R, bct, ps, ex + 6 * BLOCK, link[1], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
-                fused_bond<2, BLOCK, FLUID>(B, R, bct, ps, ex + 12 * BLOCK, link[2], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
-            }
-            if (div) s_div = 1;
-            VXH_T_MARK(2)
-            __syncthreads();                   // (B)
-            VXH_T_MARK(3)
-            if (valid) {
-                fused_gather<BLOCK>(ex, tid, negmask & 1u, F, M);
-                fused_gather<BLOCK>(ex + 6 * BLOCK, tid, negmask & 2u, F, M);
-                fused_gather<BLOCK>(ex + 12 * BLOCK, tid, negmask & 4u, F, M);
-            }
-        } else {
-            if (valid) fused_bond<0, BLOCK, FLUID>(B, R, bct, ps, ex, link[0], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
-            __syncthreads();
-            if (valid) fused_gather<BLOCK>(ex, tid, negmask & 1u, F, M);
-            __syncthreads();
-            if (valid) fused_bond<1, BLOCK, FLUID>(B, R, bct, ps, ex, link[1], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
-            __syncthreads();
-            if (valid) fused_gather<BLOCK>(ex, tid, negmask & 2u, F, M);
-            __syncthreads();
-            if (valid) fused_bond<2, BLOCK, FLUID>(B, R, bct, ps, ex, link[2], vo, vv, S.pos, S.ang, S.scale, modebits, inv_dt_prev, F, M, div);
-            if (div) s_div = 1;
-            __syncthreads();                   // (B)
-            if (valid) fused_gather<BLOCK>(ex, tid, negmask & 4u, F, M);
-        }
+        fused_round<0, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[0], modebits, inv_dt_prev, div);
+        __syncthreads();
+        fused_round<1, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[1], modebits, inv_dt_prev, div);
+        __syncthreads();
+        fused_round<2, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[2], modebits, inv_dt_prev, div);
+        if (div) s_div = 1;
+        VXH_T_MARK(2)
+        __syncthreads();                       // (B)
+        VXH_T_MARK(3)
         if (s_div) {                           // Integrate() returns before the voxel loop (VX_Sim.cpp:1777)
             __syncthreads();                   // everyone has read s_div
             if (ctl_thread) { rs.diverged = 1; fused_control_begin(R, rs, step_cap, 0, Knext); s_div = 0; }   // -> status diverged, go = 0
             __syncthreads();
             continue;
         }
-        // ---- voxel phase (all in registers; contact partners from the pose tile)
+        // ---- voxel phase: sums from the accumulators (zeroed again for the next step), pose from the tile, momenta in
+        // registers; contact partners from the pose tile
         double vel2 = 0;
+        VoxState S;
         if (valid) {
+            d3 F = mk3(acc[tid], acc[BLOCK + tid], acc[2 * BLOCK + tid]), M = mk3(acc[3 * BLOCK + tid], acc[4 * BLOCK + tid], acc[5 * BLOCK + tid]);
+            if constexpr (NACC == 2) {
+                F = F + mk3(acc[6 * BLOCK + tid], acc[7 * BLOCK + tid], acc[8 * BLOCK + tid]);
+                M = M + mk3(acc[9 * BLOCK + tid], acc[10 * BLOCK + tid], acc[11 * BLOCK + tid]);
+            }
+#pragma unroll
+            for (int k = 0; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;
+            S.pos = mk3(ps[tid], ps[BLOCK + tid], ps[2 * BLOCK + tid]); S.scale = ps[3 * BLOCK + tid];
+            S.ang = mkq(ps[4 * BLOCK + tid], ps[5 * BLOCK + tid], ps[6 * BLOCK + tid], ps[7 * BLOCK + tid]);
+            S.lm = lm; S.am = am;
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
             vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, ph_sin, ph_cos, amp_damp);
+            lm = S.lm; am = S.am;
         }
         if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
         if ((R.flags & RF_SELF_COL) && !(B.dbg & 2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
@@ -396,15 +407,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // ---- back to HBM: state into the buffer the step count selects, flag bits, control block
     if (valid) {
         const int b1 = rs.steps & 1;
-        POS(b1, 0, v) = S.pos.x; POS(b1, 1, v) = S.pos.y; POS(b1, 2, v) = S.pos.z;
-        SCALE(b1, v) = S.scale;
-        LINMOM(0, v) = S.lm.x; LINMOM(1, v) = S.lm.y; LINMOM(2, v) = S.lm.z;
-        ANGMOM(0, v) = S.am.x; ANGMOM(1, v) = S.am.y; ANGMOM(2, v) = S.am.z;
-        QUAT(0, v) = S.ang.w; QUAT(1, v) = S.ang.x; QUAT(2, v) = S.ang.y; QUAT(3, v) = S.ang.z;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-            if (link[a] >= 0) B.small_angle[(unsigned)a * nv + v] = (unsigned char)((modebits >> (2 * a)) & 3u);
+        POS(b1, 0, v) = ps[tid]; POS(b1, 1, v) = ps[BLOCK + tid]; POS(b1, 2, v) = ps[2 * BLOCK + tid];
+        SCALE(b1, v) = ps[3 * BLOCK + tid];
+        QUAT(0, v) = ps[4 * BLOCK + tid]; QUAT(1, v) = ps[5 * BLOCK + tid]; QUAT(2, v) = ps[6 * BLOCK + tid]; QUAT(3, v) = ps[7 * BLOCK + tid];
+        LINMOM(0, v) = lm.x; LINMOM(1, v) = lm.y; LINMOM(2, v) = lm.z;
+        ANGMOM(0, v) = am.x; ANGMOM(1, v) = am.y; ANGMOM(2, v) = am.z;
     }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        if (entry[a] >= 0) B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] = (unsigned char)((modebits >> (2 * a)) & 3u);
     if (tid == 0) B.rstate[r] = rs;
 }
 
