@@ -47,7 +47,7 @@ private:
     int graph_steps_ = 32;                     // streaming path: step rounds captured per hipGraph launch (0 = plain launches)
     int dbg_ = 0;
     bool fused_ = true;                        // one-workgroup-per-robot fused kernel when every robot has <= 1024 voxels
-    int steps_per_launch_ = 64;                // fused path: time steps per kernel launch
+    int steps_per_launch_ = 256;               // fused path: time steps per kernel launch
     vxh_counters counters_{};
 };
 

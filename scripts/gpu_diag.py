@@ -186,3 +186,8 @@ if __name__ == "__main__" and PHASES:
     for col, dbg in ((True, 0), (True, 1), (True, 3), (False, 0)):
         print("col", col, "dbg", dbg, flush=True)
         timing2(512, (10, 10, 10), 0.02, col, {"fused": 1, "steps_per_launch": 64, "dbg": dbg})
+
+
+if __name__ == "__main__" and "spl" in sys.argv[1:]:
+    for spl in (64, 128, 256, 512):
+        timing2(512, (10, 10, 10), 0.05, True, {"fused": 1, "steps_per_launch": spl})
