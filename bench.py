@@ -134,7 +134,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("VXH_FORCE_DIST") == "1"   # (the latter: 1-rank RCCL smoke test)
     if args.gpus != world and distributed:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
