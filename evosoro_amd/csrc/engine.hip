@@ -368,7 +368,8 @@ void Engine::prepare()
             if (n > 1024 || M.bond_classes.size() > 2047) { D.fused_ok = false; continue; }
             const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
             const int fluid = M.nmv > 0 ? 1 : 0;
-            const size_t extra = M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) + (size_t)24 * M.nmv;
+            const size_t extra = M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) + (size_t)24 * M.nmv +
+                                 ((fluid && block < 1024) ? (size_t)48 * block : 0);   // class tables, drag mesh, strain tile
             const int nex = block < 1024 ? 2 : 1;     // accumulator tiles (NACC of k_robot_steps): a function of the robot's size only
             if ((size_t)(8 + 6 * nex) * block * 8 + extra > lds_max) { D.fused_ok = false; continue; }
             Device::Group* g = nullptr;

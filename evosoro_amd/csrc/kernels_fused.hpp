@@ -17,6 +17,7 @@
 //                          the reference's summation order +X -X +Y -Y +Z -Z.
 //                          Also scratch of latch / broad-phase between steps (re-zeroed by the voxel phase).
 //   tabs                   this robot's DBondClass and DVoxClass rows
+//   st   [6][BLOCK]        FLUID, BLOCK < 1024: directional strains of the previous step (DBatch::strain otherwise)
 //   mesh [3][nmv]          FLUID only: vertices of the drag mesh
 #pragma once
 
@@ -127,30 +128,35 @@ __device__ __forceinline__ d3 rot_fwd(dq q, d3 f)      // CQuat::RotateVec3D, Ve
 }
 __device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ d3 normalized3(d3 a) { const double l = sqrt(len2(a)); return l > 0 ? a * (1.0 / l) : a; }
+__device__ __forceinline__ d3 normalized3(d3 a) { const double l = vsqrt_nn(len2(a)); return l > 0 ? a * vrcp(l) : a; }
 
+// `st`: the voxels' directional strains of the previous step, [6][BLOCK] in LDS (robots up to 768 voxels) or the
+// robot's slice of DBatch::strain with plane stride nv (1024-thread variant, where LDS is full).
 template <int BLOCK>
-__device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const double* ps, double* sh, bool valid, int v, d3 lm,
-                                         double mass_inv)
+__device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const double* ps, const double* st, unsigned st_stride, double* sh,
+                                         bool valid, int v, d3 lm, double mass_inv)
 {
     const unsigned nv = B.nv, tm = B.total_mv;
     const double nom = R.lat;
     const int nmv = R.nmv;
     for (int i = threadIdx.x; i < nmv; i += BLOCK) {
         const int gi = R.vert_begin + i;
+        int comp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) comp[q] = B.vert_comp[(unsigned)q * tm + gi];     // all eight at once: independent loads
         d3 avg = mk3(0, 0, 0); double tw = 0;
+#pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int comp = B.vert_comp[(unsigned)q * tm + gi];
-            if (comp < 0) break;
-            const int u = comp >> 3, corner = comp & 7, l = u - R.vox_begin;
-            const d3 cp = mk3((1 + B.strain[u]) * nom * 0.5, (1 + B.strain[nv + u]) * nom * 0.5, (1 + B.strain[2 * nv + u]) * nom * 0.5);
-            const d3 cn = mk3(-(1 + B.strain[3 * nv + u]) * nom * 0.5, -(1 + B.strain[4 * nv + u]) * nom * 0.5, -(1 + B.strain[5 * nv + u]) * nom * 0.5);
+            if (comp[q] < 0) break;
+            const int l = (comp[q] >> 3) - R.vox_begin, corner = comp[q] & 7;
+            const d3 cp = mk3((1 + st[l]) * nom * 0.5, (1 + st[st_stride + l]) * nom * 0.5, (1 + st[2 * st_stride + l]) * nom * 0.5);
+            const d3 cn = mk3(-(1 + st[3 * st_stride + l]) * nom * 0.5, -(1 + st[4 * st_stride + l]) * nom * 0.5, -(1 + st[5 * st_stride + l]) * nom * 0.5);
             const d3 off = mk3((corner & 4) ? cp.x : cn.x, (corner & 2) ? cp.y : cn.y, (corner & 1) ? cp.z : cn.z);
             const d3 p = mk3(ps[l], ps[BLOCK + l], ps[2 * BLOCK + l]) +
                          rot_fwd(mkq(ps[4 * BLOCK + l], ps[5 * BLOCK + l], ps[6 * BLOCK + l], ps[7 * BLOCK + l]), off);
             avg = avg + p; tw += 1.0;
         }
-        const double inv = 1.0 / tw;
+        const double inv = vrcp(tw);
         const d3 v0 = mk3(B.vert_v0[gi], B.vert_v0[tm + gi], B.vert_v0[2 * tm + gi]);
         const d3 np = avg * inv;
         const d3 now = v0 + (np - v0);                               // v + DrawOffset, as the reference stores it
@@ -161,23 +167,29 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
     if (valid) {
         const unsigned mask = B.open_face[v];
         if (mask) {
+            int cv[8];                                               // mesh vertex at each corner NNN..PPP of this voxel
+#pragma unroll
+            for (int c = 0; c < 8; ++c) cv[c] = B.corner_vert[(unsigned)c * nv + v];
             const d3 speed = lm * mass_inv;
             const d3 sdir = normalized3(speed);
-            // corner codes (NNN..PPP) of the two triangles of faces +X,-X,+Y,-Y,+Z,-Z (LW/VX_MeshUtil.cpp:165-189)
+            // corner codes of the two triangles of faces +X,-X,+Y,-Y,+Z,-Z (LW/VX_MeshUtil.cpp:165-189)
             const unsigned tri[6][2] = {{0x467u, 0x475u}, {0x032u, 0x013u}, {0x237u, 0x276u}, {0x051u, 0x045u}, {0x157u, 0x173u}, {0x064u, 0x026u}};
+#pragma unroll
             for (int d = 0; d < 6; ++d) {
                 if (!(mask & (1u << d))) continue;
+#pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const unsigned code = tri[d][t];
-                    const int ia = B.corner_vert[((code >> 8) & 7u) * nv + v], ib = B.corner_vert[((code >> 4) & 7u) * nv + v], ic = B.corner_vert[(code & 7u) * nv + v];
+                    const int ia = cv[(code >> 8) & 7u], ib = cv[(code >> 4) & 7u], ic = cv[code & 7u];
                     const d3 A = mk3(sh[ia], sh[nmv + ia], sh[2 * nmv + ia]);
                     const d3 AB = mk3(sh[ib], sh[nmv + ib], sh[2 * nmv + ib]) - A, AC = mk3(sh[ic], sh[nmv + ic], sh[2 * nmv + ic]) - A;
                     const d3 cr = cross3(AB, AC);
-                    const double area = fabs(sqrt(len2(cr)) / 2.0);
+                    const double area = fabs(vsqrt_nn(len2(cr)) / 2.0);
                     const d3 n = normalized3(cr);                       // CalcFaceNormals
-                    const float ang = (float)acos(dot3(sdir, normalized3(n)));
+                    const d3 nn = normalized3(n);                       // (the reference normalises the stored normal again, twice)
+                    const float ang = (float)vacos(dot3(sdir, nn));
                     if (fabsf(ang) < VXH_PI / 2) {
-                        const d3 proj = normalized3(n) * dot3(speed, n);    // ProjectOnTo
+                        const d3 proj = nn * dot3(speed, n);            // ProjectOnTo
                         drag = drag + normalized3(proj) * (-R.drag_coef * area * len2(proj));
                     }
                 }
@@ -191,7 +203,7 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
 // both poses from the pose tile, history from/to HBM.  Returns the outputs; the caller adds them to the accumulators.
 template <int A, int BLOCK, bool FLUID>
 __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, int entry,
-                                              unsigned& modebits, double inv_dt_prev)
+                                              unsigned& modebits, double inv_dt_prev, double* st, unsigned st_stride)
 {
     unsigned nv = B.nv;
     asm volatile("" : "+s"(nv));              // plane addresses are rebuilt here by the scalar unit: hoisted out of the step
@@ -216,8 +228,8 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
     }
     modebits = (modebits & ~(3u << (2 * A))) | (H.flags << (2 * A));
     if constexpr (FLUID) {                    // SetStrainDir (VXS_BondInternal.cpp:300-304): +A side of voxel 1, -A side of voxel 2
-        B.strain[(unsigned)A * nv + (R.vox_begin + l1)] = o.strain1;
-        B.strain[(unsigned)(3 + A) * nv + (R.vox_begin + l2)] = o.strain2;
+        st[(unsigned)A * st_stride + l1] = o.strain1;
+        st[(unsigned)(3 + A) * st_stride + l2] = o.strain2;
     }
     return o;
 }
@@ -233,12 +245,12 @@ __device__ __forceinline__ void fused_accumulate(double* acc, int l, d3 f, d3 m)
 // one axis round: bond, then both ends into the accumulators
 template <int A, int BLOCK, int NACC, bool FLUID>
 __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, double* acc, int entry,
-                                            unsigned& modebits, double inv_dt_prev, bool& div)
+                                            unsigned& modebits, double inv_dt_prev, bool& div, double* st, unsigned st_stride)
 {
     const bool has = entry >= 0;
     BondOut o;
     if (has) {
-        o = fused_bond<A, BLOCK, FLUID>(B, R, bct, ps, entry, modebits, inv_dt_prev);
+        o = fused_bond<A, BLOCK, FLUID>(B, R, bct, ps, entry, modebits, inv_dt_prev, st, st_stride);
         div = div || o.diverged;
         fused_accumulate<BLOCK>(acc, entry & 1023, o.f1, o.m1);
     }
@@ -295,6 +307,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     for (int k = tid; k < nvd; k += BLOCK) tabs[nbd + k] = ((const double*)(B.vclass_tab + R.vtab_begin))[k];
     const DBondClass* const bct = (const DBondClass*)tabs;
     const DVoxClass* const vct = (const DVoxClass*)(tabs + nbd);
+    // FLUID: directional strains of the previous step (inputs of the drag mesh) in LDS next to the tables, then the mesh
+    // vertices; the 1024-thread variant has no room for the strains and keeps them in HBM
+    constexpr bool STRAIN_LDS = FLUID && BLOCK < 1024;
+    double* const st = STRAIN_LDS ? tabs + nbd + nvd : B.strain + R.vox_begin;
+    const unsigned st_stride = STRAIN_LDS ? (unsigned)BLOCK : nv;
+    double* const mesh = tabs + nbd + nvd + (STRAIN_LDS ? 6 * BLOCK : 0);
+    if constexpr (STRAIN_LDS) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) st[k * BLOCK + tid] = tid < R.nvox ? B.strain[(unsigned)k * nv + (unsigned)(R.vox_begin + tid)] : 0.0;
+    }
     __syncthreads();
 
     // ---- this thread's voxel (momenta -> registers, pose -> LDS, accumulators zeroed) and its three bonds
@@ -345,17 +367,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         double ph_sin = 0, ph_cos = 0;
         if (valid) { ph_sin = ld_plane(B.act_sb, 0, nv, vo); ph_cos = ld_plane(B.act_cb, 0, nv, vo); }
         d3 drag = mk3(0, 0, 0);
-        if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, tabs + nbd + nvd, valid, vv, lm, C.mass_inv);
+        if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, st, st_stride, mesh, valid, vv, lm, C.mass_inv);
         const double inv_dt_prev = K.inv_dt_prev;
         VXH_T_MARK(1)
 
         // ---- bond phase: three axis rounds over the compacted bond lists
         bool div = false;
-        fused_round<0, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[0], modebits, inv_dt_prev, div);
+        fused_round<0, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[0], modebits, inv_dt_prev, div, st, st_stride);
         __syncthreads();
-        fused_round<1, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[1], modebits, inv_dt_prev, div);
+        fused_round<1, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[1], modebits, inv_dt_prev, div, st, st_stride);
         __syncthreads();
-        fused_round<2, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[2], modebits, inv_dt_prev, div);
+        fused_round<2, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[2], modebits, inv_dt_prev, div, st, st_stride);
         if (div) s_div = 1;
         VXH_T_MARK(2)
         __syncthreads();                       // (B)
@@ -412,6 +434,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         QUAT(0, v) = ps[4 * BLOCK + tid]; QUAT(1, v) = ps[5 * BLOCK + tid]; QUAT(2, v) = ps[6 * BLOCK + tid]; QUAT(3, v) = ps[7 * BLOCK + tid];
         LINMOM(0, v) = lm.x; LINMOM(1, v) = lm.y; LINMOM(2, v) = lm.z;
         ANGMOM(0, v) = am.x; ANGMOM(1, v) = am.y; ANGMOM(2, v) = am.z;
+    }
+    if constexpr (STRAIN_LDS) {
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) B.strain[(unsigned)k * nv + (unsigned)v] = st[k * BLOCK + tid];
+        }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)

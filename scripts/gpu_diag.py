@@ -191,3 +191,40 @@ if __name__ == "__main__" and PHASES:
 if __name__ == "__main__" and "spl" in sys.argv[1:]:
     for spl in (64, 128, 256, 512):
         timing2(512, (10, 10, 10), 0.05, True, {"fused": 1, "steps_per_launch": spl})
+
+
+def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel_phase=False):
+    """BASELINE configs[3]/[4]: throughput of other workloads (not the bench line)"""
+    from collections import OrderedDict
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    sim = Sim(dt_frac=0.9, simulation_time=sim_time, fitness_eval_init_time=min(0.05, sim_time / 5))
+    with engine.Engine(variant, 0) as eng:
+        for k, val in opts.items():
+            eng.set_option(k, val)
+        for i in range(count):
+            mat = workloads.full_material(shape[0], 1 + i) if full else workloads.random_material(shape, i)
+            extra = None
+            if per_voxel_phase:
+                extra = OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(i).uniform(-1, 1, size=shape), 3))])
+            ind = workloads.make_individual(i, mat, extra)
+            write_voxelyze_file(sim, env, ind, tmp, "t")
+            eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "t--id_%05i.vxa" % i))
+        eng.run()
+        c = eng.counters()
+        st = sorted(set(eng.result(i).status for i in range(count)))
+        print("variant %d: %d x %s full=%s sim %.3fs %s: max_steps %d kernel %.4fs -> %.3e vox-steps/s, %.1f us/step, alg GB/s %.1f, statuses %s" % (
+            variant, count, shape, full, sim_time, opts, c.max_steps, c.kernel_seconds, c.voxel_steps / c.kernel_seconds,
+            1e6 * c.kernel_seconds / c.max_steps, c.algorithmic_bytes / c.kernel_seconds / 1e9, st), flush=True)
+
+
+if __name__ == "__main__" and "cfgs" in sys.argv[1:]:
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.05, env_w, {}, per_voxel_phase=True)      # configs[3]
+    timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.05, env_w, {}, per_voxel_phase=True)
+    timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), {})                                        # configs[1]
+    timing_cfg(engine.VOXCAD, 2048, (6, 6, 6), 0.05, Env(), {})
+    timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.01, Env(), {}, full=True)                           # configs[4]
+    timing_cfg(engine.VOXCAD, 512, (10, 10, 10), 0.02, Env(), {}, full=True)                         # dense 10^3 (1024-thread variant)
