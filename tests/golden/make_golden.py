@@ -73,6 +73,15 @@ def cases():
     out["lw_swim6"] = dict(variant="lw", sim=Sim(dt_frac=0.9, simulation_time=0.3, fitness_eval_init_time=0.0),
                            env=env_w, ind=workloads.make_individual(6, workloads.random_material((6, 6, 6), 22),
                                                                     OrderedDict([("<PhaseOffset>", phase6)])))
+    # ---- per-voxel evolved stiffness (evosoro/examples/land_continuous.py:109): the two variants apply it at different
+    # points of the import, so one case each.  Whole numbers: python2 and python3 print them alike.
+    stiff = np.round(10 ** np.random.RandomState(31).uniform(6.0, 8.0, size=(5, 5, 5)), 0)
+    out["stiff5"] = dict(variant="land", sim=Sim(dt_frac=0.9, simulation_time=0.1, fitness_eval_init_time=0.02),
+                         env=Env(), ind=workloads.make_individual(7, workloads.random_material((5, 5, 5), 41),
+                                                                  OrderedDict([("<Stiffness>", stiff)])))
+    out["lw_stiff5"] = dict(variant="lw", sim=Sim(dt_frac=0.9, simulation_time=0.1, fitness_eval_init_time=0.02),
+                            env=Env(), ind=workloads.make_individual(8, workloads.random_material((5, 5, 5), 41),
+                                                                     OrderedDict([("<Stiffness>", stiff)])))
     return out
 
 

@@ -23,7 +23,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4"]
+CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "stiff5"]
 FLOOR_VOX = 1e-9
 
 
@@ -213,7 +213,7 @@ def test_full_size_batch_properties(eng_mod, tmp_path):
         assert results[i].steps == o.info().steps
 
 
-LW_CASES = ["lw_land6", "lw_swim6", "lw_hexapus", "lw_quadruped_land"]
+LW_CASES = ["lw_land6", "lw_swim6", "lw_hexapus", "lw_quadruped_land", "lw_stiff5"]
 
 
 def test_land_water_variant(eng_mod, golden_dir):

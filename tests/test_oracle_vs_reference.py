@@ -13,10 +13,10 @@ import pytest
 
 from oracle import vxoracle as vo
 
-LAND_CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4"]
+LAND_CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "stiff5"]
 SHIPPED = ["example_1", "example_phaseoffset"]
 # _voxcad_land_water: generated (land + fluid swimmer with facet drag) and two sample files shipped with the reference
-LW_CASES = ["lw_land6", "lw_swim6"]
+LW_CASES = ["lw_land6", "lw_swim6", "lw_stiff5"]
 LW_SHIPPED = ["lw_hexapus", "lw_quadruped_land"]
 LW_TAGS = [("normAbsoluteDisplacement", "norm_abs_disp"), ("normDistX", "norm_dist_x"), ("normDistY", "norm_dist_y"),
            ("normDistZ", "norm_dist_z"), ("VoxelNumber", "nvox")]
