@@ -17,7 +17,9 @@ struct DBondClass {
 };
 
 enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_STICKY = 16, RF_FLUID = 32, RF_LW = 64,
-                  RF_HORIZON_COL = 128 };
+                  RF_HORIZON_COL = 128,
+                  // _voxcad development (VXS_Voxel.cpp:236-328): any layer present / which ones
+                  RF_DEV = 256, RF_DEV_SIZE = 512 /* Initial- or FinalVoxelSize */, RF_DEV_FSIZE = 1024, RF_DEV_FPHASE = 2048, RF_DEV_FTAD = 4096 };
 
 struct DRobot {               // constant per robot
     int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr, pad0;
@@ -28,6 +30,7 @@ struct DRobot {               // constant per robot
     double dt, lat, bond_z_half, slow_z, col_z, grav_acc;
     double init_cm_time, stop_value, afterlife, temp_period_d;
     double min_temp_fact, growth_amplitude, col_horizon, filter_dist2, drag_coef;
+    double midlife_freeze_time;
     float temp_amplitude, temp_period;
 };
 
@@ -61,6 +64,8 @@ struct DBatch {
     const double* act_sb;             // [nv] sin / cos of 2 pi' * PhaseOffset of the voxel (pi' = 3.1415926f)
     const double* act_cb;
     const float* amp_damp;            // [nv]
+    const float* dev;                 // [7][nv] development robots: initialVoxelSize, finalVoxelSize, startGrowthTime, growthTime,
+                                      // phaseOffset, finalPhaseOffset, finalTempAmpDamp (float members of CVXS_Voxel)
     // voxel state, 18 component planes of nv doubles each: [0..3] pos xyz + scale (buffer 0), [4..7] the same
     // (buffer 1; positions/scale are double-buffered because collision forces read OTHER voxels' previous
     // positions), [8..11] quaternion w x y z, [12..14] linear momentum, [15..17] angular momentum

@@ -202,6 +202,9 @@ void Engine::prepare()
     std::vector<int> blist((size_t)3 * nv, -1);
     std::vector<float> amp_damp(nv, 1.f);
     std::vector<double> act_sb(nv, 0.0), act_cb(nv, 1.0);
+    bool any_dev = false;
+    for (int r = 0; r < nr; ++r) any_dev = any_dev || robots_[r].development;
+    std::vector<float> dev(any_dev ? (size_t)7 * nv : 7, 0.f);
     std::vector<double> px(nv, 0), py(nv, 0), pz(nv, 0), sc(nv, 0), qw(nv, 1.0);
     std::vector<unsigned char> small((size_t)3 * nv, 1);
     // land_water fluid robots: drag mesh
@@ -246,6 +249,11 @@ void Engine::prepare()
             vclass[g] = (unsigned short)M.vox_class[v];
             { const double b = (double)(2 * 3.1415926f) * (double)M.phase_offset[v]; act_sb[g] = std::sin(b); act_cb[g] = std::cos(b); }
             amp_damp[g] = M.temp_amp_damp[v];
+            if (M.development) {
+                const float vals[7] = {M.initial_voxel_size[v], M.final_voxel_size[v], M.start_growth_time[v], M.growth_time[v],
+                                       M.phase_offset[v], M.final_phase_offset[v], M.final_temp_amp_damp[v]};
+                for (int k = 0; k < 7; ++k) dev[(size_t)k * nv + g] = vals[k];
+            }
             px[g] = M.nom_pos[3 * v]; py[g] = M.nom_pos[3 * v + 1]; pz[g] = M.nom_pos[3 * v + 2];
             sc[g] = M.vox_classes[M.vox_class[v]].nom_size;
             for (int d = 0; d < 6; ++d) { int o = M.nbr[(size_t)v * 6 + d]; nbr[(size_t)d * nv + g] = o < 0 ? -1 : base + o; }
@@ -282,7 +290,10 @@ void Engine::prepare()
         R.flags = (X.self_col_enabled ? RF_SELF_COL : 0) | (X.grav_enabled ? RF_GRAV : 0) | (X.floor_enabled ? RF_FLOOR : 0) |
                   (X.temp_enabled ? RF_TEMP : 0) | ((X.sticky_floor && variant_ == 0) ? RF_STICKY : 0) |
                   ((variant_ == 1 && X.fluid_env) ? RF_FLUID : 0) | (variant_ == 1 ? RF_LW : 0) |
-                  ((X.col_system == 2 || X.col_system == 3) ? RF_HORIZON_COL : 0);
+                  ((X.col_system == 2 || X.col_system == 3) ? RF_HORIZON_COL : 0) |
+                  (M.development ? RF_DEV : 0) | ((X.has_initial_voxel_size || X.has_final_voxel_size) ? RF_DEV_SIZE : 0) |
+                  (X.has_final_voxel_size ? RF_DEV_FSIZE : 0) | (X.has_final_phase_offset ? RF_DEV_FPHASE : 0) |
+                  (X.has_final_temp_amp_damp ? RF_DEV_FTAD : 0);
         R.stop_type = X.stop_type; R.excl_wpr = wpr; R.excl_begin = excl_begin;
         R.vert_begin = mv_begin[r]; R.nmv = M.nmv;
         R.vtab_begin = vtab_begin; R.n_vclass = (int)M.vox_classes.size(); R.btab_begin = btab_begin; R.n_bclass = (int)M.bond_classes.size();
@@ -308,6 +319,7 @@ void Engine::prepare()
         R.col_horizon = X.collision_horizon;
         { double fd = X.collision_horizon * 1.5 * X.lattice_dim; R.filter_dist2 = fd * fd; }
         R.drag_coef = X.aggregate_drag_coef;
+        R.midlife_freeze_time = X.midlife_freeze_time;
         R.temp_amplitude = (float)X.temp_amplitude; R.temp_period = (float)X.temp_period;
         DRobotState& S = rstate[r];
         std::memset(&S, 0, sizeof(S));
@@ -328,6 +340,7 @@ void Engine::prepare()
     B.act_sb = D.upload(act_sb);
     B.act_cb = D.upload(act_cb);
     B.amp_damp = D.upload(amp_damp);
+    B.dev = D.upload(dev);
     {
         std::vector<double> vs((size_t)18 * nv, 0.0);
         for (int b = 0; b < 2; ++b) {

@@ -338,6 +338,17 @@ struct FetchLds {          // fused path: the workgroup's pose tile
     { const int l = slot - base; x = ps[l]; y = ps[BLOCK + l]; z = ps[2 * BLOCK + l]; s = ps[3 * BLOCK + l]; }
 };
 
+// per-voxel development parameters (float members of CVXS_Voxel, VXS_Voxel.h:92-111), only loaded for RF_DEV robots
+struct DevParams { float init_size, final_size, start_growth, growth_time, phase, final_phase, final_tad; };
+__device__ __forceinline__ DevParams load_dev(const DBatch& B, int v)
+{
+    DevParams d;
+    const unsigned nv = B.nv;
+    d.init_size = B.dev[v]; d.final_size = B.dev[nv + v]; d.start_growth = B.dev[2 * nv + v]; d.growth_time = B.dev[3 * nv + v];
+    d.phase = B.dev[4 * nv + v]; d.final_phase = B.dev[5 * nv + v]; d.final_tad = B.dev[6 * nv + v];
+    return d;
+}
+
 // Everything of EulerStep after the internal-bond sums: collision bonds, gravity, floor, integration, actuation.
 // F/M arrive holding slow damping + internal bond forces / minus internal bond moments.  Returns |new velocity|^2.
 template <class Fetch>
@@ -426,7 +437,40 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     // per robot and step, actuation_sincos), and b = 2 pi' phase, fixed per voxel (DBatch::act_sb / act_cb)
     double new_scale;
     const double act = act_sin * ph_cos + act_cos * ph_sin;
-    if (!(flags & RF_LW)) {
+    if (!(flags & RF_LW) && (flags & RF_DEV)) {
+        // _voxcad with development layers (VXS_Voxel.cpp:236-340; the reference mixes float members and double locals, kept)
+        const DevParams D = load_dev(B, v);
+        const double nom = C.nom_size;
+        const double prenatal = prenatal_c * (((double)D.init_size / nom) - 1);
+        double dev_tf = 0, dphase = 0, dtad = 0, frozen = 0, freeze_init = 1;
+        if (R.midlife_freeze_time > 0) {                                 // :247-264
+            const double middle = 0.5 * (R.stop_value - R.init_cm_time);
+            const double fs = middle - 0.5 * R.midlife_freeze_time, fe = middle + 0.5 * R.midlife_freeze_time;
+            if (t > fs && t < fe) { frozen = t - fs; if (t < fs + R.init_cm_time) freeze_init = 0; }
+            if (t > fe) frozen = R.midlife_freeze_time;
+        }
+        if (t >= (double)D.start_growth && D.growth_time > 0) {          // postnatal linear development :267-296
+            const float sg = D.start_growth + D.growth_time;             // float sum, as in the reference
+            double eff = (t <= (double)sg + R.midlife_freeze_time) ? t : (double)sg + R.midlife_freeze_time;
+            eff = eff - frozen;
+            const double k = (eff - (double)D.start_growth) / (double)D.growth_time;
+            if (flags & RF_DEV_FSIZE) { const float ratio = D.final_size / D.init_size; dev_tf = k * ((double)ratio - 1.0); }
+            if (flags & RF_DEV_FPHASE) { const float d = D.final_phase - D.phase; dphase = k * (double)d; }
+            if (flags & RF_DEV_FTAD) { const float d = D.final_tad - amp_damp; dtad = k * (double)d; }
+        }
+        double ctrl = 0;
+        if ((flags & RF_TEMP) && t >= R.init_cm_time)
+            ctrl = ((double)amp_damp + dtad) * ((double)R.temp_amplitude * sin((double)(2 * 3.1415926f) * (t / (double)R.temp_period + ((double)D.phase + dphase)))) * C.cte * freeze_init;
+        if (flags & RF_DEV_SIZE) {                                       // actuation limited by the current size :316-328
+            const double cur_size = (1 + prenatal) * (1 + dev_tf) * nom;
+            const double sig = ((cur_size / nom - 1) / R.growth_amplitude + 1) * 0.5;
+            ctrl = ctrl * (sig > 0.5 ? 0.5 : sig) * 2;
+        }
+        new_scale = ctrl * nom + (1 + prenatal) * (1 + dev_tf) * nom;
+        const double max_scale = (1 + R.growth_amplitude) * nom, min_scale = R.min_temp_fact * nom;
+        if (new_scale < S.scale && new_scale < min_scale) new_scale = S.scale;
+        if (new_scale > S.scale && new_scale > max_scale) new_scale = S.scale;
+    } else if (!(flags & RF_LW)) {
         const double prenatal = prenatal_c * (((float)C.nom_size / C.nom_size) - 1);
         double ctrl = 0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <utility>
 
 namespace vxh {
 
@@ -134,6 +135,10 @@ RobotModel build_robot(const VxaModel& vxa)
     if (m.has_phase_offset && (int)m.phase_offset.size() < r.nvox) throw std::runtime_error("<PhaseOffset> has fewer values than voxels");
     if (m.has_stiffness && (int)m.stiffness.size() < r.nvox) throw std::runtime_error("<Stiffness> has fewer values than voxels");
     if (m.has_temp_amp_damp && (int)m.temp_amp_damp.size() < r.nvox) throw std::runtime_error("<TempAmpDamp> has fewer values than voxels");
+    for (const auto& layer : {std::make_pair(m.has_final_phase_offset, &m.final_phase_offset), std::make_pair(m.has_final_temp_amp_damp, &m.final_temp_amp_damp),
+                              std::make_pair(m.has_initial_voxel_size, &m.initial_voxel_size), std::make_pair(m.has_final_voxel_size, &m.final_voxel_size),
+                              std::make_pair(m.has_growth_time, &m.growth_time), std::make_pair(m.has_start_growth_time, &m.start_growth_time)})
+        if (layer.first && (int)layer.second->size() < r.nvox) throw std::runtime_error("a development layer has fewer values than voxels");
 
     const double size = m.lattice_dim * 1.0;   // GetLatDimEnv().x with X_Dim_Adj == 1 (VX_Object.h:377, VX_Sim.cpp:528)
     r.nbr.assign((size_t)r.nvox * 6, -1);
@@ -141,6 +146,10 @@ RobotModel build_robot(const VxaModel& vxa)
     r.nom_pos.resize((size_t)r.nvox * 3);
     r.phase_offset.assign(r.nvox, 0.0f);
     r.temp_amp_damp.assign(r.nvox, 1.0f);
+    r.development = m.variant == 0 && (m.has_final_phase_offset || m.has_final_temp_amp_damp || m.has_initial_voxel_size || m.has_final_voxel_size ||
+                                        m.has_growth_time || m.has_start_growth_time || m.midlife_freeze_time > 0);
+    for (auto* arr : {&r.final_phase_offset, &r.final_temp_amp_damp, &r.initial_voxel_size, &r.final_voxel_size, &r.growth_time, &r.start_growth_time})
+        arr->assign(r.nvox, 0.0f);
     r.bond_class.assign((size_t)r.nvox * 3, -1);
     std::vector<double> link_E(r.nvox);     // Vox_E at LinkVoxels time
     for (int v = 0; v < r.nvox; ++v) {
@@ -158,6 +167,30 @@ RobotModel build_robot(const VxaModel& vxa)
         r.nom_pos[3 * v + 2] = size * (iz + 0.5);
         if (m.has_phase_offset) r.phase_offset[v] = (float)m.phase_offset[v];
         if (m.has_temp_amp_damp) r.temp_amp_damp[v] = (float)m.temp_amp_damp[v];
+        if (m.variant == 0) {
+            // development parameters, VX_Sim.cpp:885-975: every member is a float, every right-hand side a double
+            const float bound = (float)m.stop_value;      // onsetBound = terminationBound (OnsetRelative/TerminationRelative are refused)
+            r.final_phase_offset[v] = m.has_final_phase_offset ? (float)m.final_phase_offset[v] : 0.0f;
+            r.final_temp_amp_damp[v] = m.has_final_temp_amp_damp ? (float)m.final_temp_amp_damp[v] : 1.0f;
+            auto size_of = [&](double from_vxa) {
+                double tf = 1 + (m.growth_amplitude * from_vxa);
+                double eff = (tf < m.min_temp_fact) ? m.min_temp_fact : tf;
+                return (float)(eff * size);
+            };
+            r.initial_voxel_size[v] = m.has_initial_voxel_size ? size_of(m.initial_voxel_size[v]) : (float)size;
+            r.final_voxel_size[v] = m.has_final_voxel_size ? size_of(m.final_voxel_size[v]) : r.initial_voxel_size[v];
+            if (m.has_start_growth_time) {
+                double t0 = m.start_growth_time[v] * (bound - m.init_cm_time) + m.init_cm_time;
+                r.start_growth_time[v] = (t0 >= bound - m.min_growth_time) ? (float)(bound - m.min_growth_time) : (float)t0;
+            } else if (m.has_final_voxel_size || m.has_growth_time) r.start_growth_time[v] = (float)m.init_cm_time;
+            else r.start_growth_time[v] = (float)(m.stop_value - m.midlife_freeze_time);
+            const float span = bound - r.start_growth_time[v];            // float - float
+            if (m.has_growth_time) {
+                double g = m.growth_time[v] * (span - m.midlife_freeze_time);
+                r.growth_time[v] = (float)((g <= m.min_growth_time) ? m.min_growth_time : g);
+            } else if (m.has_final_voxel_size) r.growth_time[v] = (float)(span - m.midlife_freeze_time);
+            else r.growth_time[v] = (float)m.min_growth_time;
+        }
         const int step[3] = {1, nx, nx * ny};
         const int coord[3] = {ix, iy, iz}, lim[3] = {nx, ny, nz};
         for (int a = 0; a < 3; ++a) {

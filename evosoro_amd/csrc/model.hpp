@@ -41,6 +41,9 @@ struct RobotModel {
     std::vector<int> vox_class;             // index into `vox_classes`
     std::vector<double> nom_pos;            // [nvox*3]
     std::vector<float> phase_offset, temp_amp_damp;
+    // development (float members of CVXS_Voxel, VX_Sim.cpp:885-975); `development` = any of them differs from a plain robot
+    bool development = false;
+    std::vector<float> final_phase_offset, final_temp_amp_damp, initial_voxel_size, final_voxel_size, growth_time, start_growth_time;
     // per bond slot (voxel v, axis a) -> slot 3*v+a ; -1 class = no bond
     std::vector<int> bond_class;            // [nvox*3]
     // collisions

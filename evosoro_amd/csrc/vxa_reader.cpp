@@ -231,7 +231,6 @@ VxaModel read_vxa(const char* data, size_t len, int variant)
     m.min_temp_fact = num(sim, "MinTempFact", 0.1);
     if (const XmlNode* ga = sim ? sim->child("GA") : nullptr)
         if (const XmlNode* f = ga->child("FitnessFileName")) m.fitness_file_name = f->text;
-    if (m.midlife_freeze_time > 0) m.unsupported.push_back("MidLifeFreezeTime>0");
     if (!(m.stop_type >= 0 && m.stop_type <= 3)) m.unsupported.push_back("StopConditionType>3");
 
     // ---- Environment (VX_Environment.cpp:123-234; LW/VX_Environment.cpp:190-191)
@@ -257,6 +256,7 @@ VxaModel read_vxa(const char* data, size_t len, int variant)
         m.temp_period = num(th, "TempPeriod", 0.1);
     }
     m.growth_amplitude = num(env, "GrowthAmplitude", 0);
+    m.min_growth_time = num(env, "MinGrowthTime", 0);
     m.sticky_floor = flag(env, "StickyFloor", false);
     m.fluid_env = flag(env, "FluidEnvironment", false);
     m.aggregate_drag_coef = num(env, "AggregateDragCoefficient", 0);
@@ -267,6 +267,7 @@ VxaModel read_vxa(const char* data, size_t len, int variant)
         if (flag(env, "NeedleInHaystack", false)) m.unsupported.push_back("NeedleInHaystack");
         if (has(env, "FloorRadius")) m.unsupported.push_back("FloorRadius");
         if (has(env, "Sources")) m.unsupported.push_back("Sources");
+        if (flag(env, "OnsetRelative", false) || flag(env, "TerminationRelative", false)) m.unsupported.push_back("OnsetRelative/TerminationRelative");
     }
 
     // ---- VXC (VX_Object.cpp)
@@ -320,8 +321,18 @@ VxaModel read_vxa(const char* data, size_t len, int variant)
     if (const XmlNode* b = st->child("PhaseOffset")) { m.has_phase_offset = true; read_voxel_layers(b, m, m.phase_offset); }
     if (const XmlNode* b = st->child("TempAmpDamp")) { m.has_temp_amp_damp = true; read_voxel_layers(b, m, m.temp_amp_damp); }
     if (const XmlNode* b = st->child("Stiffness")) { m.has_stiffness = true; read_voxel_layers(b, m, m.stiffness); }
-    for (const char* tag : {"FinalPhaseOffset", "FinalTempAmpDamp", "InitialVoxelSize", "FinalVoxelSize", "GrowthTime",
-                            "StartGrowthTime", "StiffnessPlasticityRate", "VestigialLimbs"})
+    if (variant == 0) {   // development layers exist in _voxcad only (VX_Object.cpp:1910-2140)
+        if (const XmlNode* b = st->child("FinalPhaseOffset")) { m.has_final_phase_offset = true; read_voxel_layers(b, m, m.final_phase_offset); }
+        if (const XmlNode* b = st->child("FinalTempAmpDamp")) { m.has_final_temp_amp_damp = true; read_voxel_layers(b, m, m.final_temp_amp_damp); }
+        if (const XmlNode* b = st->child("InitialVoxelSize")) { m.has_initial_voxel_size = true; read_voxel_layers(b, m, m.initial_voxel_size); }
+        if (const XmlNode* b = st->child("FinalVoxelSize")) { m.has_final_voxel_size = true; read_voxel_layers(b, m, m.final_voxel_size); }
+        if (const XmlNode* b = st->child("GrowthTime")) { m.has_growth_time = true; read_voxel_layers(b, m, m.growth_time); }
+        if (const XmlNode* b = st->child("StartGrowthTime")) { m.has_start_growth_time = true; read_voxel_layers(b, m, m.start_growth_time); }
+    } else {
+        for (const char* tag : {"FinalPhaseOffset", "FinalTempAmpDamp", "InitialVoxelSize", "FinalVoxelSize", "GrowthTime", "StartGrowthTime"})
+            if (st->child(tag)) m.unsupported.push_back(std::string("<") + tag + "> development layer (land_water)");
+    }
+    for (const char* tag : {"StiffnessPlasticityRate", "VestigialLimbs"})
         if (st->child(tag)) m.unsupported.push_back(std::string("<") + tag + "> development layer");
     if (variant == 0 && m.temp_amp_damp.size() && !m.has_temp_amp_damp) m.temp_amp_damp.clear();
     return m;

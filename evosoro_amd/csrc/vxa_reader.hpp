@@ -42,7 +42,7 @@ struct VxaModel {
     // Environment
     bool grav_enabled = false, floor_enabled = false, temp_enabled = false, vary_temp_enabled = false;
     double grav_acc = -9.81, temp_amplitude = 0, temp_base = 25, temp_period = 0.1;
-    double growth_amplitude = 0;
+    double growth_amplitude = 0, min_growth_time = 0;
     bool sticky_floor = false;
     bool fluid_env = false;
     double aggregate_drag_coef = 0;
@@ -53,6 +53,10 @@ struct VxaModel {
     std::vector<unsigned char> structure;      // nx*ny*nz, x fastest
     bool has_phase_offset = false, has_temp_amp_damp = false, has_stiffness = false;
     std::vector<double> phase_offset, temp_amp_damp, stiffness;   // by occupied-voxel counter
+    // _voxcad development layers (VX_Object.cpp:1910-2140), empty when the tag is absent
+    bool has_final_phase_offset = false, has_final_temp_amp_damp = false, has_initial_voxel_size = false, has_final_voxel_size = false,
+         has_growth_time = false, has_start_growth_time = false;
+    std::vector<double> final_phase_offset, final_temp_amp_damp, initial_voxel_size, final_voxel_size, growth_time, start_growth_time;
     std::vector<std::string> unsupported;      // features present in the file that the engine does not model
 };
 

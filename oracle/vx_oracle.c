@@ -107,6 +107,7 @@ typedef struct {
     int bond[6];       /* InternalBondIndices by BondDir PX,NX,PY,NY,PZ,NZ (VX_Enums.h:107-114), -1 none */
     /* float-typed per-voxel parameters, VX/VXS_Voxel.h:92-111 */
     float phase_offset, temp_amp_damp, temp_amplitude, temp_period, initial_voxel_size, start_growth_time, growth_time;
+    float final_phase_offset, final_temp_amp_damp, final_voxel_size, onset_bound, termination_bound;
     /* state, VX/VXS_Voxel.h:126-145 */
     v3 pos, lin_mom, ang_mom, vel, ang_vel; qt angle; double scale, last_scale; int static_fric;
     v3 strain_pos, strain_neg;   /* StrainPosDirsCur / StrainNegDirsCur */
@@ -494,18 +495,46 @@ static void euler_step(vxo_sim* s, int vi)
     }
 
     if (s->m.variant == 0) {
-        /* SCALE, VX/VXS_Voxel.cpp:224-340 with development (growth) tags absent */
+        /* SCALE, VX/VXS_Voxel.cpp:224-340 (the velocity-adjusted development of :343-381 needs NumTimeStepsInWindow > 0,
+           which evosoro never writes and the readers refuse) */
         double maxScale = (1 + s->m.growth_amplitude) * v->nom_size;
         double minScale = s->m.min_temp_fact * v->nom_size;
         double currScale;
-        double CtrlTempFact = 0, DevTempFact = 0, DevPhaseAddOn = 0, DevTempAmpDampAddOn = 0, FreezeInitialized = 1;
+        double CtrlTempFact = 0, DevTempFact = 0, DevPhaseAddOn = 0, DevTempAmpDampAddOn = 0, k = 0, FrozenTimeAdj = 0, FreezeInitialized = 1;
         double c = (s->cur_time >= 0.5 * s->m.init_cm_time) ? 1.0 : 2 * s->cur_time / s->m.init_cm_time;
         double PreNatalTempFrac = c * ((v->initial_voxel_size / v->nom_size) - 1);
+        if (s->m.midlife_freeze_time > 0) {                                         /* :247-264 */
+            double middleTime = 0.5 * (s->m.stop_value - s->m.init_cm_time);
+            double FreezeStart = middleTime - 0.5 * s->m.midlife_freeze_time;
+            double FreezeEnd = middleTime + 0.5 * s->m.midlife_freeze_time;
+            if (s->cur_time > FreezeStart && s->cur_time < FreezeEnd) {
+                FrozenTimeAdj = s->cur_time - FreezeStart;
+                if (s->cur_time < FreezeStart + s->m.init_cm_time) FreezeInitialized = 0;
+            }
+            if (s->cur_time > FreezeEnd) FrozenTimeAdj = s->m.midlife_freeze_time;
+        }
+        if (s->cur_time >= v->start_growth_time && v->growth_time > 0) {            /* postnatal linear development :267-296 */
+            /* startGrowthTime + growthTime is a FLOAT sum (both members are float) before the double freeze time is added */
+            float sg = v->start_growth_time + v->growth_time;
+            double EffectiveCurTime = (s->cur_time <= sg + s->m.midlife_freeze_time) ? s->cur_time : sg + s->m.midlife_freeze_time;
+            EffectiveCurTime = EffectiveCurTime - FrozenTimeAdj;
+            k = (EffectiveCurTime - v->start_growth_time) / v->growth_time;
+            if (s->m.final_voxel_size) { float ratio = v->final_voxel_size / v->initial_voxel_size; DevTempFact = k * (ratio - 1.0); }
+            if (s->m.final_phase_offset) { float d = v->final_phase_offset - v->phase_offset; DevPhaseAddOn = k * d; }
+            if (s->m.final_temp_amp_damp) { float d = v->final_temp_amp_damp - v->temp_amp_damp; DevTempAmpDampAddOn = k * d; }
+        }
         if (s->m.temp_enabled && s->cur_time >= s->m.init_cm_time) {
             double ThisCTE = v->cte;
             double ThisPhase = v->phase_offset + DevPhaseAddOn;
             double ThisTempAmpDamp = v->temp_amp_damp + DevTempAmpDampAddOn;
             CtrlTempFact = ThisTempAmpDamp * (v->temp_amplitude * sin(2 * 3.1415926f * (s->cur_time / v->temp_period + ThisPhase))) * ThisCTE * FreezeInitialized;
+        }
+        if (s->m.initial_voxel_size || s->m.final_voxel_size) {                     /* actuation limited by the current size :316-328 */
+            double currSize = (1 + PreNatalTempFrac) * (1 + DevTempFact) * v->nom_size;
+            double originalSigmoid = (currSize / v->nom_size - 1) / s->m.growth_amplitude;
+            double positiveSigmoid = (originalSigmoid + 1) * 0.5;
+            double cappedSigmoid = (positiveSigmoid > 0.5) ? 0.5 : positiveSigmoid;
+            CtrlTempFact = CtrlTempFact * cappedSigmoid * 2;
         }
         currScale = CtrlTempFact * v->nom_size + (1 + PreNatalTempFrac) * (1 + DevTempFact) * v->nom_size;
         if (currScale < v->last_scale && currScale < minScale) currScale = v->last_scale;
@@ -798,7 +827,35 @@ vxo_sim* vxo_create(const vxo_model* m)
         v->temp_period = (float)m->temp_period;
         v->phase_offset = m->phase_offset ? (float)m->phase_offset[i] : (float)0.0;
         v->temp_amp_damp = m->temp_amp_damp ? (float)m->temp_amp_damp[i] : (float)1.0;
-        v->initial_voxel_size = (float)v->nom_size;
+        /* development parameters, VX/VX_Sim.cpp:885-975; every member is a float, the right-hand sides are doubles */
+        v->final_phase_offset = m->final_phase_offset ? (float)m->final_phase_offset[i] : (float)0.0;
+        v->final_temp_amp_damp = m->final_temp_amp_damp ? (float)m->final_temp_amp_damp[i] : (float)1.0;
+        v->onset_bound = (float)m->stop_value;            /* OnsetRelative / TerminationRelative (ParentLifetime) are refused by the readers */
+        v->termination_bound = (float)m->stop_value;
+        if (m->initial_voxel_size) {
+            double tf = 1 + (m->growth_amplitude * m->initial_voxel_size[i]);
+            double eff = (tf < m->min_temp_fact) ? m->min_temp_fact : tf;
+            v->initial_voxel_size = (float)(eff * v->nom_size);
+        } else v->initial_voxel_size = (float)v->nom_size;
+        if (m->final_voxel_size) {
+            double tf = 1 + (m->growth_amplitude * m->final_voxel_size[i]);
+            double eff = (tf < m->min_temp_fact) ? m->min_temp_fact : tf;
+            v->final_voxel_size = (float)(eff * v->nom_size);
+        } else v->final_voxel_size = v->initial_voxel_size;
+        if (m->start_growth_time) {
+            double t0 = m->start_growth_time[i] * (v->onset_bound - m->init_cm_time) + m->init_cm_time;
+            if (t0 >= v->onset_bound - m->min_growth_time) v->start_growth_time = (float)(v->onset_bound - m->min_growth_time);
+            else v->start_growth_time = (float)t0;
+        } else if (m->final_voxel_size || m->growth_time) v->start_growth_time = (float)m->init_cm_time;
+        else v->start_growth_time = (float)(m->stop_value - m->midlife_freeze_time);
+        if (m->growth_time) {
+            float span = v->termination_bound - v->start_growth_time;                  /* float - float */
+            double g = m->growth_time[i] * (span - m->midlife_freeze_time);
+            v->growth_time = (float)((g <= m->min_growth_time) ? m->min_growth_time : g);
+        } else if (m->final_voxel_size) {
+            float span = v->termination_bound - v->start_growth_time;
+            v->growth_time = (float)(span - m->midlife_freeze_time);
+        } else v->growth_time = (float)m->min_growth_time;
         if (m->variant == 0 && m->stiffness) v->E = m->stiffness[i];               /* SetEMod without refresh, :983-988 */
     }
     s->opt_dt = calc_max_dt(s);

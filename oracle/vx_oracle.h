@@ -32,6 +32,13 @@ typedef struct vxo_model {
     const double* phase_offset;  /* [nvox] by simulation index, or NULL (tag <PhaseOffset>) */
     const double* temp_amp_damp; /* [nvox] or NULL (<TempAmpDamp>) ; _voxcad only */
     const double* stiffness;     /* [nvox] or NULL (<Stiffness>) evolved per-voxel modulus */
+    /* _voxcad development layers (VX_Object.cpp:1910-2140), each [nvox] by simulation index or NULL */
+    const double* final_phase_offset;   /* <FinalPhaseOffset> */
+    const double* final_temp_amp_damp;  /* <FinalTempAmpDamp> */
+    const double* initial_voxel_size;   /* <InitialVoxelSize>, in units of GrowthAmplitude around the nominal size */
+    const double* final_voxel_size;     /* <FinalVoxelSize> */
+    const double* growth_time;          /* <GrowthTime>, fraction of the available lifetime */
+    const double* start_growth_time;    /* <StartGrowthTime>, fraction of the lifetime after InitCmTime */
     /* Simulator */
     double dt_frac, bond_damping_z, col_damping_z, slow_damping_z;
     int self_col_enabled, col_system;
@@ -43,6 +50,7 @@ typedef struct vxo_model {
     int grav_enabled; double grav_acc; int floor_enabled;
     int temp_enabled; double temp_amplitude, temp_base, temp_period; int vary_temp_enabled;
     double growth_amplitude;
+    double min_growth_time;      /* <MinGrowthTime>, VX_Environment.cpp:210 */
     int sticky_floor;
     /* land_water only */
     int fluid_env; double aggregate_drag_coef;

@@ -30,6 +30,9 @@ class VxoModel(ctypes.Structure):
         ("mat_us", ctypes.POINTER(ctypes.c_double)), ("mat_ud", ctypes.POINTER(ctypes.c_double)),
         ("phase_offset", ctypes.POINTER(ctypes.c_double)), ("temp_amp_damp", ctypes.POINTER(ctypes.c_double)),
         ("stiffness", ctypes.POINTER(ctypes.c_double)),
+        ("final_phase_offset", ctypes.POINTER(ctypes.c_double)), ("final_temp_amp_damp", ctypes.POINTER(ctypes.c_double)),
+        ("initial_voxel_size", ctypes.POINTER(ctypes.c_double)), ("final_voxel_size", ctypes.POINTER(ctypes.c_double)),
+        ("growth_time", ctypes.POINTER(ctypes.c_double)), ("start_growth_time", ctypes.POINTER(ctypes.c_double)),
         ("dt_frac", ctypes.c_double), ("bond_damping_z", ctypes.c_double), ("col_damping_z", ctypes.c_double),
         ("slow_damping_z", ctypes.c_double), ("self_col_enabled", ctypes.c_int), ("col_system", ctypes.c_int),
         ("collision_horizon", ctypes.c_double), ("stop_type", ctypes.c_int), ("stop_value", ctypes.c_double),
@@ -38,7 +41,7 @@ class VxoModel(ctypes.Structure):
         ("grav_enabled", ctypes.c_int), ("grav_acc", ctypes.c_double), ("floor_enabled", ctypes.c_int),
         ("temp_enabled", ctypes.c_int), ("temp_amplitude", ctypes.c_double), ("temp_base", ctypes.c_double),
         ("temp_period", ctypes.c_double), ("vary_temp_enabled", ctypes.c_int),
-        ("growth_amplitude", ctypes.c_double), ("sticky_floor", ctypes.c_int),
+        ("growth_amplitude", ctypes.c_double), ("min_growth_time", ctypes.c_double), ("sticky_floor", ctypes.c_int),
         ("fluid_env", ctypes.c_int), ("aggregate_drag_coef", ctypes.c_double),
     ]
 
@@ -137,6 +140,11 @@ def _flag(parent, tag, default):
     return 1 if _atoi(el.text) != 0 else 0
 
 
+DEV_LAYERS = (("FinalPhaseOffset", "final_phase_offset"), ("FinalTempAmpDamp", "final_temp_amp_damp"),
+              ("InitialVoxelSize", "initial_voxel_size"), ("FinalVoxelSize", "final_voxel_size"),
+              ("GrowthTime", "growth_time"), ("StartGrowthTime", "start_growth_time"))
+
+
 def parse_vxa(path_or_text, variant=0):
     """Parse a .vxa into a plain dict (numpy arrays for the lattice and per-voxel layers)."""
     if os.path.exists(path_or_text):
@@ -190,6 +198,7 @@ def parse_vxa(path_or_text, variant=0):
     d["vary_temp_enabled"] = _flag(therm, "VaryTempEnabled", 0)
     d["temp_period"] = _num(therm, "TempPeriod", 0.1)
     d["growth_amplitude"] = _num(env, "GrowthAmplitude", 0.0)
+    d["min_growth_time"] = _num(env, "MinGrowthTime", 0.0)
     d["sticky_floor"] = _flag(env, "StickyFloor", 0)
     d["fluid_env"] = _flag(env, "FluidEnvironment", 0)
     d["aggregate_drag_coef"] = _num(env, "AggregateDragCoefficient", 0.0)
@@ -223,7 +232,7 @@ def parse_vxa(path_or_text, variant=0):
     d["structure"] = cells
     occupied = cells > 0
     nvox = int(occupied.sum())
-    for tag, key in (("PhaseOffset", "phase_offset"), ("TempAmpDamp", "temp_amp_damp"), ("Stiffness", "stiffness")):
+    for tag, key in (("PhaseOffset", "phase_offset"), ("TempAmpDamp", "temp_amp_damp"), ("Stiffness", "stiffness")) + DEV_LAYERS:
         block = st.find(tag)
         if block is None:
             d[key] = None
@@ -253,7 +262,7 @@ class OracleSim(object):
         m = VxoModel()
         for name, _ in VxoModel._fields_:
             if name in ("structure", "nmat", "mat_E", "mat_rho", "mat_nu", "mat_cte", "mat_us", "mat_ud",
-                        "phase_offset", "temp_amp_damp", "stiffness"):
+                        "phase_offset", "temp_amp_damp", "stiffness") + tuple(k for _, k in DEV_LAYERS):
                 continue
             setattr(m, name, model[name])
         m.structure = model["structure"].ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))
@@ -263,6 +272,8 @@ class OracleSim(object):
         m.mat_cte, m.mat_us, m.mat_ud = _dptr(mats["cte"]), _dptr(mats["us"]), _dptr(mats["ud"])
         m.phase_offset, m.temp_amp_damp = _dptr(model["phase_offset"]), _dptr(model["temp_amp_damp"])
         m.stiffness = _dptr(model["stiffness"])
+        for _, key in DEV_LAYERS:
+            setattr(m, key, _dptr(model.get(key)))
         self._cmodel = m
         self._h = lib().vxo_create(ctypes.byref(m))
 

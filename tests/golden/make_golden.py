@@ -82,6 +82,28 @@ def cases():
     out["lw_stiff5"] = dict(variant="lw", sim=Sim(dt_frac=0.9, simulation_time=0.1, fitness_eval_init_time=0.02),
                             env=Env(), ind=workloads.make_individual(8, workloads.random_material((5, 5, 5), 41),
                                                                      OrderedDict([("<Stiffness>", stiff)])))
+    # ---- development (evosoro/examples/growth.py:69-75,91-95: IND_SIZE (5,5,4), GrowthAmplitude 0.5, MinTempFact 0.4,
+    # DtFrac 0.5): per-voxel initial and final size; and a second case with every development layer present
+    env_g = Env()
+    env_g.add_param("growth_amplitude", 0.5, "<GrowthAmplitude>")
+    rs = np.random.RandomState(51)
+    ini = np.round(rs.uniform(-1, 1, size=(5, 5, 4)), 3)
+    fin = np.round(rs.uniform(-1, 1, size=(5, 5, 4)), 3)
+    out["grow5"] = dict(variant="land",
+                        sim=Sim(dt_frac=0.5, simulation_time=0.4, fitness_eval_init_time=0.05, min_temp_fact=0.4),
+                        env=env_g, ind=workloads.make_individual(9, workloads.random_material((5, 5, 4), 52, 0.15),
+                                                                 OrderedDict([("<InitialVoxelSize>", ini), ("<FinalVoxelSize>", fin)])))
+    env_g2 = Env()
+    env_g2.add_param("growth_amplitude", 0.3, "<GrowthAmplitude>")
+    env_g2.add_param("min_growth_time", 0.01, "<MinGrowthTime>")
+    rs = np.random.RandomState(53)
+    layers = OrderedDict()
+    for tag, lo, hi in (("<PhaseOffset>", -1, 1), ("<FinalPhaseOffset>", -1, 1), ("<TempAmpDamp>", 0.2, 1), ("<FinalTempAmpDamp>", 0.2, 1),
+                        ("<InitialVoxelSize>", -1, 1), ("<FinalVoxelSize>", -1, 1), ("<GrowthTime>", 0, 1), ("<StartGrowthTime>", 0, 1)):
+        layers[tag] = np.round(rs.uniform(lo, hi, size=(4, 4, 4)), 3)
+    out["devo4"] = dict(variant="land",
+                        sim=Sim(dt_frac=0.7, simulation_time=0.3, fitness_eval_init_time=0.04, min_temp_fact=0.5),
+                        env=env_g2, ind=workloads.make_individual(10, workloads.random_material((4, 4, 4), 54, 0.1), layers))
     return out
 
 

@@ -13,7 +13,7 @@ import pytest
 
 from oracle import vxoracle as vo
 
-LAND_CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "stiff5"]
+LAND_CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "stiff5", "grow5", "devo4"]
 SHIPPED = ["example_1", "example_phaseoffset"]
 # _voxcad_land_water: generated (land + fluid swimmer with facet drag) and two sample files shipped with the reference
 LW_CASES = ["lw_land6", "lw_swim6", "lw_stiff5"]
