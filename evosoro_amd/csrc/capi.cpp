@@ -5,6 +5,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "engine.hpp"
 
@@ -105,6 +106,16 @@ int vxh_add_vxa_file(vxh_engine* e, const char* path, int* robot_index_out)
     ss << in.rdbuf();
     const std::string text = ss.str();
     return vxh_add_vxa_buffer(e, text.data(), text.size(), robot_index_out);
+}
+
+int vxh_add_vxa_files(vxh_engine* e, const char* const* paths, int n, int* first_index_out)
+{
+    if (!e || !e->impl || n < 0 || (n > 0 && !paths)) return VXH_ERR_ARG;
+    std::vector<std::string> list;
+    for (int i = 0; i < n; ++i) { if (!paths[i]) return VXH_ERR_ARG; list.emplace_back(paths[i]); }
+    int rc = guarded(e, [&] { int idx = e->impl->add_vxa_files(list); if (first_index_out) *first_index_out = idx; });
+    if (rc == VXH_ERR_PARSE && e->last_error.compare(0, 3, "io:") == 0) rc = VXH_ERR_IO;
+    return rc;
 }
 
 int vxh_num_robots(const vxh_engine* e) { return (e && e->impl) ? e->impl->num_robots() : VXH_ERR_ARG; }

@@ -7,7 +7,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <exception>
+#include <fstream>
+#include <sstream>
 #include <stdexcept>
+#include <thread>
 
 #include "engine.hpp"
 #include "kernels.hpp"
@@ -135,6 +140,49 @@ int Engine::add_vxa(const char* data, size_t len)
     prepared_ = false;
     state_downloaded_ = control_downloaded_ = false;
     return (int)robots_.size() - 1;
+}
+
+// A generation arrives as hundreds of .vxa files; reading, XML parsing and model building (hop-distance lists, bond
+// classes, drag mesh) are independent per robot and take longer than the GPU needs to simulate them, so they are
+// spread over the host cores.  Robots are appended in the order of `paths`; the first failure (in that order) is
+// rethrown and nothing is appended.
+int Engine::add_vxa_files(const std::vector<std::string>& paths)
+{
+    const int n = (int)paths.size();
+    std::vector<RobotModel> built(n);
+    std::vector<std::exception_ptr> errors(n);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            try {
+                std::ifstream in(paths[i], std::ios::binary);
+                if (!in) throw std::runtime_error("io: cannot open " + paths[i]);
+                std::stringstream ss;
+                ss << in.rdbuf();
+                const std::string text = ss.str();
+                VxaModel vxa = read_vxa(text.data(), text.size(), variant_);
+                if (!vxa.unsupported.empty()) {
+                    std::string msg = "unsupported .vxa feature(s):";
+                    for (const auto& u : vxa.unsupported) msg += " [" + u + "]";
+                    throw std::invalid_argument(msg + " in " + paths[i]);
+                }
+                built[i] = build_robot(vxa);
+            } catch (...) {
+                errors[i] = std::current_exception();
+            }
+        }
+    };
+    const int nthreads = std::max(1, std::min({n, (int)std::thread::hardware_concurrency(), 64}));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    for (int i = 0; i < n; ++i) if (errors[i]) std::rethrow_exception(errors[i]);
+    const int first = (int)robots_.size();
+    for (int i = 0; i < n; ++i) robots_.push_back(std::move(built[i]));
+    prepared_ = false;
+    state_downloaded_ = control_downloaded_ = false;
+    return first;
 }
 
 void Engine::clear()

@@ -20,6 +20,7 @@ public:
     Engine(int variant, int device_id);       // throws std::runtime_error when no HIP device is usable
     ~Engine();
     int add_vxa(const char* data, size_t len);              // returns robot index; throws
+    int add_vxa_files(const std::vector<std::string>& paths);   // parse + build on all host cores, append in order; returns first index
     int num_robots() const { return (int)robots_.size(); }
     const RobotModel& robot(int i) const { return robots_[i]; }
     void run();                                // to completion

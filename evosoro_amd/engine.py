@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_num_robots", "vxh_robot_dims",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_counters", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version"]
@@ -96,6 +96,7 @@ def load_library():
     lib.vxh_destroy.restype = None
     lib.vxh_add_vxa_file.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(I)]
     lib.vxh_add_vxa_buffer.argtypes = [P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(I)]
+    lib.vxh_add_vxa_files.argtypes = [P, ctypes.POINTER(ctypes.c_char_p), I, ctypes.POINTER(I)]
     lib.vxh_num_robots.argtypes = [P]
     lib.vxh_robot_dims.argtypes = [P, I, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(D), ctypes.POINTER(LL)]
     lib.vxh_run.argtypes = [P]
@@ -169,6 +170,13 @@ class Engine(object):
     def add_vxa_file(self, path):
         idx = ctypes.c_int(-1)
         self._check(self._lib.vxh_add_vxa_file(self._h, os.fsencode(path), ctypes.byref(idx)))
+        return idx.value
+
+    def add_vxa_files(self, paths):
+        """a whole generation: parsed and built on all host cores, appended in order; returns the first robot index"""
+        arr = (ctypes.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        idx = ctypes.c_int(-1)
+        self._check(self._lib.vxh_add_vxa_files(self._h, arr, len(paths), ctypes.byref(idx)))
         return idx.value
 
     def add_vxa_text(self, text):

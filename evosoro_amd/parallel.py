@@ -90,8 +90,11 @@ def run_shard(engine_module, paths, variant, device_index, options=None, write_x
     with engine_module.Engine(variant, device_index) as eng:
         for key, val in (options or {}).items():
             eng.set_option(key, val)
-        for path in paths:
-            eng.add_vxa_file(path)
+        if hasattr(eng, "add_vxa_files"):
+            eng.add_vxa_files(list(paths))       # parsed and built on all host cores
+        else:
+            for path in paths:
+                eng.add_vxa_file(path)
         eng.run()
         for i in range(len(paths)):
             res = eng.result(i)

@@ -101,6 +101,9 @@ void vxh_destroy(vxh_engine* e);
 
 int  vxh_add_vxa_file(vxh_engine* e, const char* path, int* robot_index_out);
 int  vxh_add_vxa_buffer(vxh_engine* e, const char* xml, size_t len, int* robot_index_out);
+/* A whole generation at once (the files evaluate_all wrote, evosoro/tools/evaluation.py:62,89): read, parsed and built on
+ * all host cores, appended in the order given; on error nothing is appended and the first failing file is reported. */
+int  vxh_add_vxa_files(vxh_engine* e, const char* const* paths, int n, int* first_index_out);
 int  vxh_num_robots(const vxh_engine* e);
 int  vxh_robot_dims(const vxh_engine* e, int robot, int* nvox, int* nbond, double* dt, long long* planned_steps);
 

@@ -228,3 +228,31 @@ if __name__ == "__main__" and "cfgs" in sys.argv[1:]:
     timing_cfg(engine.VOXCAD, 2048, (6, 6, 6), 0.05, Env(), {})
     timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.01, Env(), {}, full=True)                           # configs[4]
     timing_cfg(engine.VOXCAD, 512, (10, 10, 10), 0.02, Env(), {}, full=True)                         # dense 10^3 (1024-thread variant)
+
+
+if __name__ == "__main__" and "e2e" in sys.argv[1:]:
+    # whole-generation wall clock through the file boundary: write 512 .vxa, parse + upload, 0.5 s of simulated time, result XMLs
+    import time
+    tmp = tempfile.mkdtemp()
+    for d in ("voxelyzeFiles", "fitnessFiles"):
+        os.makedirs(os.path.join(tmp, d))
+    sim = Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1)
+    env = Env()
+    t0 = time.perf_counter()
+    paths = []
+    for ind in workloads.population(512, (10, 10, 10)):
+        write_voxelyze_file(sim, env, ind, tmp, "t")
+        paths.append(os.path.join(tmp, "voxelyzeFiles", "t--id_%05i.vxa" % ind.id))
+    t1 = time.perf_counter()
+    with engine.Engine(engine.VOXCAD, 0) as eng:
+        eng.add_vxa_files(paths)
+        t2 = time.perf_counter()
+        eng.run()
+        t3 = time.perf_counter()
+        for i in range(len(paths)):
+            eng.write_result_xml(i, os.path.join(tmp, "fitnessFiles", "o%05i.xml" % i))
+        t4 = time.perf_counter()
+        c = eng.counters()
+        print("e2e 512 x 10^3, 0.5 s simulated: python .vxa writer %.2f s | parse %.2f s | upload+run %.2f s (kernel %.2f s, %d max steps) | download+XML %.2f s | "
+              "engine total %.2f s -> %.3e vox-steps/s end to end vs %.3e in-kernel" % (
+                  t1 - t0, t2 - t1, t3 - t2, c.kernel_seconds, c.max_steps, t4 - t3, t4 - t1, c.voxel_steps / (t4 - t1), c.voxel_steps / c.kernel_seconds))

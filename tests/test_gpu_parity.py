@@ -303,3 +303,23 @@ def test_diverging_robot_is_reported_like_the_reference(eng_mod, tmp_path):
             assert eng.result(0).status == eng_mod.ROBOT_DIVERGED
             assert eng.result(0).steps == o.info().steps
             assert eng.result(1).status == eng_mod.ROBOT_FINISHED and np.isfinite(eng.result(1).cur_cm).all()
+
+
+def test_batch_import_matches_sequential_import(eng_mod, golden_dir, tmp_path):
+    """vxh_add_vxa_files (whole generation, parsed on all host cores) == vxh_add_vxa_file one by one: same order, same
+    robots, bitwise the same trajectories; a bad path fails the call and appends nothing."""
+    names = ["probe6", "rand6_col", "soft5_init0", "phase4", "stiff5", "grow5"] * 3
+    paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in names]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as a, eng_mod.Engine(eng_mod.VOXCAD, 0) as b:
+        assert a.add_vxa_files(paths) == 0
+        for p in paths:
+            b.add_vxa_file(p)
+        assert a.num_robots() == b.num_robots() == len(paths)
+        assert [a.dims(i) for i in range(len(paths))] == [b.dims(i) for i in range(len(paths))]
+        a.step(150)
+        b.step(150)
+        for i in range(len(paths)):
+            assert np.array_equal(a.state(i), b.state(i)), i
+        with pytest.raises(Exception):
+            a.add_vxa_files(paths[:2] + [str(tmp_path / "missing.vxa")])
+        assert a.num_robots() == len(paths)
