@@ -256,3 +256,9 @@ if __name__ == "__main__" and "e2e" in sys.argv[1:]:
         print("e2e 512 x 10^3, 0.5 s simulated: python .vxa writer %.2f s | parse %.2f s | upload+run %.2f s (kernel %.2f s, %d max steps) | download+XML %.2f s | "
               "engine total %.2f s -> %.3e vox-steps/s end to end vs %.3e in-kernel" % (
                   t1 - t0, t2 - t1, t3 - t2, c.kernel_seconds, c.max_steps, t4 - t3, t4 - t1, c.voxel_steps / (t4 - t1), c.voxel_steps / c.kernel_seconds))
+
+
+if __name__ == "__main__" and "small" in sys.argv[1:]:
+    timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), {})
+    timing_cfg(engine.VOXCAD, 2048, (6, 6, 6), 0.05, Env(), {})
+    timing_cfg(engine.VOXCAD, 4096, (6, 6, 6), 0.05, Env(), {})
