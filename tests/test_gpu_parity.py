@@ -323,3 +323,44 @@ def test_batch_import_matches_sequential_import(eng_mod, golden_dir, tmp_path):
         with pytest.raises(Exception):
             a.add_vxa_files(paths[:2] + [str(tmp_path / "missing.vxa")])
         assert a.num_robots() == len(paths)
+
+
+def test_edge_sizes_in_one_batch(eng_mod, tmp_path):
+    """Empty lattice, single voxel, two voxels, a one-voxel-wide tower and a lattice of exactly 1024 voxels (every
+    thread of the largest workgroup owns a voxel) side by side: the empty one is reported EMPTY (the reference would
+    never return), the others follow the oracle.
+    (A rod lying FLAT on the floor is deliberately not used: its whole motion is a 2e-8-voxel stick-slip of the prenatal
+    size change against friction, and the reference algorithm itself moves by 5e-10 voxel there when the lattice
+    constant changes by one ulp.)"""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    sim, env = Sim(dt_frac=0.9, simulation_time=0.02, fitness_eval_init_time=0.004), Env()
+    mats = [np.zeros((3, 3, 3), dtype=int), np.zeros((3, 3, 3), dtype=int), np.zeros((3, 3, 3), dtype=int),
+            np.zeros((1, 1, 12), dtype=int), np.full((16, 8, 8), 3, dtype=int)]
+    mats[1][1, 1, 0] = 3
+    mats[2][1, 1, 0] = 3; mats[2][1, 1, 1] = 4
+    mats[3][0, 0, :] = [1, 3, 4, 3, 1, 2, 3, 4, 3, 1, 3, 4]
+    mats[4][::3, ::2, ::2] = 1
+    mats[4][1::4, 1::3, :] = 4
+    os.makedirs(tmp_path / "voxelyzeFiles", exist_ok=True)
+    paths = []
+    for k, m in enumerate(mats):
+        write_voxelyze_file(sim, env, workloads.make_individual(k, m), str(tmp_path), "e")
+        paths.append(str(tmp_path / "voxelyzeFiles" / ("e--id_%05i.vxa" % k)))
+    sims = [None] + [vo.OracleSim.from_vxa(p) for p in paths[1:]]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.add_vxa_files(paths)
+        assert [eng.dims(i)["nvox"] for i in range(5)] == [0, 1, 2, 12, 1024]
+        for upto in (1, 5, 60):
+            eng.step(upto - sims[1].info().steps)
+            for i in range(1, 5):
+                sims[i].step(upto - sims[i].info().steps)
+                assert _pos_err(eng.state(i), sims[i].state(), 0.01) < FLOOR_VOX, (i, upto)
+        eng.run()
+        assert eng.result(0).status == eng_mod.ROBOT_EMPTY
+        for i in range(1, 5):
+            sims[i].step(-1)
+            assert eng.result(i).status == eng_mod.ROBOT_FINISHED and eng.result(i).steps == sims[i].info().steps
+            assert np.abs(np.array(eng.result(i).cur_cm) - np.array(sims[i].info().cur_cm)).max() / 0.01 < 1e-7, i
