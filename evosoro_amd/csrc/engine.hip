@@ -27,15 +27,6 @@ void hip_check(hipError_t e, const char* what)
 }
 #define HIP_OK(call) hip_check((call), #call)
 
-template <class T>
-int intern_bytes(std::vector<T>& table, const T& value)
-{
-    for (size_t i = 0; i < table.size(); ++i)
-        if (std::memcmp(&table[i], &value, sizeof(T)) == 0) return (int)i;
-    table.push_back(value);
-    return (int)table.size() - 1;
-}
-
 }  // namespace
 
 struct Engine::Device {
@@ -44,11 +35,10 @@ struct Engine::Device {
     // fused path: robots grouped by kernel variant (workgroup size 256/512/768/1024, exchange buffers, fluid), one
     // stream per group so that the groups fill the chip together
     struct Group {
-        int block = 0, nex = 0, fluid = 0;
+        int block = 0, nacc = 0, fluid = 0;   // template arguments of k_robot_steps
         int count = 0;
         const int* list = nullptr;
         size_t lds = 0;                   // dynamic LDS bytes
-        int mesh_off = 0;                 // doubles from the start of dynamic LDS
         hipStream_t stream = nullptr;
         hipEvent_t t0 = nullptr, t1 = nullptr;
         std::vector<int> robots;
@@ -431,13 +421,13 @@ void Engine::prepare()
             const int fluid = M.nmv > 0 ? 1 : 0;
             const size_t extra = M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) + (size_t)24 * M.nmv +
                                  ((fluid && block < 1024) ? (size_t)48 * block : 0);   // class tables, drag mesh, strain tile
-            const int nex = block < 1024 ? 2 : 1;     // accumulator tiles (NACC of k_robot_steps): a function of the robot's size only
-            if ((size_t)(8 + 6 * nex) * block * 8 + extra > lds_max) { D.fused_ok = false; continue; }
+            const int nacc = block < 1024 ? 2 : 1;    // accumulator tiles: a function of the robot's size only
+            if ((size_t)(8 + 6 * nacc) * block * 8 + extra > lds_max) { D.fused_ok = false; continue; }
             Device::Group* g = nullptr;
-            for (auto& q : D.groups) if (q.block == block && q.nex == nex && q.fluid == fluid) g = &q;
-            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nex = nex; g->fluid = fluid; }
+            for (auto& q : D.groups) if (q.block == block && q.nacc == nacc && q.fluid == fluid) g = &q;
+            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nacc = nacc; g->fluid = fluid; }
             g->robots.push_back(r);
-            g->lds = std::max(g->lds, (size_t)(8 + 6 * nex) * block * 8 + extra);
+            g->lds = std::max(g->lds, (size_t)(8 + 6 * nacc) * block * 8 + extra);
         }
         size_t gi = 0;
         for (auto& g : D.groups) {
@@ -479,19 +469,19 @@ void Engine::prepare()
 
 void Engine::reset() { if (!robots_.empty()) prepare(); }
 
-template <int BLOCK, int NEX, bool FLUID>
+template <int BLOCK, int NACC, bool FLUID>
 static void launch_variant(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK, NEX, FLUID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(fused LDS)");
+        hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK, NACC, FLUID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(fused LDS)");
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((k_robot_steps<BLOCK, NEX, FLUID>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters);
+    hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters);
 }
 
 template <bool FLUID>
-static void launch_group(const DBatch& B, int block, int nex, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+static void launch_group(const DBatch& B, int block, int nacc, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
     if (block == 256) launch_variant<256, 2, FLUID>(B, list, count, lds, s, cap, iters);
     else if (block == 512) launch_variant<512, 2, FLUID>(B, list, count, lds, s, cap, iters);
@@ -521,8 +511,8 @@ void Engine::advance(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters) {
             for (size_t k = 0; k < D.groups.size(); ++k) {
                 const auto& g = D.groups[k];
-                if (g.fluid) launch_group<true>(B, g.block, g.nex, g.list, g.count, g.lds, g.stream, cap, iters);
-                else launch_group<false>(B, g.block, g.nex, g.list, g.count, g.lds, g.stream, cap, iters);
+                if (g.fluid) launch_group<true>(B, g.block, g.nacc, g.list, g.count, g.lds, g.stream, cap, iters);
+                else launch_group<false>(B, g.block, g.nacc, g.list, g.count, g.lds, g.stream, cap, iters);
                 ++launches; ++group_launches[k];
             }
         }

@@ -7,12 +7,10 @@
 //   voxel_update    CVXS_Voxel::EulerStep / CalcTotalForce / CalcTotalMoment / CalcFloorEffect (VXS_Voxel.cpp:169-758),
 //                   CVXS_BondCollision::CalcContactForce (VXS_BondCollision.cpp:41-59), MaxVoxVel of UpdateStats
 // Two launch shapes share those device functions:
-//   k_robot_steps<BLOCK,NEX,FLUID>  fused path: ONE workgroup per robot (robots up to BLOCK voxels), thread = voxel + its
-//                         three positive bonds.  The robot is RESIDENT in the CU for the whole launch: every thread
-//                         keeps its voxel's integrator state in registers, publishes its pose into an LDS tile that
-//                         neighbour bonds, contact forces, the broad-phase and the drag mesh read, and hands
-//                         Force2/Moment2 of its bonds to the neighbour voxel through a second LDS tile.  Per step only
-//                         the bond history crosses L2/HBM; many steps per launch.
+//   k_robot_steps<BLOCK,NACC,FLUID>  fused path (kernels_fused.hpp): ONE workgroup per robot (robots up to BLOCK voxels),
+//                         the robot RESIDENT in the CU for a whole launch of many time steps: voxel momenta in registers,
+//                         poses and force accumulators in LDS, bonds taken from per-axis compacted lists.  Per step only
+//                         the bond history crosses L2/HBM.
 //   k_step_begin / k_bonds / k_voxels   streaming path for lattices of any size (one thread per bond slot / voxel,
 //                         state and bond outputs through HBM).
 #pragma once
