@@ -104,6 +104,12 @@ def cases():
     out["devo4"] = dict(variant="land",
                         sim=Sim(dt_frac=0.7, simulation_time=0.3, fitness_eval_init_time=0.04, min_temp_fact=0.5),
                         env=env_g2, ind=workloads.make_individual(10, workloads.random_material((4, 4, 4), 54, 0.1), layers))
+    # ---- BASELINE configs[2] size: the first two robots of the bench population (bench.py: random 10x10x10, seeds 0 and 1,
+    # self-collision on), the whole 0.5 s evaluation; final state and result XML only
+    for k in (0, 1):
+        out["bench10_%d" % k] = dict(variant="land", early=False,
+                                     sim=Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.05),
+                                     env=Env(), ind=workloads.random_robot(20 + k, (10, 10, 10), k))
     return out
 
 
@@ -156,9 +162,10 @@ def main():
         subprocess.run(["timeout", "900", refbin[case["variant"]], "-f", vxa], check=False)
         xml = os.path.join(RUN_DIR, "fitnessFiles", "softbotsOutput--id_%05i.xml" % ind.id)
         shutil.copy(xml, os.path.join(exp_dir, name + ".xml"))
-        subprocess.run(["timeout", "900", probe[case["variant"]], "-f", vxa, "-o",
-                        os.path.join(exp_dir, name + ".early.bin"), "-max", "200", "-every", "25", "-noresult"],
-                       check=True)
+        if case.get("early", True):     # (skipped for the 10^3 robots: 700 voxels x 9 snapshots would be 0.7 MB each)
+            subprocess.run(["timeout", "900", probe[case["variant"]], "-f", vxa, "-o",
+                            os.path.join(exp_dir, name + ".early.bin"), "-max", "200", "-every", "25", "-noresult"],
+                           check=True)
         subprocess.run(["timeout", "900", probe[case["variant"]], "-f", vxa, "-o",
                         os.path.join(exp_dir, name + ".final.bin"), "-every", "100000000", "-noresult"], check=True)
 

@@ -364,3 +364,28 @@ def test_edge_sizes_in_one_batch(eng_mod, tmp_path):
             sims[i].step(-1)
             assert eng.result(i).status == eng_mod.ROBOT_FINISHED and eng.result(i).steps == sims[i].info().steps
             assert np.abs(np.array(eng.result(i).cur_cm) - np.array(sims[i].info().cur_cm)).max() / 0.01 < 1e-7, i
+
+
+def test_bench_size_robots_whole_evaluation(eng_mod, golden_dir):
+    """BASELINE configs[2] size against the REFERENCE itself: the first two robots of the bench population, the whole
+    0.5 s evaluation with self-collision (7806 steps), final centre of mass and result tags vs the reference binary's
+    trace / XML; tolerance from the robots' own conditioning as everywhere."""
+    from oracle import vxoracle as vo
+    names = ["bench10_0", "bench10_1"]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.add_vxa_files([os.path.join(golden_dir, "vxa", n + ".vxa") for n in names])
+        eng.run()
+        for i, name in enumerate(names):
+            model = vo.parse_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"))
+            lat = model["lattice_dim"]
+            trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".final.bin"))
+            want = vo.read_result_xml(os.path.join(golden_dir, "expected", name + ".xml"))
+            res = eng.result(i)
+            planned = eng.dims(i)["planned_steps"]
+            tol = max(FLOOR_VOX, 20 * _spread(model, (planned // 2, planned))[0])
+            assert res.status == eng_mod.ROBOT_FINISHED and res.steps == trace["total_steps"] == 7806
+            assert np.abs(np.array(res.ini_cm) - trace["ini_cm"]).max() / lat <= tol, (name, tol)
+            assert np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / lat <= tol, (name, tol)
+            for tag, val in (("NormFinalDist", res.norm_final_dist), ("finalDistY", res.final_dist_y)):
+                assert abs(val - want[tag]) <= 2 * tol + 1e-5 * abs(want[tag]), (name, tag, val, want[tag])
+            print(name, "tolerance (voxel)", tol, "CoM error (voxel)", np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / lat)

@@ -50,7 +50,11 @@ def test_early_trace_bit_exact(golden_dir, name):
         assert np.array_equal(sim.state(), rec["state"]), "state differs at step %d" % rec["step"]
 
 
-@pytest.mark.parametrize("name", LAND_CASES)
+# BASELINE configs[2] size: two robots of the bench population, whole 0.5 s evaluation (7806 steps, ~700 voxels, collisions)
+BIG_CASES = ["bench10_0", "bench10_1"]
+
+
+@pytest.mark.parametrize("name", LAND_CASES + BIG_CASES)
 def test_full_run_final_state_and_result(golden_dir, name):
     trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".final.bin"))
     sim = _sim(golden_dir, name)
