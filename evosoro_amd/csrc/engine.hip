@@ -422,12 +422,12 @@ void Engine::prepare()
             const size_t extra = M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) + (size_t)24 * M.nmv +
                                  ((fluid && block < 1024) ? (size_t)48 * block : 0);   // class tables, drag mesh, strain tile
             const int nacc = block < 1024 ? 2 : 1;    // accumulator tiles: a function of the robot's size only
-            if ((size_t)(8 + 6 * nacc) * block * 8 + extra > lds_max) { D.fused_ok = false; continue; }
+            if ((size_t)(8 + 6 * nacc + 2) * block * 8 + extra > lds_max) { D.fused_ok = false; continue; }
             Device::Group* g = nullptr;
             for (auto& q : D.groups) if (q.block == block && q.nacc == nacc && q.fluid == fluid) g = &q;
             if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nacc = nacc; g->fluid = fluid; }
             g->robots.push_back(r);
-            g->lds = std::max(g->lds, (size_t)(8 + 6 * nacc) * block * 8 + extra);
+            g->lds = std::max(g->lds, (size_t)(8 + 6 * nacc + 2) * block * 8 + extra);
         }
         size_t gi = 0;
         for (auto& g : D.groups) {

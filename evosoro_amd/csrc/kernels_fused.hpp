@@ -16,6 +16,8 @@
 //                          tile, the two ends of a round are added in two barrier-separated sub-steps, which gives
 //                          the reference's summation order +X -X +Y -Y +Z -Z.
 //                          Also scratch of latch / broad-phase between steps (re-zeroed by the voxel phase).
+//   pht  [2][BLOCK]        sin / cos of 2 pi' * PhaseOffset of every voxel (constants of the launch; kept out of registers
+//                          and out of the step's load queue)
 //   tabs                   this robot's DBondClass and DVoxClass rows
 //   st   [6][BLOCK]        FLUID, BLOCK < 1024: directional strains of the previous step (DBatch::strain otherwise)
 //   mesh [3][nmv]          FLUID only: vertices of the drag mesh
@@ -88,24 +90,32 @@ __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, 
         const double H = R.col_horizon;
         int cnt = 0;
         unsigned long long word = 0;
-        for (int j = 0; j < ns; ++j) {
-            if ((j & 63) == 0) word = row[j >> 6];
-            if (j == i) continue;
-            const int other = shi[j], lj = other & 1023;
-            const d3 d = pi - mk3(ps[lj], ps[BLOCK + lj], ps[2 * BLOCK + lj]);
-            const double d2 = len2(d);
-            if (!(d2 < R.filter_dist2)) continue;
-            if ((word >> (j & 63)) & 1ull) continue;          // !pV1->IsNearbyVox(SIndex2)
-            const double s1 = (j > i) ? si : ps[3 * BLOCK + lj];   // scale of Vox1 = the earlier one, used twice (:2382)
-            const double act = H * (s1 + s1) * 0.5;
-            if (d2 < act * act) {
-                if (cnt < VXH_MAXCOL) {
-                    const DVoxClass& Cj = vct[other >> 10];
-                    const size_t at = (size_t)cnt * B.col_rows + (R.surf_begin + i);
-                    B.col_partner[at] = R.vox_begin + lj;
-                    B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
+        for (int j0 = 0; j0 < ns; j0 += 8) {       // eight candidates at a time: their LDS reads are issued together
+            if ((j0 & 63) == 0) word = row[j0 >> 6];
+            int other[8]; double qx[8], qy[8], qz[8], qs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) other[u] = shi[min(j0 + u, ns - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int lj = other[u] & 1023; qx[u] = ps[lj]; qy[u] = ps[BLOCK + lj]; qz[u] = ps[2 * BLOCK + lj]; qs[u] = ps[3 * BLOCK + lj]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j >= ns || j == i) continue;
+                const d3 d = pi - mk3(qx[u], qy[u], qz[u]);
+                const double d2 = len2(d);
+                if (!(d2 < R.filter_dist2)) continue;
+                if ((word >> (j & 63)) & 1ull) continue;          // !pV1->IsNearbyVox(SIndex2)
+                const double s1 = (j > i) ? si : qs[u];           // scale of Vox1 = the earlier one, used twice (:2382)
+                const double act = H * (s1 + s1) * 0.5;
+                if (d2 < act * act) {
+                    if (cnt < VXH_MAXCOL) {
+                        const DVoxClass& Cj = vct[other[u] >> 10];
+                        const size_t at = (size_t)cnt * B.col_rows + (R.surf_begin + i);
+                        B.col_partner[at] = R.vox_begin + (other[u] & 1023);
+                        B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
+                    }
+                    ++cnt;
                 }
-                ++cnt;
             }
         }
         if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
@@ -283,7 +293,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     extern __shared__ __align__(16) double lds[];
     double* const ps = lds;
     double* const acc = lds + 8 * BLOCK;
-    double* const tabs = acc + NACC * 6 * BLOCK;
+    double* const pht = acc + NACC * 6 * BLOCK;    // sin / cos of every voxel's actuation phase, [2][BLOCK]
+    double* const tabs = pht + 2 * BLOCK;
     // the robot's mutable control block lives in LDS for the whole launch: the per-step control is a serial chain
     // of ~20 dependent accesses executed by one thread while the workgroup waits, so it must not touch HBM
     __shared__ DRobotState rs;
@@ -335,6 +346,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         const int b0 = rs.steps & 1;
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
         amp_damp = B.amp_damp[v];
+        pht[tid] = B.act_sb[v]; pht[BLOCK + tid] = B.act_cb[v];
         lm = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v));
         am = mk3(ANGMOM(0, v), ANGMOM(1, v), ANGMOM(2, v));
         ps[tid] = POS(b0, 0, v); ps[BLOCK + tid] = POS(b0, 1, v); ps[2 * BLOCK + tid] = POS(b0, 2, v); ps[3 * BLOCK + tid] = SCALE(b0, v);
@@ -343,6 +355,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #pragma unroll
     for (int k = 0; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;
     const FetchLds<BLOCK> fetch{ps, base};
+    int ccnt = 0;                             // number of collision partners of my voxel (refreshed after a broad-phase run)
 
     // the control thread sits in the LAST wave: the one with the fewest (often no) voxels, so its serial work hides
     // behind the other waves' voxel phase
@@ -358,14 +371,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // loop-invariant 64-bit pointers, which it then spills)
         int vv = v, rowv = row;
         asm volatile("" : "+v"(vv), "+v"(rowv));
-        const unsigned vo = (unsigned)vv * 8u;
         bool scratch_used = false;            // latch / broad-phase borrow the accumulator tile
         if (K.latch || K.eol) { fused_latch_cm<BLOCK>(R, rs, ps, acc, valid, C, K.latch != 0, K.eol != 0); scratch_used = true; }
         if (K.rebuild) { fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct); scratch_used = true; }
         if (scratch_used) { acc[tid] = 0.0; __syncthreads(); }
-        const int ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;   // issued early, consumed in the voxel phase
-        double ph_sin = 0, ph_cos = 0;
-        if (valid) { ph_sin = ld_plane(B.act_sb, 0, nv, vo); ph_cos = ld_plane(B.act_cb, 0, nv, vo); }
+        // the partner count only changes when the broad-phase ran; no global load sits at the head of the step's queue
+        if (K.rebuild || it == 0) ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;
         d3 drag = mk3(0, 0, 0);
         if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, st, st_stride, mesh, valid, vv, lm, C.mass_inv);
         const double inv_dt_prev = K.inv_dt_prev;
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             S.lm = lm; S.am = am;
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, ph_sin, ph_cos, amp_damp);
+            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, pht[tid], pht[BLOCK + tid], amp_damp);
             lm = S.lm; am = S.am;
         }
         if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
