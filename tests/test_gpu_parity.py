@@ -389,3 +389,35 @@ def test_bench_size_robots_whole_evaluation(eng_mod, golden_dir):
             for tag, val in (("NormFinalDist", res.norm_final_dist), ("finalDistY", res.final_dist_y)):
                 assert abs(val - want[tag]) <= 2 * tol + 1e-5 * abs(want[tag]), (name, tag, val, want[tag])
             print(name, "tolerance (voxel)", tol, "CoM error (voxel)", np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / lat)
+
+
+def test_free_floating_population_conserves_momentum(eng_mod, tmp_path):
+    """Size-independent property at BASELINE configs[2] size (512 robots of 10x10x10): without gravity, floor and the
+    velocity-proportional "slow" damping (whose coefficient depends on the material) the only forces are internal
+    (bonds, self-collision, actuation), so the total linear momentum of every robot stays at its initial value, zero.
+    All voxels have the same mass (one density in the evosoro palette), so sum(velocity) is the momentum up to a
+    factor.  Checked against the scale of the individual voxel velocities after the actuation has run for a while."""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.06, fitness_eval_init_time=0.01)
+    env = Env(gravity_enabled=0, floor_enabled=0)
+    paths = []
+    for i in range(512):
+        write_voxelyze_file(sim, env, workloads.random_robot(i, (10, 10, 10), i), str(tmp_path), "f")
+        path = str(tmp_path / "voxelyzeFiles" / ("f--id_%05i.vxa" % i))
+        text = open(path).read()
+        assert "<SlowDampingZ>0.01</SlowDampingZ>" in text       # hard-wired in the writer, like in the reference
+        open(path, "w").write(text.replace("<SlowDampingZ>0.01</SlowDampingZ>", "<SlowDampingZ>0</SlowDampingZ>"))
+        paths.append(path)
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.add_vxa_files(paths)
+        eng.step(600)
+        worst = 0.0
+        for i in range(0, 512, 7):
+            vel = eng.state(i)[:, 8:11]
+            speed = np.abs(vel).max()
+            assert speed > 1e-4                       # the robots do move (actuation started at t = 0.01 s)
+            worst = max(worst, np.abs(vel.sum(axis=0)).max() / (speed * len(vel)))
+        assert worst < 1e-9, worst
