@@ -48,7 +48,7 @@ enum { VXH_MAXCOL = 64 };     // collision partners kept per surface voxel (over
 // all device pointers of a batch; passed to kernels by value
 struct DBatch {
     int n_robots, nv;                 // nv = total padded voxel slots (multiple of 64 per robot)
-    int dbg, pad1;                    // developer switches (scripts/gpu_diag.py), 0 in production
+    int dbg, pad1;                    // developer switches (tests/dev_gpu_diag.py), 0 in production
     const DRobot* robot;
     DRobotState* rstate;
     const int* wave_robot;            // [nv/64] robot of each 64-voxel group

@@ -27,7 +27,7 @@ namespace vxh {
 
 enum { VXH_FUSED_STATIC_LDS = 320 };
 
-// developer instrumentation (scripts/gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
+// developer instrumentation (tests/dev_gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
 // of the phases of a step
 #ifdef VXH_PHASE_TIMING
 #define VXH_T_DECL unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_readcyclecounter();

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer diagnostic (GPU box): per-step error of the HIP engine against the CPU oracle on the golden robots,
-then a timing of a synthetic batch.  Not part of the product or of the test-suite."""
+"""Developer diagnostics for the GPU box (not collected by pytest, not part of the product): per-step error of the HIP
+engine against the CPU oracle on the golden robots, timings of synthetic batches, per-phase cycle shares (library
+built by `make -C evosoro_amd/csrc prof`), whole-generation wall clock.  Lives under tests/ because it uses oracle/."""
 import os
 import sys
 import time
