@@ -335,8 +335,9 @@ void Engine::prepare()
         R.stop_type = X.stop_type; R.excl_wpr = wpr; R.excl_begin = excl_begin;
         R.vert_begin = mv_begin[r]; R.nmv = M.nmv;
         R.vtab_begin = vtab_begin; R.n_vclass = (int)M.vox_classes.size(); R.btab_begin = btab_begin; R.n_bclass = (int)M.bond_classes.size();
+        if (X.fluid_env && variant_ == 1 && (M.nvox > 1024 || !fused_))
+            throw std::invalid_argument("unsupported: fluid drag needs the fused path (robots of at most 1024 voxels)");
         if (M.nmv > 0) {
-            if (M.nvox > 1024 || !fused_) throw std::invalid_argument("unsupported: fluid drag needs the fused path (robots of at most 1024 voxels)");
             const size_t tm = (size_t)std::max(total_mv, 1);
             for (int i = 0; i < M.nmv; ++i) {
                 for (int q = 0; q < 8; ++q) {
@@ -641,6 +642,23 @@ void Engine::download()
             for (int k = 0; k < 4; ++k) H.quat[4 * v + k] = plane(8 + k)[base + v];
             H.scale[v] = plane(4 * b + 3)[base + v];
         }
+    }
+    // land_water robots stepped by the fused kernel: directional strains of the last step (RobotVolumeEnd)
+    bool any_mesh = false;
+    for (int r = 0; r < nr; ++r) any_mesh = any_mesh || robots_[r].nmv > 0;
+    if (any_mesh && fused_ && D.fused_ok) {
+        std::vector<double> st((size_t)6 * nv);
+        HIP_OK(hipMemcpy(st.data(), B.strain, sizeof(double) * st.size(), hipMemcpyDeviceToHost));
+        for (int r = 0; r < nr; ++r) {
+            const RobotModel& M = robots_[r];
+            if (M.nmv == 0) continue;
+            HostState& H = host_[r];
+            H.strain.resize((size_t)6 * M.nvox);
+            for (int v = 0; v < M.nvox; ++v)
+                for (int k = 0; k < 6; ++k) H.strain[(size_t)6 * v + k] = st[(size_t)k * nv + D.vox_begin[r] + v];
+        }
+    } else {
+        for (int r = 0; r < nr; ++r) host_[r].strain.clear();
     }
     state_downloaded_ = true;
 }

@@ -11,6 +11,7 @@ namespace vxh {
 
 struct HostState {                      // final/current state of one robot, downloaded from the device
     std::vector<double> pos, quat, scale, lin_mom, ang_mom;   // pos [3*n] xyz-interleaved, quat [4*n] wxyz
+    std::vector<double> strain;                                // land_water: [6*n] StrainPosDirsCur xyz, StrainNegDirsCur xyz of the last step
     double cur_time = 0, ini_cm[3] = {0, 0, 0}, eol_post_y = 0;
     int steps = 0, status = 0, cm_init = 0, rebuilds = 0;
 };

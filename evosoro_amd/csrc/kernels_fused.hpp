@@ -1,4 +1,5 @@
-// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NACC, FLUID>, one workgroup per robot, the robot
+// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NACC, MESH> (MESH: land_water robots, which carry
+// the deformable surface mesh),, one workgroup per robot, the robot
 // resident in the CU for a whole launch of many time steps (included at the end of kernels.hpp).
 //
 // A step has two kinds of work items mapped onto the same threads:
@@ -19,8 +20,8 @@
 //   pht  [2][BLOCK]        sin / cos of 2 pi' * PhaseOffset of every voxel (constants of the launch; kept out of registers
 //                          and out of the step's load queue)
 //   tabs                   this robot's DBondClass and DVoxClass rows
-//   st   [6][BLOCK]        FLUID, BLOCK < 1024: directional strains of the previous step (DBatch::strain otherwise)
-//   mesh [3][nmv]          FLUID only: vertices of the drag mesh
+//   st   [6][BLOCK]        MESH, BLOCK < 1024: directional strains of the previous step (DBatch::strain otherwise)
+//   mesh [3][nmv]          MESH only: vertices of the drag mesh (robots in a fluid)
 #pragma once
 
 namespace vxh {
@@ -211,7 +212,7 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
 
 // Bond t of axis A (packed entry of DBatch::blist: negative-end voxel | positive-end voxel << 10 | class << 20):
 // both poses from the pose tile, history from/to HBM.  Returns the outputs; the caller adds them to the accumulators.
-template <int A, int BLOCK, bool FLUID>
+template <int A, int BLOCK, bool MESH>
 __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, int entry,
                                               unsigned& modebits, double inv_dt_prev, double* st, unsigned st_stride)
 {
@@ -237,7 +238,7 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
         st_plane(B.hist, 3 * 3 + A, nv, voff, H.g0); st_plane(B.hist, 4 * 3 + A, nv, voff, H.g1); st_plane(B.hist, 5 * 3 + A, nv, voff, H.g2);
     }
     modebits = (modebits & ~(3u << (2 * A))) | (H.flags << (2 * A));
-    if constexpr (FLUID) {                    // SetStrainDir (VXS_BondInternal.cpp:300-304): +A side of voxel 1, -A side of voxel 2
+    if constexpr (MESH) {                     // SetStrainDir (VXS_BondInternal.cpp:300-304): +A side of voxel 1, -A side of voxel 2
         st[(unsigned)A * st_stride + l1] = o.strain1;
         st[(unsigned)(3 + A) * st_stride + l2] = o.strain2;
     }
@@ -253,14 +254,14 @@ __device__ __forceinline__ void fused_accumulate(double* acc, int l, d3 f, d3 m)
 }
 
 // one axis round: bond, then both ends into the accumulators
-template <int A, int BLOCK, int NACC, bool FLUID>
+template <int A, int BLOCK, int NACC, bool MESH>
 __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, double* acc, int entry,
                                             unsigned& modebits, double inv_dt_prev, bool& div, double* st, unsigned st_stride)
 {
     const bool has = entry >= 0;
     BondOut o;
     if (has) {
-        o = fused_bond<A, BLOCK, FLUID>(B, R, bct, ps, entry, modebits, inv_dt_prev, st, st_stride);
+        o = fused_bond<A, BLOCK, MESH>(B, R, bct, ps, entry, modebits, inv_dt_prev, st, st_stride);
         div = div || o.diverged;
         fused_accumulate<BLOCK>(acc, entry & 1023, o.f1, o.m1);
     }
@@ -286,7 +287,7 @@ __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotSta
     K.rebuild = c.rebuild;
 }
 
-template <int BLOCK, int NACC, bool FLUID>
+template <int BLOCK, int NACC, bool MESH>
 __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const DRobot* __restrict__ robots,
                                                                             const int* __restrict__ robot_list, long long step_cap, int iters)
 {
@@ -318,9 +319,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     for (int k = tid; k < nvd; k += BLOCK) tabs[nbd + k] = ((const double*)(B.vclass_tab + R.vtab_begin))[k];
     const DBondClass* const bct = (const DBondClass*)tabs;
     const DVoxClass* const vct = (const DVoxClass*)(tabs + nbd);
-    // FLUID: directional strains of the previous step (inputs of the drag mesh) in LDS next to the tables, then the mesh
-    // vertices; the 1024-thread variant has no room for the strains and keeps them in HBM
-    constexpr bool STRAIN_LDS = FLUID && BLOCK < 1024;
+    // MESH (land_water robots): directional strains of the previous step (inputs of the surface mesh: fluid drag, and the
+    // RobotVolumeEnd tag on the host) in LDS next to the tables, then the mesh vertices; the 1024-thread variant has no
+    // room for the strains and keeps them in HBM
+    constexpr bool STRAIN_LDS = MESH && BLOCK < 1024;
     double* const st = STRAIN_LDS ? tabs + nbd + nvd : B.strain + R.vox_begin;
     const unsigned st_stride = STRAIN_LDS ? (unsigned)BLOCK : nv;
     double* const mesh = tabs + nbd + nvd + (STRAIN_LDS ? 6 * BLOCK : 0);
@@ -378,17 +380,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // the partner count only changes when the broad-phase ran; no global load sits at the head of the step's queue
         if (K.rebuild || it == 0) ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;
         d3 drag = mk3(0, 0, 0);
-        if constexpr (FLUID) drag = fused_drag<BLOCK>(B, R, ps, st, st_stride, mesh, valid, vv, lm, C.mass_inv);
+        const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
+        if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK>(B, R, ps, st, st_stride, mesh, valid, vv, lm, C.mass_inv); }
         const double inv_dt_prev = K.inv_dt_prev;
         VXH_T_MARK(1)
 
         // ---- bond phase: three axis rounds over the compacted bond lists
         bool div = false;
-        fused_round<0, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[0], modebits, inv_dt_prev, div, st, st_stride);
+        fused_round<0, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[0], modebits, inv_dt_prev, div, st, st_stride);
         __syncthreads();
-        fused_round<1, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[1], modebits, inv_dt_prev, div, st, st_stride);
+        fused_round<1, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[1], modebits, inv_dt_prev, div, st, st_stride);
         __syncthreads();
-        fused_round<2, BLOCK, NACC, FLUID>(B, R, bct, ps, acc, entry[2], modebits, inv_dt_prev, div, st, st_stride);
+        fused_round<2, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[2], modebits, inv_dt_prev, div, st, st_stride);
         if (div) s_div = 1;
         VXH_T_MARK(2)
         __syncthreads();                       // (B)
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             S.lm = lm; S.am = am;
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, FLUID, drag, pht[tid], pht[BLOCK + tid], amp_damp);
+            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, fluid, drag, pht[tid], pht[BLOCK + tid], amp_damp);
             lm = S.lm; am = S.am;
         }
         if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path

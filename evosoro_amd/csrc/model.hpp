@@ -49,7 +49,7 @@ struct RobotModel {
     // collisions
     std::vector<int> surf;                  // surface voxels, ascending
     std::vector<int> near_off, near_idx;    // CSR over ALL voxels: sorted voxel indices within N hops (self included)
-    // land_water fluid drag mesh (LW/VX_MeshUtil.cpp LinkSimVoxels :110-276): deformable surface vertices = lattice
+    // land_water surface mesh (LW/VX_MeshUtil.cpp LinkSimVoxels :110-276; fluid drag and the RobotVolume tags): vertices = lattice
     // corners touched by 1..7 voxels; every exposed voxel face carries two triangles owned by that voxel
     int nmv = 0;
     std::vector<int> vert_comp;             // [nmv*8] voxel*8 + corner code (NNN..PPP = 0..7) or -1, in voxel order

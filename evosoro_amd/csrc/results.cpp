@@ -4,12 +4,69 @@
 // (VX_Sim.cpp:2415-2441,2584-2712).  Numbers are printed like `ostream << double` (6 significant digits,
 // Utils/XML_Rip.h:57) in TinyXML's layout (4 blanks per level).
 #include <cmath>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 
 #include "engine.hpp"
 
 namespace vxh {
+
+namespace {
+
+// CVX_MeshUtil::computeCurrentRobotVolume (LW/VX_MeshUtil.cpp:908-952): signed tetrahedra over the facets of the
+// deformable surface mesh; vertices as updateDeformableMesh / GetCurVLoc (:368-428) places them: mean over the voxels
+// touching the lattice corner of Pos + R(Angle) * corner, corner = +-(1 + strain) * L / 2.  `pos` etc. may be null:
+// the rest state (RobotVolumeStart is taken right after Import, voxelyzeMain/main.cpp:65).
+double robot_volume(const RobotModel& M, const double* pos, const double* quat, const double* strain)
+{
+    if (M.nmv == 0) return 0.0;
+    const double nom = M.vxa.lattice_dim;
+    std::vector<double> vert((size_t)M.nmv * 3);
+    for (int i = 0; i < M.nmv; ++i) {
+        double ax = 0, ay = 0, az = 0, tw = 0;
+        for (int q = 0; q < 8; ++q) {
+            const int comp = M.vert_comp[(size_t)i * 8 + q];
+            if (comp < 0) break;
+            const int u = comp >> 3, corner = comp & 7;
+            double st[6] = {0, 0, 0, 0, 0, 0};
+            if (strain) for (int k = 0; k < 6; ++k) st[k] = strain[(size_t)6 * u + k];
+            const double ox = (corner & 4) ? (1 + st[0]) * nom * 0.5 : -(1 + st[3]) * nom * 0.5;
+            const double oy = (corner & 2) ? (1 + st[1]) * nom * 0.5 : -(1 + st[4]) * nom * 0.5;
+            const double oz = (corner & 1) ? (1 + st[2]) * nom * 0.5 : -(1 + st[5]) * nom * 0.5;
+            double px = M.nom_pos[3 * u], py = M.nom_pos[3 * u + 1], pz = M.nom_pos[3 * u + 2];
+            double qw = 1, qx = 0, qy = 0, qz = 0;
+            if (pos) { px = pos[3 * u]; py = pos[3 * u + 1]; pz = pos[3 * u + 2]; qw = quat[4 * u]; qx = quat[4 * u + 1]; qy = quat[4 * u + 2]; qz = quat[4 * u + 3]; }
+            // CQuat::RotateVec3D, Vec3D.h:293-299
+            const double tw_ = ox * qx + oy * qy + oz * qz, tx = ox * qw - oy * qz + oz * qy, ty = ox * qz + oy * qw - oz * qx, tz = -ox * qy + oy * qx + oz * qw;
+            ax += px + (qw * tx + qx * tw_ + qy * tz - qz * ty);
+            ay += py + (qw * ty - qx * tz + qy * tw_ + qz * tx);
+            az += pz + (qw * tz + qx * ty - qy * tx + qz * tw_);
+            tw += 1.0;
+        }
+        const double inv = 1.0 / tw;
+        const double v0x = M.vert_v0[(size_t)3 * i], v0y = M.vert_v0[(size_t)3 * i + 1], v0z = M.vert_v0[(size_t)3 * i + 2];
+        vert[(size_t)3 * i] = v0x + (ax * inv - v0x); vert[(size_t)3 * i + 1] = v0y + (ay * inv - v0y); vert[(size_t)3 * i + 2] = v0z + (az * inv - v0z);
+    }
+    // corner codes (NNN..PPP) of the two triangles of faces +X,-X,+Y,-Y,+Z,-Z (LW/VX_MeshUtil.cpp:165-189)
+    static const unsigned tri[6][2] = {{0x467u, 0x475u}, {0x032u, 0x013u}, {0x237u, 0x276u}, {0x051u, 0x045u}, {0x157u, 0x173u}, {0x064u, 0x026u}};
+    double volume = 0.0;
+    for (int v = 0; v < M.nvox; ++v)
+        for (int d = 0; d < 6; ++d) {
+            if (!(M.open_face[v] & (1u << d))) continue;
+            for (int t = 0; t < 2; ++t) {
+                const unsigned code = tri[d][t];
+                const double* a = &vert[(size_t)3 * M.corner_vert[(size_t)v * 8 + ((code >> 8) & 7u)]];
+                const double* b = &vert[(size_t)3 * M.corner_vert[(size_t)v * 8 + ((code >> 4) & 7u)]];
+                const double* c = &vert[(size_t)3 * M.corner_vert[(size_t)v * 8 + (code & 7u)]];
+                const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+                volume += (1.0 / 6.0) * (cx * c[0] + cy * c[1] + cz * c[2]);
+            }
+        }
+    return volume;
+}
+
+}  // namespace
 
 void compute_result(const RobotModel& M, const HostState& S, vxh_result* r)
 {
@@ -58,6 +115,10 @@ void compute_result(const RobotModel& M, const HostState& S, vxh_result* r)
         const double dx = inv * (cm[0] - S.ini_cm[0]), dy = inv * (cm[1] - S.ini_cm[1]), dz = inv * (cm[2] - S.ini_cm[2]);
         r->norm_dist_x = (float)dx; r->norm_dist_y = (float)dy; r->norm_dist_z = (float)dz;   // float-typed in the reference
         r->norm_abs_disp = (float)std::sqrt(dx * dx + dy * dy + dz * dz);
+        r->robot_volume_start = robot_volume(M, nullptr, nullptr, nullptr);
+        if (S.steps == 0) r->robot_volume_end = r->robot_volume_start;
+        else r->robot_volume_end = ((int)S.strain.size() == 6 * M.nvox) ? robot_volume(M, S.pos.data(), S.quat.data(), S.strain.data())
+                                                                          : -1.0;   // streaming path: strains are not recorded
     }
 }
 
@@ -96,11 +157,11 @@ std::string result_xml(const RobotModel& M, const vxh_result& r)
         tag(out, "normDistX", r.norm_dist_x);
         tag(out, "normDistY", r.norm_dist_y);
         tag(out, "normDistZ", r.norm_dist_z);
-        // shape descriptors (mesh volume / qhull) are outside the hot path: the reference prints -1 for the hull
-        // values when qhull is unavailable; volumes are not computed here either
-        tag(out, "RobotVolumeStart", -1);
+        // the hull volumes need qhull (--computeShapeDescriptors) and the shape complexity an external Python 2 script:
+        // the reference prints -1 for the hull without the flag; -1 here for all four
+        tag(out, "RobotVolumeStart", r.robot_volume_start);
         tag(out, "ConvexHullVolumeStart", -1);
-        tag(out, "RobotVolumeEnd", -1);
+        tag(out, "RobotVolumeEnd", r.robot_volume_end);
         tag(out, "ConvexHullVolumeEnd", -1);
         tag(out, "ShapeComplexityStart", -1);
         tag(out, "ShapeComplexityEnd", -1);

@@ -34,6 +34,7 @@ class VxhResult(ctypes.Structure):
                 ("fall_adj_post_y", ctypes.c_double), ("num_non_feet_touching_floor", ctypes.c_double),
                 ("num_touching_floor", ctypes.c_double), ("norm_abs_disp", ctypes.c_double),
                 ("norm_dist_x", ctypes.c_double), ("norm_dist_y", ctypes.c_double), ("norm_dist_z", ctypes.c_double),
+                ("robot_volume_start", ctypes.c_double), ("robot_volume_end", ctypes.c_double),
                 ("col_rebuilds", ctypes.c_int), ("reserved", ctypes.c_int)]
 
     def as_dict(self):

@@ -14,7 +14,8 @@ RECORD_FIELDS = ["status", "steps", "nvox", "nbond", "dt", "cur_time", "lifetime
                  "norm_final_dist", "norm_regime_dist", "norm_frozen_dist", "final_dist", "final_dist_y",
                  "anterior_dist", "posterior_dist", "anterior_y", "posterior_y", "end_of_life_posterior_y",
                  "fall_adj_post_y", "num_non_feet_touching_floor", "num_touching_floor",
-                 "norm_abs_disp", "norm_dist_x", "norm_dist_y", "norm_dist_z", "col_rebuilds"]
+                 "norm_abs_disp", "norm_dist_x", "norm_dist_y", "norm_dist_z", "robot_volume_start", "robot_volume_end",
+                 "col_rebuilds"]
 RECORD_LEN = len(RECORD_FIELDS)
 
 

@@ -63,6 +63,8 @@ typedef struct vxh_result {
     double num_non_feet_touching_floor, num_touching_floor;
     /* _voxcad_land_water tags, LW/VX_SimGA.cpp:58-62 */
     double norm_abs_disp, norm_dist_x, norm_dist_y, norm_dist_z;
+    double robot_volume_start, robot_volume_end;   /* <RobotVolumeStart/End>, LW/VX_MeshUtil.cpp:908-952 (the hull and
+                                                      shape-complexity tags are printed as -1) */
     int col_rebuilds;      /* diagnostic: how often CalcL1Bonds ran (VX/VX_Sim.cpp:1741-1747) */
     int reserved;
 } vxh_result;

@@ -248,6 +248,9 @@ def test_land_water_variant(eng_mod, golden_dir):
             assert np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / models[i]["lattice_dim"] <= tol, name
             for tag, val in (("normAbsoluteDisplacement", res.norm_abs_disp), ("normDistZ", res.norm_dist_z)):
                 assert abs(val - want[tag]) <= 2 * tol + 1e-5 * abs(want[tag]), (name, tag, val, want[tag])
+            # mesh-volume tags (LW/VX_MeshUtil.cpp:908-952): rest volume exactly, deformed volume to the printed digits
+            assert "%.6g" % res.robot_volume_start == "%.6g" % want["RobotVolumeStart"], name
+            assert abs(res.robot_volume_end - want["RobotVolumeEnd"]) <= 2e-5 * want["RobotVolumeEnd"] + 10 * tol * 1e-6, (name, res.robot_volume_end)
 
 
 def _write_robot(tmp_path, ident, material, sim, env, name):
