@@ -1,6 +1,6 @@
-// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NACC, MESH> (MESH: land_water robots, which carry
-// the deformable surface mesh),, one workgroup per robot, the robot
-// resident in the CU for a whole launch of many time steps (included at the end of kernels.hpp).
+// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NACC, MESH>, one workgroup per robot, the robot
+// resident in the CU for a whole launch of many time steps (included at the end of kernels.hpp).  MESH = land_water
+// robots, which carry the deformable surface mesh (fluid drag, RobotVolume tags).
 //
 // A step has two kinds of work items mapped onto the same threads:
 //   voxels  thread t owns voxel t: its momenta stay in registers for the whole launch, its pose is published in LDS;
@@ -26,7 +26,7 @@
 
 namespace vxh {
 
-enum { VXH_FUSED_STATIC_LDS = 320 };
+enum { VXH_FUSED_STATIC_LDS = 320 };      // upper bound of the kernel's static __shared__ variables
 
 // developer instrumentation (tests/dev_gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
 // of the phases of a step
@@ -38,7 +38,7 @@ enum { VXH_FUSED_STATIC_LDS = 320 };
 #define VXH_T_DECL
 #define VXH_T_MARK(k)
 #define VXH_T_FLUSH
-#endif      // upper bound of the kernel's static __shared__ variables
+#endif
 
 // plane `plane` (of nv doubles) of a SoA array, element at byte offset voff: uniform 64-bit base + 32-bit lane offset
 __device__ __forceinline__ double ld_plane(const double* base, unsigned plane, unsigned nv, unsigned voff)
