@@ -12,7 +12,7 @@ struct DVoxClass {
 struct DBondClass {
     double L, a1, a2, b1, b2, b3;
     double sq_a1m1, sq_a1m2, sq_a2i1, sq_a2i2, sq_b1m1, sq_b1m2, sq_b2fm1, sq_b2fm2, sq_b3i1, sq_b3i2;
-    double stress_E1, stress_E2, area_sum;
+    double stress_k, strain_a1, strain_a2, area_sum;   // CurStress = stress_k * strain, CurStrainV1/V2 = strain_a1/a2 * strain
     int homogeneous, pad;
 };
 

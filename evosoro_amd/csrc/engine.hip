@@ -277,7 +277,7 @@ void Engine::prepare()
             d.sq_a1m1 = c.sq_a1m1; d.sq_a1m2 = c.sq_a1m2; d.sq_a2i1 = c.sq_a2i1; d.sq_a2i2 = c.sq_a2i2;
             d.sq_b1m1 = c.sq_b1m1; d.sq_b1m2 = c.sq_b1m2; d.sq_b2fm1 = c.sq_b2fm1; d.sq_b2fm2 = c.sq_b2fm2;
             d.sq_b3i1 = c.sq_b3i1; d.sq_b3i2 = c.sq_b3i2;
-            d.stress_E1 = c.stress_E1; d.stress_E2 = c.stress_E2; d.area_sum = c.area_sum; d.homogeneous = c.homogeneous;
+            d.stress_k = c.stress_k; d.strain_a1 = c.strain_a1; d.strain_a2 = c.strain_a2; d.area_sum = c.area_sum; d.homogeneous = c.homogeneous;
             btab.push_back(d);
         }
         if (M.vox_classes.size() > 32767 || M.bond_classes.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one robot");

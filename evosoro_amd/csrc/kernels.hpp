@@ -260,24 +260,12 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     }
     const d3 ang2 = to_rotvec(qb2, B.slthresh_acos2sqrt);   // one instance for both modes: a mixed wave runs it once
 
-    // axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307; linear materials)
+    // axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307; linear materials): the reference's series-spring
+    // iteration is linear in the strain, its three factors are constants of the bond class (model.cpp make_bond_class)
     const double strain = vdiv(pos2.x, C.L);
-    double stress;
-    o.strain1 = o.strain2 = strain;            // CurStrainV1 / CurStrainV2 (SetStrainDir), read by the land_water drag mesh
-    if (C.homogeneous) stress = C.stress_E1 * strain;
-    else {
-        double e1 = strain, e2 = strain, t1 = C.stress_E1 * e1, t2 = C.stress_E2 * e2;
-        double diff = fabs(t1 - t2), sum = fabs(t1 + t2);
-        for (int it = 0; it < 3 && diff > sum * .0005; ++it) {
-            const double rs12 = vrcp(t1 + t2);      // one reciprocal for both quotients of the reference (<= 1 ulp apart)
-            e1 = ((2 * t2) * rs12) * e1;
-            e2 = ((2 * t1) * rs12) * e2;
-            t1 = C.stress_E1 * e1; t2 = C.stress_E2 * e2;
-            diff = fabs(t1 - t2); sum = fabs(t1 + t2);
-        }
-        stress = (t1 + t2) / 2;
-        o.strain1 = e1; o.strain2 = e2;
-    }
+    const double stress = C.stress_k * strain;
+    o.strain1 = C.strain_a1 * strain;          // CurStrainV1 / CurStrainV2 (SetStrainDir), read by the land_water surface mesh
+    o.strain2 = C.strain_a2 * strain;
     o.diverged = strain > 100;                 // VX_Sim.cpp:1775
 
     // beam equations (VXS_BondInternal.cpp:128-153)

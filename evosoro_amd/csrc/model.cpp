@@ -81,6 +81,23 @@ BondClass make_bond_class(const VxaModel& m, const VoxClass& c1, double E1, cons
     b.sq_b3i1 = 2.0 * std::sqrt(b.b3 * c1.inertia);       b.sq_b3i2 = 2.0 * std::sqrt(b.b3 * c2.inertia);
     b.stress_E1 = c1.stress_E;
     b.stress_E2 = c2.stress_E;
+    // Axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307, linear materials).  Same material: stress = E * strain.
+    // Otherwise the reference splits the strain between the two half-bonds with up to three fixed-point iterations
+    // (tolerance 5e-4).  Every iterate is proportional to the strain and the loop condition compares two quantities that
+    // are both proportional to |strain|, so the whole procedure is a multiplication by three constants of the bond class;
+    // they are obtained by running the reference's loop once, here, on a unit strain.
+    b.stress_k = b.stress_E1; b.strain_a1 = b.strain_a2 = 1.0;
+    if (!b.homogeneous) {
+        double e1 = 1.0, e2 = 1.0, t1 = b.stress_E1 * e1, t2 = b.stress_E2 * e2;
+        double diff = std::fabs(t1 - t2), sum = std::fabs(t1 + t2);
+        for (int it = 0; it < 3 && diff > sum * .0005; ++it) {
+            e1 = 2 * t2 / (t1 + t2) * e1;
+            e2 = 2 * t1 / (t1 + t2) * e2;
+            t1 = b.stress_E1 * e1; t2 = b.stress_E2 * e2;
+            diff = std::fabs(t1 - t2); sum = std::fabs(t1 + t2);
+        }
+        b.stress_k = (t1 + t2) / 2; b.strain_a1 = e1; b.strain_a2 = e2;
+    }
     b.area_sum = Ly * Lz + Ly * Lz;   // CSArea1 + CSArea2 (VXS_Bond.cpp:75, VXS_Voxel.cpp:625-631)
     return b;
 }

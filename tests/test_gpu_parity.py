@@ -2,8 +2,8 @@
 the reference C++, tests/test_oracle_vs_reference.py) and against the reference's golden outputs.
 
 Stated FP tolerance.  Both sides compute in FP64; the engine differs from the reference by device-libm ulps, FMA
-contraction, the order of a few sums and three algebraic rewrites (half-angle form of FromAngleToPosX, angle-addition
-form of the actuation sine, one reciprocal for the two quotients of the stress split; DESIGN.md "Numerics"), i.e. by
+contraction, the order of a few sums and a few algebraic rewrites (half-angle form of FromAngleToPosX, angle-addition
+form of the actuation sine, the stress split folded into per-class constants; DESIGN.md "Numerics"), i.e. by
 perturbations of relative size 1e-16 .. 1e-12 per operation, the upper end where the reference's own acos is
 ill-conditioned to the same degree.  How far
 such perturbations grow is a property of the ROBOT, not of the implementation: most robots are well conditioned
