@@ -10,9 +10,13 @@ struct DVoxClass {
     int mat, pad;
 };
 struct DBondClass {
-    double L, a1, a2, b1, b2, b3;
-    double sq_a1m1, sq_a1m2, sq_a2i1, sq_a2i2, sq_b1m1, sq_b1m2, sq_b2fm1, sq_b2fm2, sq_b3i1, sq_b3i2;
-    double stress_k, strain_a1, strain_a2, area_sum;   // CurStress = stress_k * strain, CurStrainV1/V2 = strain_a1/a2 * strain
+    double L, a2, b1, b2, b3;
+    double kf;                    // axial force per unit strain: stress_k * (area1 + area2) / 2 (model.cpp make_bond_class)
+    double strain_a1, strain_a2;  // CurStrainV1/V2 = strain_a1/a2 * strain
+    // AddDampForces (VXS_BondInternal.cpp:310-346): the 2 sqrt(k m) terms of VX_Bond.h:65-71, already multiplied by the
+    // robot's BondDampingZ / 2 (moments: / 4) and by 1 / dt, so the kernel multiplies plain differences of the bond-frame
+    // pose: forces on voxel 1 / 2 (A linear-x, B linear-yz, F angular), moments on voxel 1 / 2 (T twist, G linear, H angular)
+    double dA1, dB1, dF1, dA2, dB2, dF2, dT1, dG1, dH1, dT2, dG2, dH2;
     int homogeneous, pad;
 };
 

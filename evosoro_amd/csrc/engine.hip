@@ -273,11 +273,14 @@ void Engine::prepare()
             const BondClass& c = M.bond_classes[i];
             DBondClass d;
             std::memset(&d, 0, sizeof(d));
-            d.L = c.L; d.a1 = c.a1; d.a2 = c.a2; d.b1 = c.b1; d.b2 = c.b2; d.b3 = c.b3;
-            d.sq_a1m1 = c.sq_a1m1; d.sq_a1m2 = c.sq_a1m2; d.sq_a2i1 = c.sq_a2i1; d.sq_a2i2 = c.sq_a2i2;
-            d.sq_b1m1 = c.sq_b1m1; d.sq_b1m2 = c.sq_b1m2; d.sq_b2fm1 = c.sq_b2fm1; d.sq_b2fm2 = c.sq_b2fm2;
-            d.sq_b3i1 = c.sq_b3i1; d.sq_b3i2 = c.sq_b3i2;
-            d.stress_k = c.stress_k; d.strain_a1 = c.strain_a1; d.strain_a2 = c.strain_a2; d.area_sum = c.area_sum; d.homogeneous = c.homogeneous;
+            const double zi = (0.5 * X.bond_damping_z) * (1.0 / M.dt), zh = 0.5 * zi;   // BondDampingZ/2 (moments: /4) over dt
+            d.L = c.L; d.a2 = c.a2; d.b1 = c.b1; d.b2 = c.b2; d.b3 = c.b3;
+            d.kf = c.stress_k * c.area_sum / 2; d.strain_a1 = c.strain_a1; d.strain_a2 = c.strain_a2;
+            d.dA1 = c.sq_a1m1 * zi; d.dB1 = c.sq_b1m1 * zi; d.dF1 = c.sq_b2fm1 * zi;
+            d.dA2 = c.sq_a1m2 * zi; d.dB2 = c.sq_b1m2 * zi; d.dF2 = c.sq_b2fm2 * zi;
+            d.dT1 = c.sq_a2i1 * zh; d.dG1 = c.sq_b2fm1 * zh; d.dH1 = c.sq_b3i1 * zh;
+            d.dT2 = c.sq_a2i2 * zh; d.dG2 = c.sq_b2fm2 * zh; d.dH2 = c.sq_b3i2 * zh;
+            d.homogeneous = c.homogeneous;
             btab.push_back(d);
         }
         if (M.vox_classes.size() > 32767 || M.bond_classes.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one robot");

@@ -215,11 +215,11 @@ __device__ __forceinline__ void store_bond_hist(const DBatch& B, int slot, const
 }
 
 // One internal bond along axis A between voxel 1 (negative side) and voxel 2: pure arithmetic, `H` in/out.
-// inv_dt_prev = 1/dt of the previous step, 0 on the first step (no damping then, VXS_BondInternal.cpp:311).
+// damp_on = a previous step exists (no damping on the first one, dt == 0 then: VXS_BondInternal.cpp:311).
 template <int A>
 __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClass& C, BondHist& H,
                                                 d3 p1, dq q1, double s1, d3 p2, dq q2, double s2,
-                                                double inv_dt_prev, double bond_z_half)
+                                                bool damp_on)
 {
     BondOut o;
     const double nom_dist = (s1 + s2) * 0.5;
@@ -263,13 +263,12 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     // axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307; linear materials): the reference's series-spring
     // iteration is linear in the strain, its three factors are constants of the bond class (model.cpp make_bond_class)
     const double strain = vdiv(pos2.x, C.L);
-    const double stress = C.stress_k * strain;
     o.strain1 = C.strain_a1 * strain;          // CurStrainV1 / CurStrainV2 (SetStrainDir), read by the land_water surface mesh
     o.strain2 = C.strain_a2 * strain;
     o.diverged = strain > 100;                 // VX_Sim.cpp:1775
 
     // beam equations (VXS_BondInternal.cpp:128-153)
-    d3 f1 = mk3(stress * C.area_sum / 2, C.b1 * pos2.y - C.b2 * (ang1.z + ang2.z), C.b1 * pos2.z + C.b2 * (ang1.y + ang2.y));
+    d3 f1 = mk3(C.kf * strain, C.b1 * pos2.y - C.b2 * (ang1.z + ang2.z), C.b1 * pos2.z + C.b2 * (ang1.y + ang2.y));
     d3 f2 = -f1;
     d3 m1 = mk3(C.a2 * (ang1.x - ang2.x), C.b2 * pos2.z + C.b3 * (2 * ang1.y + ang2.y), -C.b2 * pos2.y + C.b3 * (2 * ang1.z + ang2.z));
     d3 m2 = mk3(C.a2 * (ang2.x - ang1.x), C.b2 * pos2.z + C.b3 * (ang1.y + 2 * ang2.y), -C.b2 * pos2.y + C.b3 * (ang1.z + 2 * ang2.z));
@@ -277,19 +276,18 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     // velocity damping from the finite-differenced bond-frame pose (AddDampForces :310-346); skipped on the step the
     // mode flips, and the history is only refreshed when it runs
     if (!changed) {
-        if (inv_dt_prev != 0) {
+        if (damp_on) {
             const bool hl = (H.flags & 2u) != 0;        // expand the stored history (see DBatch::hist)
             const d3 hpos2 = mk3(H.p0, hl ? 0.0 : H.p1, hl ? 0.0 : H.p2);
             const d3 hang1 = mk3(0.0, hl ? H.p1 : 0.0, hl ? H.p2 : 0.0);
             const d3 hang2 = mk3(H.g0, H.g1, H.g2);
-            const double inv = inv_dt_prev;
-            d3 v = (pos2 - hpos2) * inv, w1 = (ang1 - hang1) * inv, w2 = (ang2 - hang2) * inv;
-            const double z = bond_z_half;
-            f1 = f1 + mk3(C.sq_a1m1 * v.x, C.sq_b1m1 * v.y - C.sq_b2fm1 * (w1.z + w2.z), C.sq_b1m1 * v.z + C.sq_b2fm1 * (w1.y + w2.y)) * z;
+            // differences of the bond-frame pose; 1/dt and BondDampingZ/2 are inside the d* constants (DBondClass)
+            const d3 v = pos2 - hpos2, w1 = ang1 - hang1, w2 = ang2 - hang2;
+            f1 = f1 + mk3(C.dA1 * v.x, C.dB1 * v.y - C.dF1 * (w1.z + w2.z), C.dB1 * v.z + C.dF1 * (w1.y + w2.y));
             if (!C.homogeneous)
-                f2 = f2 + mk3(-C.sq_a1m2 * v.x, -C.sq_b1m2 * v.y + C.sq_b2fm2 * (w1.z + w2.z), -C.sq_b1m2 * v.z - C.sq_b2fm2 * (w1.y + w2.y)) * z;
-            m1 = m1 + mk3(-C.sq_a2i1 * (w2.x - w1.x), C.sq_b2fm1 * v.z + C.sq_b3i1 * (2 * w1.y + w2.y), -C.sq_b2fm1 * v.y + C.sq_b3i1 * (2 * w1.z + w2.z)) * (0.5 * z);
-            m2 = m2 + mk3(C.sq_a2i2 * (w2.x - w1.x), C.sq_b2fm2 * v.z + C.sq_b3i2 * (w1.y + 2 * w2.y), -C.sq_b2fm2 * v.y + C.sq_b3i2 * (w1.z + 2 * w2.z)) * (0.5 * z);
+                f2 = f2 + mk3(-C.dA2 * v.x, -C.dB2 * v.y + C.dF2 * (w1.z + w2.z), -C.dB2 * v.z - C.dF2 * (w1.y + w2.y));
+            m1 = m1 + mk3(-C.dT1 * (w2.x - w1.x), C.dG1 * v.z + C.dH1 * (2 * w1.y + w2.y), -C.dG1 * v.y + C.dH1 * (2 * w1.z + w2.z));
+            m2 = m2 + mk3(C.dT2 * (w2.x - w1.x), C.dG2 * v.z + C.dH2 * (w1.y + 2 * w2.y), -C.dG2 * v.y + C.dH2 * (w1.z + 2 * w2.z));
         }
         // _LastPos2 / _LastAngle1 / _LastAngle2 in the layout of the mode that produced them (ang1 == 0 in small mode;
         // pos2.y == pos2.z == ang1.x == 0 in large mode)
@@ -662,8 +660,7 @@ __device__ __forceinline__ void stream_bond(const DBatch& B, const DRobot& R, co
     const double sc1 = SCALE(cur, v1), sc2 = SCALE(cur, v2);
     BondHist H = load_bond_hist(B, slot);
     const unsigned old_flags = H.flags;
-    const double inv = rs.dt_prev != 0 ? 1.0 / rs.dt_prev : 0.0;
-    BondOut o = bond_compute<A>(B, B.bclass_tab[R.btab_begin + bc], H, p1, q1, sc1, p2, q2, sc2, inv, R.bond_z_half);
+    BondOut o = bond_compute<A>(B, B.bclass_tab[R.btab_begin + bc], H, p1, q1, sc1, p2, q2, sc2, rs.dt_prev != 0);
     store_bond_hist(B, slot, H, old_flags);
     if (o.diverged) atomicOr(&B.rstate[r].diverged, 1);
     BOUT(0, slot) = o.f1.x; BOUT(1, slot) = o.f1.y; BOUT(2, slot) = o.f1.z;

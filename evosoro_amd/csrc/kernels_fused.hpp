@@ -214,7 +214,7 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
 // both poses from the pose tile, history from/to HBM.  Returns the outputs; the caller adds them to the accumulators.
 template <int A, int BLOCK, bool MESH>
 __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, int entry,
-                                              unsigned& modebits, double inv_dt_prev, double* st, unsigned st_stride)
+                                              unsigned& modebits, bool damp_on, double* st, unsigned st_stride)
 {
     unsigned nv = B.nv;
     asm volatile("" : "+s"(nv));              // plane addresses are rebuilt here by the scalar unit: hoisted out of the step
@@ -232,7 +232,7 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
     const d3 p2 = mk3(ps[l2], ps[BLOCK + l2], ps[2 * BLOCK + l2]);
     const double s2 = ps[3 * BLOCK + l2];
     const dq q2 = mkq(ps[4 * BLOCK + l2], ps[5 * BLOCK + l2], ps[6 * BLOCK + l2], ps[7 * BLOCK + l2]);
-    BondOut o = bond_compute<A>(B, bct[entry >> 20], H, p1, q1, s1, p2, q2, s2, inv_dt_prev, R.bond_z_half);
+    BondOut o = bond_compute<A>(B, bct[entry >> 20], H, p1, q1, s1, p2, q2, s2, damp_on);
     if (H.store_hist) {
         st_plane(B.hist, 0 * 3 + A, nv, voff, H.p0); st_plane(B.hist, 1 * 3 + A, nv, voff, H.p1); st_plane(B.hist, 2 * 3 + A, nv, voff, H.p2);
         st_plane(B.hist, 3 * 3 + A, nv, voff, H.g0); st_plane(B.hist, 4 * 3 + A, nv, voff, H.g1); st_plane(B.hist, 5 * 3 + A, nv, voff, H.g2);
@@ -256,12 +256,12 @@ __device__ __forceinline__ void fused_accumulate(double* acc, int l, d3 f, d3 m)
 // one axis round: bond, then both ends into the accumulators
 template <int A, int BLOCK, int NACC, bool MESH>
 __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, double* acc, int entry,
-                                            unsigned& modebits, double inv_dt_prev, bool& div, double* st, unsigned st_stride)
+                                            unsigned& modebits, bool damp_on, bool& div, double* st, unsigned st_stride)
 {
     const bool has = entry >= 0;
     BondOut o;
     if (has) {
-        o = fused_bond<A, BLOCK, MESH>(B, R, bct, ps, entry, modebits, inv_dt_prev, st, st_stride);
+        o = fused_bond<A, BLOCK, MESH>(B, R, bct, ps, entry, modebits, damp_on, st, st_stride);
         div = div || o.diverged;
         fused_accumulate<BLOCK>(acc, entry & 1023, o.f1, o.m1);
     }
@@ -269,13 +269,13 @@ __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, co
     if (has) fused_accumulate<BLOCK>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
 }
 
-struct FusedCtl { double time, inv_dt_prev, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild; };
+struct FusedCtl { double time, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild, damp_on, pad; };
 
 __device__ __forceinline__ void fused_control_begin(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step, FusedCtl& K)
 {
     const StepCtl c = step_control_begin(R, rs, step_cap, begin_new_step);
     K.go = c.go; K.latch = c.latch; K.eol = c.eol; K.rebuild = 0;
-    K.time = rs.cur_time; K.inv_dt_prev = rs.dt_prev != 0 ? 1.0 / rs.dt_prev : 0.0;
+    K.time = rs.cur_time; K.damp_on = rs.dt_prev != 0;
     K.prenatal_c = actuation_prenatal_c(R, rs.cur_time);
     K.act_sin = K.act_cos = 0;
     if (c.go) actuation_sincos(R, rs.cur_time, K.act_sin, K.act_cos);
@@ -382,16 +382,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         d3 drag = mk3(0, 0, 0);
         const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
         if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK>(B, R, ps, st, st_stride, mesh, valid, vv, lm, C.mass_inv); }
-        const double inv_dt_prev = K.inv_dt_prev;
+        const bool damp_on = K.damp_on != 0;
         VXH_T_MARK(1)
 
         // ---- bond phase: three axis rounds over the compacted bond lists
         bool div = false;
-        fused_round<0, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[0], modebits, inv_dt_prev, div, st, st_stride);
+        fused_round<0, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[0], modebits, damp_on, div, st, st_stride);
         __syncthreads();
-        fused_round<1, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[1], modebits, inv_dt_prev, div, st, st_stride);
+        fused_round<1, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[1], modebits, damp_on, div, st, st_stride);
         __syncthreads();
-        fused_round<2, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[2], modebits, inv_dt_prev, div, st, st_stride);
+        fused_round<2, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[2], modebits, damp_on, div, st, st_stride);
         if (div) s_div = 1;
         VXH_T_MARK(2)
         __syncthreads();                       // (B)
