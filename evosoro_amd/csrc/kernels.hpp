@@ -58,6 +58,24 @@ __device__ __forceinline__ d3 rotinv(dq q, d3 f)    // CQuat::RotateVec3DInv, Ve
                tw * q.y - tx * q.z + ty * q.w + tz * q.x,
                tw * q.z + tx * q.y - ty * q.x + tz * q.w);
 }
+// v -> conj(q) v q for a UNIT quaternion as a matrix-vector product: 24 operations once, 9 per vector (rotinv: 24 each)
+struct RotInv {
+    double m00, m01, m02, m10, m11, m12, m20, m21, m22;
+    __device__ __forceinline__ explicit RotInv(dq q)
+    {
+        const double x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+        const double xx = x2 * q.x, yy = y2 * q.y, zz = z2 * q.z, xy = x2 * q.y, xz = x2 * q.z, yz = y2 * q.z, wx = x2 * q.w, wy = y2 * q.w, wz = z2 * q.w;
+        m00 = 1.0 - (yy + zz); m11 = 1.0 - (xx + zz); m22 = 1.0 - (xx + yy);
+        m01 = xy + wz; m10 = xy - wz;        // row i of R^T = column i of the rotation matrix of q
+        m02 = xz - wy; m20 = xz + wy;
+        m12 = yz + wx; m21 = yz - wx;
+    }
+    __device__ __forceinline__ d3 operator()(d3 f) const
+    {
+        return mk3(m00 * f.x + m01 * f.y + m02 * f.z, m10 * f.x + m11 * f.y + m12 * f.z, m20 * f.x + m21 * f.y + m22 * f.z);
+    }
+};
+
 // ToXDirBond / ToOrigDirBond, VX_Bond.h:45-48 ; axis 0 = X, 1 = Y, 2 = Z.  The axis is a template argument: the frame
 // change is a compile-time permutation, not a chain of selects.
 template <int A> __device__ __forceinline__ d3 to_xdir(d3 p)
@@ -299,11 +317,13 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
         H.flags = (H.flags & 2u) | (small ? 1u : 0u);
     }
 
-    // back to the global frame (:158-171)
-    o.f1 = to_orig<A>(rotinv(rot, f1));
-    o.f2 = C.homogeneous ? -o.f1 : to_orig<A>(rotinv(rot, f2));
-    o.m1 = to_orig<A>(rotinv(rot, m1));
-    o.m2 = to_orig<A>(rotinv(rot, m2));
+    // back to the global frame (:158-171): three or four vectors go through the same RotateVec3DInv(rot, .), so the
+    // rotation is expanded once into its matrix (conj(q) v q = R^T v for a unit quaternion; |rot| = 1 to rounding)
+    const RotInv T(rot);
+    o.f1 = to_orig<A>(T(f1));
+    o.f2 = C.homogeneous ? -o.f1 : to_orig<A>(T(f2));
+    o.m1 = to_orig<A>(T(m1));
+    o.m2 = to_orig<A>(T(m2));
     return o;
 }
 
