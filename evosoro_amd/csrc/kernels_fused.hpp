@@ -198,8 +198,12 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
                     const double area = fabs(vsqrt_nn(len2(cr)) / 2.0);
                     const d3 n = normalized3(cr);                       // CalcFaceNormals
                     const d3 nn = normalized3(n);                       // (the reference normalises the stored normal again, twice)
-                    const float ang = (float)vacos(dot3(sdir, nn));
-                    if (fabsf(ang) < VXH_PI / 2) {
+                    // LW/VX_Sim.cpp:1556-1559 tests (float)acos(c) < PI/2 with c = v^ . n^.  The largest float below PI/2 is
+                    // 1.57079625 and acos(c) rounds to it or below iff acos(c) <= 1.570796310901641845703125 (the midpoint
+                    // to the next float, a tie going to the even mantissa below), i.e. iff c >= cos(midpoint); c > 1
+                    // (two parallel unit vectors, rounding) makes the reference's acos a NaN and the facet drag-free.
+                    const double c = dot3(sdir, nn);
+                    if (c >= 1.5893254773528196e-08 && c <= 1.0) {
                         const d3 proj = nn * dot3(speed, n);            // ProjectOnTo
                         drag = drag + normalized3(proj) * (-R.drag_coef * area * len2(proj));
                     }

@@ -194,7 +194,7 @@ if __name__ == "__main__" and "spl" in sys.argv[1:]:
         timing2(512, (10, 10, 10), 0.05, True, {"fused": 1, "steps_per_launch": spl})
 
 
-def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel_phase=False):
+def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel_phase=False, phases=False):
     """BASELINE configs[3]/[4]: throughput of other workloads (not the bench line)"""
     from collections import OrderedDict
     tmp = tempfile.mkdtemp()
@@ -214,6 +214,9 @@ def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel
         eng.run()
         c = eng.counters()
         st = sorted(set(eng.result(i).status for i in range(count)))
+        if phases:
+            eng.clear()
+            return
         print("variant %d: %d x %s full=%s sim %.3fs %s: max_steps %d kernel %.4fs -> %.3e vox-steps/s, %.1f us/step, alg GB/s %.1f, statuses %s" % (
             variant, count, shape, full, sim_time, opts, c.max_steps, c.kernel_seconds, c.voxel_steps / c.kernel_seconds,
             1e6 * c.kernel_seconds / c.max_steps, c.algorithmic_bytes / c.kernel_seconds / 1e9, st), flush=True)
@@ -263,3 +266,11 @@ if __name__ == "__main__" and "small" in sys.argv[1:]:
     timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), {})
     timing_cfg(engine.VOXCAD, 2048, (6, 6, 6), 0.05, Env(), {})
     timing_cfg(engine.VOXCAD, 4096, (6, 6, 6), 0.05, Env(), {})
+
+
+if __name__ == "__main__" and "lwphases" in sys.argv[1:]:
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.03, env_w, {}, per_voxel_phase=True, phases=True)
