@@ -10,9 +10,10 @@ struct DVoxClass {
     int mat, pad;
 };
 struct DBondClass {
-    double L, a2, b1, b2, b3;
-    double kf;                    // axial force per unit strain: stress_k * (area1 + area2) / 2 (model.cpp make_bond_class)
-    double strain_a1, strain_a2;  // CurStrainV1/V2 = strain_a1/a2 * strain
+    double L100, a2, b1, b2, b3;  // L100 = 100 * L: the bond has diverged when its elongation exceeds it (strain > 100)
+    // per unit ELONGATION (strain = elongation / L, the 1 / L is folded in): axial force stress_k * (area1 + area2) / 2 / L
+    // (model.cpp make_bond_class) and the half-bond strains CurStrainV1/V2
+    double kf_L, strain_a1_L, strain_a2_L;
     // AddDampForces (VXS_BondInternal.cpp:310-346): the 2 sqrt(k m) terms of VX_Bond.h:65-71, already multiplied by the
     // robot's BondDampingZ / 2 (moments: / 4) and by 1 / dt, so the kernel multiplies plain differences of the bond-frame
     // pose: forces on voxel 1 / 2 (A linear-x, B linear-yz, F angular), moments on voxel 1 / 2 (T twist, G linear, H angular)

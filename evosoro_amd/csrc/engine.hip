@@ -274,8 +274,8 @@ void Engine::prepare()
             DBondClass d;
             std::memset(&d, 0, sizeof(d));
             const double zi = (0.5 * X.bond_damping_z) * (1.0 / M.dt), zh = 0.5 * zi;   // BondDampingZ/2 (moments: /4) over dt
-            d.L = c.L; d.a2 = c.a2; d.b1 = c.b1; d.b2 = c.b2; d.b3 = c.b3;
-            d.kf = c.stress_k * c.area_sum / 2; d.strain_a1 = c.strain_a1; d.strain_a2 = c.strain_a2;
+            d.L100 = 100.0 * c.L; d.a2 = c.a2; d.b1 = c.b1; d.b2 = c.b2; d.b3 = c.b3;
+            d.kf_L = c.stress_k * c.area_sum / 2 / c.L; d.strain_a1_L = c.strain_a1 / c.L; d.strain_a2_L = c.strain_a2 / c.L;
             d.dA1 = c.sq_a1m1 * zi; d.dB1 = c.sq_b1m1 * zi; d.dF1 = c.sq_b2fm1 * zi;
             d.dA2 = c.sq_a1m2 * zi; d.dB2 = c.sq_b1m2 * zi; d.dF2 = c.sq_b2fm2 * zi;
             d.dT1 = c.sq_a2i1 * zh; d.dG1 = c.sq_b2fm1 * zh; d.dH1 = c.sq_b3i1 * zh;

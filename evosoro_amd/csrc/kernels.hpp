@@ -114,6 +114,15 @@ __device__ __forceinline__ double vsqrt(double x)
     d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
 }
+// 1 / sqrt(x), x > 0 normal: v_rsq_f64 + two Newton steps (<= 1 ulp)
+__device__ __forceinline__ double vrsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);      // y (1 + e/2 + 3 e^2/8)
+    e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(y * e, 0.5, y);
+}
 __device__ __forceinline__ double vsqrt_nn(double x) { const double s = vsqrt(x); return x == 0 ? 0.0 : s; }
 __device__ __forceinline__ double vrcp(double b)
 {
@@ -181,16 +190,17 @@ __device__ __forceinline__ double vacos(double x)
 __device__ __forceinline__ dq from_angle_to_pos_x(d3 from)
 {
     if (from.x == 0 && from.y == 0 && from.z == 0) return mkq(1, 0, 0, 0);
-    double yox = vdiv(from.y, from.x), zox = vdiv(from.z, from.x);
+    const double rx = vrcp(from.x);           // one reciprocal for y/x and z/x (x == 0: both tests fail, like with inf/NaN quotients)
+    const double yox = from.y * rx, zox = from.z * rx;
     if (yox < VXH_SMALL_ANGLE_RAD && yox > -VXH_SMALL_ANGLE_RAD && zox < VXH_SMALL_ANGLE_RAD && zox > -VXH_SMALL_ANGLE_RAD) {
         double y = 0.5 * zox, z = -0.5 * yox;
         return mkq(1 + 0.5 * (-y * y - z * z), 0, y, z);
     }
-    double l = vsqrt(from.x * from.x + from.y * from.y + from.z * from.z);
-    d3 n = from;
-    if (l > 0) { double li = vrcp(l); n.x *= li; n.y *= li; n.z *= li; }
+    const double li = vrsqrt(from.x * from.x + from.y * from.y + from.z * from.z);   // NormalizeFast: from * (1 / |from|)
+    const d3 n = from * li;
     if (n.x < -0.999999999999995) return mkq(0, 0, 1, 0);     // cos(PI - DISCARD_ANGLE_RAD)
-    const double c = vsqrt(0.5 + 0.5 * n.x), h = vdiv(0.5, c);
+    const double s = 0.5 + 0.5 * n.x, ri = vrsqrt(s);         // c = sqrt(s), 1 / (2 c) = ri / 2
+    const double c = s * ri, h = 0.5 * ri;
     return mkq(c, 0, n.z * h, -n.y * h);
 }
 // CQuat::ToRotationVector, Vec3D.h:270-285
@@ -279,14 +289,14 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     const d3 ang2 = to_rotvec(qb2, B.slthresh_acos2sqrt);   // one instance for both modes: a mixed wave runs it once
 
     // axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307; linear materials): the reference's series-spring
-    // iteration is linear in the strain, its three factors are constants of the bond class (model.cpp make_bond_class)
-    const double strain = vdiv(pos2.x, C.L);
-    o.strain1 = C.strain_a1 * strain;          // CurStrainV1 / CurStrainV2 (SetStrainDir), read by the land_water surface mesh
-    o.strain2 = C.strain_a2 * strain;
-    o.diverged = strain > 100;                 // VX_Sim.cpp:1775
+    // iteration is linear in the strain = elongation / L, its three factors (with the 1 / L) are constants of the bond
+    // class (model.cpp make_bond_class, DBondClass)
+    o.strain1 = C.strain_a1_L * pos2.x;        // CurStrainV1 / CurStrainV2 (SetStrainDir), read by the land_water surface mesh
+    o.strain2 = C.strain_a2_L * pos2.x;
+    o.diverged = pos2.x > C.L100;              // strain > 100, VX_Sim.cpp:1775
 
     // beam equations (VXS_BondInternal.cpp:128-153)
-    d3 f1 = mk3(C.kf * strain, C.b1 * pos2.y - C.b2 * (ang1.z + ang2.z), C.b1 * pos2.z + C.b2 * (ang1.y + ang2.y));
+    d3 f1 = mk3(C.kf_L * pos2.x, C.b1 * pos2.y - C.b2 * (ang1.z + ang2.z), C.b1 * pos2.z + C.b2 * (ang1.y + ang2.y));
     d3 f2 = -f1;
     d3 m1 = mk3(C.a2 * (ang1.x - ang2.x), C.b2 * pos2.z + C.b3 * (2 * ang1.y + ang2.y), -C.b2 * pos2.y + C.b3 * (2 * ang1.z + ang2.z));
     d3 m2 = mk3(C.a2 * (ang2.x - ang1.x), C.b2 * pos2.z + C.b3 * (ang1.y + 2 * ang2.y), -C.b2 * pos2.y + C.b3 * (ang1.z + 2 * ang2.z));
