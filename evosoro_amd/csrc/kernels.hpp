@@ -209,7 +209,10 @@ __device__ __forceinline__ d3 to_rotvec(dq q, double slthresh)
     double sl = 1.0 - q.w * q.w;
     if (sl <= 0) return mk3(0, 0, 0);
     double wc = q.w > 1 ? 1 : q.w;
-    double f = (sl < slthresh) ? vsqrt_nn(vdiv(2 - 2 * wc, sl)) : vdiv(vacos(wc), vsqrt(sl));
+    // sqrt((2 - 2w) / sl) = (2 - 2w) * rsqrt((2 - 2w) * sl)  and  acos(w) / sqrt(sl) = acos(w) * rsqrt(sl): one refined v_rsq_f64
+    // each instead of a division and a square root (sl > 0 here, hence w < 1 and 2 - 2w > 0)
+    const double a = 2 - 2 * wc;
+    double f = (sl < slthresh) ? a * vrsqrt(a * sl) : vacos(wc) * vrsqrt(sl);
     return mk3(2.0 * q.x * f, 2.0 * q.y * f, 2.0 * q.z * f);
 }
 
@@ -440,6 +443,9 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     dq spin = qmul(mkq(0, w.x * 0.5, w.y * 0.5, w.z * 0.5), S.ang);
     dq ang = mkq(S.ang.w + spin.w * dt, S.ang.x + spin.x * dt, S.ang.y + spin.y * dt, S.ang.z + spin.z * dt);
     {
+        // NormalizeFast with the reference's own two roundings (sqrt, then 1 / l): the `w >= 1 -> identity` snap below
+        // discards rotations smaller than ~1.5e-8 rad, and whether w lands on 1.0 depends on the last bit of 1 / l
+        // (a single-rounding rsqrt here moved probe6 by 5e-9 voxel within ten steps)
         const double l = vsqrt_nn(ang.x * ang.x + ang.y * ang.y + ang.z * ang.z + ang.w * ang.w);
         if (l != 0) { const double li = vrcp(l); ang.w *= li; ang.x *= li; ang.y *= li; ang.z *= li; }
         if (ang.w >= 1.0) ang = mkq(1.0, 0, 0, 0);
