@@ -249,12 +249,17 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
     return o;
 }
 
-// acc[.][l] += (f, -m): the calling thread is the only writer of voxel l's entry between two barriers
-template <int BLOCK>
+// acc[.][l] += (f, -m): the calling thread is the only writer of voxel l's entry between two barriers.  FIRST: the entry
+// still holds the zero the voxel phase left there, so the sum is the value itself (0 + x == x: same bits, no read).
+template <int BLOCK, bool FIRST>
 __device__ __forceinline__ void fused_accumulate(double* acc, int l, d3 f, d3 m)
 {
     double* e = acc + l;
-    e[0] += f.x; e[BLOCK] += f.y; e[2 * BLOCK] += f.z; e[3 * BLOCK] -= m.x; e[4 * BLOCK] -= m.y; e[5 * BLOCK] -= m.z;
+    if constexpr (FIRST) {
+        e[0] = f.x; e[BLOCK] = f.y; e[2 * BLOCK] = f.z; e[3 * BLOCK] = -m.x; e[4 * BLOCK] = -m.y; e[5 * BLOCK] = -m.z;
+    } else {
+        e[0] += f.x; e[BLOCK] += f.y; e[2 * BLOCK] += f.z; e[3 * BLOCK] -= m.x; e[4 * BLOCK] -= m.y; e[5 * BLOCK] -= m.z;
+    }
 }
 
 // one axis round: bond, then both ends into the accumulators
@@ -267,10 +272,10 @@ __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, co
     if (has) {
         o = fused_bond<A, BLOCK, MESH>(B, R, bct, ps, entry, modebits, damp_on, st, st_stride);
         div = div || o.diverged;
-        fused_accumulate<BLOCK>(acc, entry & 1023, o.f1, o.m1);
+        fused_accumulate<BLOCK, A == 0>(acc, entry & 1023, o.f1, o.m1);
     }
     if constexpr (NACC == 1) __syncthreads();
-    if (has) fused_accumulate<BLOCK>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
+    if (has) fused_accumulate<BLOCK, A == 0 && NACC == 2>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
 }
 
 struct FusedCtl { double time, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild, damp_on, pad; };
