@@ -274,3 +274,24 @@ if __name__ == "__main__" and "lwphases" in sys.argv[1:]:
     env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
     env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
     timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.03, env_w, {}, per_voxel_phase=True, phases=True)
+
+
+if __name__ == "__main__" and "crosscheck" in sys.argv[1:]:
+    # the two kernel families (fused resident / streaming) on the whole bench population: max state difference per robot
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    sim = Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.05)
+    paths = []
+    for ind in workloads.population(512, (10, 10, 10)):
+        write_voxelyze_file(sim, Env(), ind, tmp, "t")
+        paths.append(os.path.join(tmp, "voxelyzeFiles", "t--id_%05i.vxa" % ind.id))
+    states = {}
+    for fused in (1, 0):
+        with engine.Engine(engine.VOXCAD, 0) as eng:
+            eng.set_option("fused", fused)
+            eng.add_vxa_files(paths)
+            eng.step(400)
+            states[fused] = [eng.state(i) for i in range(len(paths))]
+    diff = np.array([np.abs(a[:, :3] - b[:, :3]).max() / 0.01 for a, b in zip(states[1], states[0])])
+    print("fused vs streaming after 400 steps, position difference in voxels: median %.2e, 90%% %.2e, 99%% %.2e, max %.2e" % (
+        np.median(diff), np.percentile(diff, 90), np.percentile(diff, 99), diff.max()))
