@@ -476,10 +476,14 @@ void Engine::reset() { if (!robots_.empty()) prepare(); }
 template <int BLOCK, int NACC, bool FLUID>
 static void launch_variant(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
+    // the opt-in to more than 64 KB of dynamic LDS is per function AND per device (engines on several devices may live in
+    // one process); remember the largest size granted on each
+    static size_t attr_lds[64] = {};
+    int dev = 0;
+    hip_check(hipGetDevice(&dev), "hipGetDevice");
+    if (dev < 0 || dev >= 64 || lds > attr_lds[dev]) {
         hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK, NACC, FLUID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(fused LDS)");
-        attr_lds = lds;
+        if (dev >= 0 && dev < 64) attr_lds[dev] = lds;
     }
     hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters);
 }
