@@ -29,7 +29,8 @@ enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_ST
 struct DRobot {               // constant per robot
     int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr, pad0;
     long long excl_begin;     // first word of this robot's exclusion rows in DBatch::excl
-    int vert_begin, nmv;      // drag-mesh vertices of this robot (fluid robots)
+    int vert_begin, nmv;      // surface-mesh vertices of this robot (land_water robots)
+    int facet_begin, nfacet;  // its facets in DBatch::facet_vox / facet_vert
     int vtab_begin, n_vclass; // this robot's rows of DBatch::vclass_tab (class ids stored per voxel are robot-local)
     int btab_begin, n_bclass; // ... and of DBatch::bclass_tab
     double dt, lat, bond_z_half, slow_z, col_z, grav_acc;
@@ -99,6 +100,11 @@ struct DBatch {
     const double* vert_v0;            // [3][total_mv] rest position
     const int* corner_vert;           // [8][nv] robot-local mesh vertex at each corner of the voxel or -1
     const unsigned char* open_face;   // [nv] exposed faces PX,NX,PY,NY,PZ,NZ
+    int total_facet, pad4;
+    const int* facet_vox;             // [total_facet] local voxel owning the facet (reference order: per voxel, per face, two triangles)
+    const int* facet_vert;            // [3][total_facet] its three robot-local mesh vertices
+    const int* facet_first;           // [nv] first facet of the voxel, relative to the robot's facet_begin
+    const unsigned char* facet_count; // [nv]
     double* strain;                   // [6][nv] StrainPosDirsCur xyz, StrainNegDirsCur xyz (fluid robots only)
     double* dragf;                    // [3][nv] DragForce of the current step
     unsigned long long* prof;         // developer builds (-DVXH_PHASE_TIMING): per-wave phase cycle sums, else null

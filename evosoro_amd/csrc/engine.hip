@@ -253,6 +253,11 @@ void Engine::prepare()
     std::vector<int> vert_comp((size_t)8 * std::max(total_mv, 1), -1), corner_vert(any_fluid ? (size_t)8 * nv : 8, -1);
     std::vector<double> vert_v0((size_t)3 * std::max(total_mv, 1), 0.0);
     std::vector<unsigned char> open_face(any_fluid ? nv : 1, 0);
+    int total_facet = 0;
+    std::vector<int> facet_begin(nr, 0);
+    for (int r = 0; r < nr; ++r) { facet_begin[r] = total_facet; total_facet += (int)robots_[r].facet_vox.size(); }
+    std::vector<int> facet_vox(std::max(total_facet, 1), 0), facet_vert((size_t)3 * std::max(total_facet, 1), 0), facet_first(any_fluid ? nv : 1, 0);
+    std::vector<unsigned char> facet_count(any_fluid ? nv : 1, 0);
     std::vector<DRobotState> rstate(nr);
 
     for (int r = 0; r < nr; ++r) {
@@ -337,6 +342,11 @@ void Engine::prepare()
                   (X.has_final_temp_amp_damp ? RF_DEV_FTAD : 0);
         R.stop_type = X.stop_type; R.excl_wpr = wpr; R.excl_begin = excl_begin;
         R.vert_begin = mv_begin[r]; R.nmv = M.nmv;
+        R.facet_begin = facet_begin[r]; R.nfacet = (int)M.facet_vox.size();
+        for (size_t f = 0; f < M.facet_vox.size(); ++f) {
+            facet_vox[facet_begin[r] + f] = M.facet_vox[f];
+            for (int k = 0; k < 3; ++k) facet_vert[(size_t)k * std::max(total_facet, 1) + facet_begin[r] + f] = M.facet_vert[f * 3 + k];
+        }
         R.vtab_begin = vtab_begin; R.n_vclass = (int)M.vox_classes.size(); R.btab_begin = btab_begin; R.n_bclass = (int)M.bond_classes.size();
         if (X.fluid_env && variant_ == 1 && (M.nvox > 1024 || !fused_))
             throw std::invalid_argument("unsupported: fluid drag needs the fused path (robots of at most 1024 voxels)");
@@ -352,6 +362,7 @@ void Engine::prepare()
             for (int v = 0; v < M.nvox; ++v) {
                 for (int c = 0; c < 8; ++c) corner_vert[(size_t)c * nv + base + v] = M.corner_vert[(size_t)v * 8 + c];
                 open_face[base + v] = M.open_face[v];
+                facet_first[base + v] = M.facet_first[v]; facet_count[base + v] = M.facet_count[v];
             }
         }
         R.dt = M.dt; R.lat = X.lattice_dim; R.bond_z_half = 0.5 * X.bond_damping_z; R.slow_z = X.slow_damping_z; R.col_z = X.col_damping_z;
@@ -405,6 +416,11 @@ void Engine::prepare()
     B.vert_v0 = D.upload(vert_v0);
     B.corner_vert = D.upload(corner_vert);
     B.open_face = D.upload(open_face);
+    B.total_facet = std::max(total_facet, 1);
+    B.facet_vox = D.upload(facet_vox);
+    B.facet_vert = D.upload(facet_vert);
+    B.facet_first = D.upload(facet_first);
+    B.facet_count = D.upload(facet_count);
     B.strain = D.alloc_zero<double>(any_fluid ? (size_t)6 * nv : 1);
     B.dragf = D.alloc_zero<double>(any_fluid ? (size_t)3 * nv : 1);
     B.col_rows = std::max(ns, 1);

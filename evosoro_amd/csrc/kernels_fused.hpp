@@ -143,18 +143,27 @@ __device__ __forceinline__ d3 normalized3(d3 a) { const double l = vsqrt_nn(len2
 
 // `st`: the voxels' directional strains of the previous step, [6][BLOCK] in LDS (robots up to 768 voxels) or the
 // robot's slice of DBatch::strain with plane stride nv (1024-thread variant, where LDS is full).
-template <int BLOCK>
+template <int BLOCK, int SCR_DOUBLES>
 __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const double* ps, const double* st, unsigned st_stride, double* sh,
-                                         bool valid, int v, d3 lm, double mass_inv)
+                                         double* scr, bool valid, int v, d3 lm, double mass_inv)
 {
     const unsigned nv = B.nv, tm = B.total_mv;
     const double nom = R.lat;
     const int nmv = R.nmv;
-    for (int i = threadIdx.x; i < nmv; i += BLOCK) {
-        const int gi = R.vert_begin + i;
-        int comp[8];
+    struct VertRec { int comp[8]; double v0x, v0y, v0z; };
+    auto load_vert = [&](int i) {               // constant per-vertex data, requested one iteration ahead
+        VertRec r;
+        const int gi = R.vert_begin + min(i, nmv - 1);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) comp[q] = B.vert_comp[(unsigned)q * tm + gi];     // all eight at once: independent loads
+        for (int q = 0; q < 8; ++q) r.comp[q] = B.vert_comp[(unsigned)q * tm + gi];
+        r.v0x = B.vert_v0[gi]; r.v0y = B.vert_v0[tm + gi]; r.v0z = B.vert_v0[2 * tm + gi];
+        return r;
+    };
+    VertRec vnext = load_vert(threadIdx.x);
+    for (int i = threadIdx.x; i < nmv; i += BLOCK) {
+        const VertRec vr = vnext;
+        vnext = load_vert(i + BLOCK);
+        const int (&comp)[8] = vr.comp;
         d3 avg = mk3(0, 0, 0); double tw = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -168,49 +177,65 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
             avg = avg + p; tw += 1.0;
         }
         const double inv = vrcp(tw);
-        const d3 v0 = mk3(B.vert_v0[gi], B.vert_v0[tm + gi], B.vert_v0[2 * tm + gi]);
+        const d3 v0 = mk3(vr.v0x, vr.v0y, vr.v0z);
         const d3 np = avg * inv;
         const d3 now = v0 + (np - v0);                               // v + DrawOffset, as the reference stores it
         sh[i] = now.x; sh[nmv + i] = now.y; sh[2 * nmv + i] = now.z;
     }
+    // Phase 2, one thread per FACET (the robot's facets in the reference's order: per voxel, faces +X,-X,+Y,-Y,+Z,-Z, two
+    // triangles each), so the wavefronts are full whatever the number of exposed faces of a voxel.  `scr` (the accumulator
+    // tile, idle until the bond rounds) holds every voxel's velocity, then chunk after chunk the facets' contributions,
+    // which each voxel sums in facet order.
+    const int nfac = R.nfacet;
+    constexpr int CHF = (SCR_DOUBLES / BLOCK - 3) * BLOCK / 3;      // facets per chunk
+    double* const spd = scr;                                        // [3][BLOCK] velocity of every voxel
+    double* const fd = scr + 3 * BLOCK;                             // [3][CHF] drag of the facets of the current chunk
+    const int tid = threadIdx.x;
+    if (valid) { const d3 sp = lm * mass_inv; spd[tid] = sp.x; spd[BLOCK + tid] = sp.y; spd[2 * BLOCK + tid] = sp.z; }
     __syncthreads();
     d3 drag = mk3(0, 0, 0);
-    if (valid) {
-        const unsigned mask = B.open_face[v];
-        if (mask) {
-            int cv[8];                                               // mesh vertex at each corner NNN..PPP of this voxel
-#pragma unroll
-            for (int c = 0; c < 8; ++c) cv[c] = B.corner_vert[(unsigned)c * nv + v];
-            const d3 speed = lm * mass_inv;
+    const int my_first = valid ? B.facet_first[v] : 0, my_count = valid ? (int)B.facet_count[v] : 0;
+    const unsigned tf = B.total_facet;
+    struct FacetRec { int u, ia, ib, ic; };
+    auto load_facet = [&](int f) {              // the four indices of facet f (constant data: requested one iteration ahead)
+        FacetRec r;
+        const unsigned gf = R.facet_begin + min(f, nfac - 1);
+        r.u = B.facet_vox[gf]; r.ia = B.facet_vert[gf]; r.ib = B.facet_vert[tf + gf]; r.ic = B.facet_vert[2u * tf + gf];
+        return r;
+    };
+    for (int c0 = 0; c0 < nfac; c0 += CHF) {
+        FacetRec next = load_facet(c0 + tid);
+        for (int f = c0 + tid; f < min(nfac, c0 + CHF); f += BLOCK) {
+            const FacetRec rec = next;
+            next = load_facet(f + BLOCK);
+            const int u = rec.u, ia = rec.ia, ib = rec.ib, ic = rec.ic;
+            const d3 speed = mk3(spd[u], spd[BLOCK + u], spd[2 * BLOCK + u]);
             const d3 sdir = normalized3(speed);
-            // corner codes of the two triangles of faces +X,-X,+Y,-Y,+Z,-Z (LW/VX_MeshUtil.cpp:165-189)
-            const unsigned tri[6][2] = {{0x467u, 0x475u}, {0x032u, 0x013u}, {0x237u, 0x276u}, {0x051u, 0x045u}, {0x157u, 0x173u}, {0x064u, 0x026u}};
-#pragma unroll
-            for (int d = 0; d < 6; ++d) {
-                if (!(mask & (1u << d))) continue;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const unsigned code = tri[d][t];
-                    const int ia = cv[(code >> 8) & 7u], ib = cv[(code >> 4) & 7u], ic = cv[code & 7u];
-                    const d3 A = mk3(sh[ia], sh[nmv + ia], sh[2 * nmv + ia]);
-                    const d3 AB = mk3(sh[ib], sh[nmv + ib], sh[2 * nmv + ib]) - A, AC = mk3(sh[ic], sh[nmv + ic], sh[2 * nmv + ic]) - A;
-                    const d3 cr = cross3(AB, AC);
-                    const double area = fabs(vsqrt_nn(len2(cr)) / 2.0);
-                    const d3 n = normalized3(cr);                       // CalcFaceNormals
-                    const d3 nn = normalized3(n);                       // (the reference normalises the stored normal again, twice)
-                    // LW/VX_Sim.cpp:1556-1559 tests (float)acos(c) < PI/2 with c = v^ . n^.  The largest float below PI/2 is
-                    // 1.57079625 and acos(c) rounds to it or below iff acos(c) <= 1.570796310901641845703125 (the midpoint
-                    // to the next float, a tie going to the even mantissa below), i.e. iff c >= cos(midpoint); c > 1
-                    // (two parallel unit vectors, rounding) makes the reference's acos a NaN and the facet drag-free.
-                    const double c = dot3(sdir, nn);
-                    if (c >= 1.5893254773528196e-08 && c <= 1.0) {
-                        const d3 proj = nn * dot3(speed, n);            // ProjectOnTo
-                        drag = drag + normalized3(proj) * (-R.drag_coef * area * len2(proj));
-                    }
-                }
+            const d3 A = mk3(sh[ia], sh[nmv + ia], sh[2 * nmv + ia]);
+            const d3 AB = mk3(sh[ib], sh[nmv + ib], sh[2 * nmv + ib]) - A, AC = mk3(sh[ic], sh[nmv + ic], sh[2 * nmv + ic]) - A;
+            const d3 cr = cross3(AB, AC);
+            const double area = fabs(vsqrt_nn(len2(cr)) / 2.0);
+            const d3 n = normalized3(cr);                       // CalcFaceNormals
+            const d3 nn = normalized3(n);                       // (the reference normalises the stored normal again, twice)
+            // LW/VX_Sim.cpp:1556-1559 tests (float)acos(c) < PI/2 with c = v^ . n^.  The largest float below PI/2 is
+            // 1.57079625 and acos(c) rounds to it or below iff acos(c) <= 1.570796310901641845703125 (the midpoint
+            // to the next float, a tie going to the even mantissa below), i.e. iff c >= cos(midpoint); c > 1
+            // (two parallel unit vectors, rounding) makes the reference's acos a NaN and the facet drag-free.
+            const double c = dot3(sdir, nn);
+            d3 contrib = mk3(0, 0, 0);
+            if (c >= 1.5893254773528196e-08 && c <= 1.0) {
+                const d3 proj = nn * dot3(speed, n);            // ProjectOnTo
+                contrib = normalized3(proj) * (-R.drag_coef * area * len2(proj));
             }
+            fd[f - c0] = contrib.x; fd[CHF + (f - c0)] = contrib.y; fd[2 * CHF + (f - c0)] = contrib.z;
         }
+        __syncthreads();
+        for (int k = max(my_first, c0); k < min(my_first + my_count, c0 + CHF); ++k)     // my facets of this chunk, in order
+            drag = drag + mk3(fd[k - c0], fd[CHF + (k - c0)], fd[2 * CHF + (k - c0)]);
+        __syncthreads();
     }
+    for (int k = tid; k < SCR_DOUBLES; k += BLOCK) scr[k] = 0.0;    // the accumulators must be zero when the bond rounds start
+    __syncthreads();
     return drag;
 }
 
@@ -390,7 +415,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (K.rebuild || it == 0) ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;
         d3 drag = mk3(0, 0, 0);
         const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
-        if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK>(B, R, ps, st, st_stride, mesh, valid, vv, lm, C.mass_inv); }
+        if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK, NACC * 6 * BLOCK>(B, R, ps, st, st_stride, mesh, acc, valid, vv, lm, C.mass_inv); }
         const bool damp_on = K.damp_on != 0;
         VXH_T_MARK(1)
 

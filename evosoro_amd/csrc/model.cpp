@@ -296,6 +296,22 @@ RobotModel build_robot(const VxaModel& vxa)
             int iz = i / (nx * ny), iy = (i - iz * nx * ny) / nx, ix = i - iz * nx * ny - iy * nx;
             for (int c = 0; c < 8; ++c) r.corner_vert[(size_t)v * 8 + c] = map[d3(ix + cdx[c], iy + cdy[c], iz + cdz[c])];
         }
+        // corner codes (NNN..PPP = 0..7) of the two triangles of faces +X,-X,+Y,-Y,+Z,-Z (LW/VX_MeshUtil.cpp:165-189)
+        static const unsigned tri[6][2] = {{0x467u, 0x475u}, {0x032u, 0x013u}, {0x237u, 0x276u}, {0x051u, 0x045u}, {0x157u, 0x173u}, {0x064u, 0x026u}};
+        r.facet_first.assign(r.nvox, 0);
+        r.facet_count.assign(r.nvox, 0);
+        for (int v = 0; v < r.nvox; ++v) {
+            r.facet_first[v] = (int)r.facet_vox.size();
+            for (int d = 0; d < 6; ++d) {
+                if (!(r.open_face[v] & (1u << d))) continue;
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned code = tri[d][t];
+                    r.facet_vox.push_back(v);
+                    for (int k = 0; k < 3; ++k) r.facet_vert.push_back(r.corner_vert[(size_t)v * 8 + ((code >> (8 - 4 * k)) & 7u)]);
+                }
+            }
+            r.facet_count[v] = (unsigned char)((int)r.facet_vox.size() - r.facet_first[v]);
+        }
     }
     (void)same_bits;
     return r;

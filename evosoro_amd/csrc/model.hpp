@@ -59,6 +59,10 @@ struct RobotModel {
     std::vector<double> vert_v0;            // [nmv*3] rest position (incl. the 1e-6 offset hack of GetXYZ)
     std::vector<int> corner_vert;           // [nvox*8] mesh vertex at each corner of the voxel or -1
     std::vector<unsigned char> open_face;   // [nvox] bit d set when face PX,NX,PY,NY,PZ,NZ is exposed
+    // the facets in the reference's order (per voxel: faces +X,-X,+Y,-Y,+Z,-Z, two triangles each; LW/VX_MeshUtil.cpp:165-193)
+    std::vector<int> facet_vox, facet_vert; // [nfacet] owning voxel ; [nfacet*3] mesh vertices
+    std::vector<int> facet_first;           // [nvox] first facet of the voxel (its facets are contiguous)
+    std::vector<unsigned char> facet_count; // [nvox] 0..12
     // local class tables (merged batch-wide by the engine)
     std::vector<VoxClass> vox_classes;
     std::vector<BondClass> bond_classes;
