@@ -424,3 +424,25 @@ def test_free_floating_population_conserves_momentum(eng_mod, tmp_path):
             assert speed > 1e-4                       # the robots do move (actuation started at t = 0.01 s)
             worst = max(worst, np.abs(vel.sum(axis=0)).max() / (speed * len(vel)))
         assert worst < 1e-9, worst
+
+
+def test_two_ranks_share_the_gpu(eng_mod, golden_dir, tmp_path):
+    """The multi-rank path end to end with the real engine: two processes (gloo; RCCL does not allow two ranks on one
+    device) shard a generation by cost, each steps its shard on cuda:0, one gather gives both the whole table; it
+    equals what a single process computes (bitwise: a robot's trajectory does not depend on its batch)."""
+    import sys
+    from evosoro_amd import parallel
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", os.path.join(os.path.dirname(__file__), "dist_worker_gpu.py"), str(tmp_path),
+           os.path.join(golden_dir, "vxa")]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    t0, t1 = np.load(tmp_path / "table_rank0.npy"), np.load(tmp_path / "table_rank1.npy")
+    assert np.array_equal(t0, t1)
+    names = ["phase4", "soft5_init0", "rand6_nocol", "probe6", "stiff5", "grow5", "rand6_col"]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.add_vxa_files([os.path.join(golden_dir, "vxa", n + ".vxa") for n in names])
+        eng.run()
+        solo = np.stack([parallel.result_to_record(eng.result(i)) for i in range(len(names))])
+    assert np.array_equal(t0, solo)
