@@ -7,6 +7,8 @@ process per GPU, backend "nccl" = RCCL over xGMI on MI355X, "gloo" on CPU for te
 on its own GPU with no data-path communication, and ONE collective returns the fixed-size result records
 (<= 256 B per robot) to every rank.
 """
+import os
+
 import numpy as np
 
 RECORD_FIELDS = ["status", "steps", "nvox", "nbond", "dt", "cur_time", "lifetime",
@@ -121,6 +123,10 @@ def run_population(engine_module, paths, variant=0, costs=None, options=None, wr
     else:
         mine = list(range(len(paths)))
     device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if distributed and device_index == 0 and torch.cuda.is_available() and torch.cuda.device_count() > 1:
+        # one process per GPU: a launcher (torch.distributed.run) exports LOCAL_RANK; honour it when the caller did not
+        # call torch.cuda.set_device itself, instead of piling every rank onto device 0
+        device_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     records, _ = run_shard(engine_module, [paths[i] for i in mine], variant, device_index, options, write_xml)
     device = torch.device("cuda", device_index) if (distributed and dist.get_backend() == "nccl") else None
     return gather_records(records, mine, len(paths), device)
