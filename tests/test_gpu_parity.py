@@ -446,3 +446,56 @@ def test_two_ranks_share_the_gpu(eng_mod, golden_dir, tmp_path):
         eng.run()
         solo = np.stack([parallel.result_to_record(eng.result(i)) for i in range(len(names))])
     assert np.array_equal(t0, solo)
+
+
+def test_parameter_sweep_vs_oracle(eng_mod, tmp_path):
+    """Every switch the evosoro writer exposes, in seeded random combinations (gravity / floor / temperature / sticky
+    floor / self-collision on and off, DtFrac, frequency, amplitude, lattice size, stiffnesses, shapes), plus text-level
+    edits of the constants it hard-wires (damping ratios, collision system and horizon): 24 robots in one batch against
+    the oracle, strict bar on the first steps, conditioning-calibrated bar afterwards."""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    rng = np.random.RandomState(2024)
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    paths = []
+    for k in range(24):
+        shape = tuple(int(n) for n in rng.randint(2, 7, size=3))
+        sim = Sim(dt_frac=float(np.round(rng.uniform(0.3, 0.95), 2)), simulation_time=0.05,
+                  fitness_eval_init_time=float(np.round(rng.uniform(0.0, 0.01), 3)),
+                  self_collisions_enabled=bool(rng.randint(2)), min_temp_fact=float(np.round(rng.uniform(0.1, 0.6), 2)))
+        env = Env(frequency=float(np.round(rng.uniform(2, 8), 1)), gravity_enabled=int(rng.randint(2)), temp_enabled=int(rng.randint(2)),
+                  floor_enabled=int(rng.randint(2)), sticky_floor=int(rng.randint(2)), temp_amp=float(np.round(rng.uniform(26, 45), 0)),
+                  lattice_dimension=float(rng.choice([0.005, 0.01, 0.02])), fat_stiffness=float(rng.choice([1e6, 5e6])),
+                  bone_stiffness=float(rng.choice([5e7, 5e8])), muscle_stiffness=float(rng.choice([5e6, 1e7])))
+        if rng.randint(2):
+            env.add_param("growth_amplitude", float(np.round(rng.uniform(0.05, 0.4), 2)), "<GrowthAmplitude>")
+        per_voxel = None
+        if rng.randint(2):
+            from collections import OrderedDict
+            per_voxel = OrderedDict([("<PhaseOffset>", np.round(rng.uniform(-1, 1, size=shape), 3))])
+        ind = workloads.make_individual(k, workloads.random_material(shape, 100 + k, 0.2), per_voxel)
+        write_voxelyze_file(sim, env, ind, str(tmp_path), "s")
+        path = str(tmp_path / "voxelyzeFiles" / ("s--id_%05i.vxa" % k))
+        text = open(path).read()
+        for tag, choices in (("BondDampingZ", ["1", "0.5", "0.1"]), ("ColDampingZ", ["0.8", "0.2"]), ("SlowDampingZ", ["0.01", "0.001", "0"]),
+                             ("ColSystem", ["3", "1"]), ("CollisionHorizon", ["2", "3"])):
+            old = text[text.index("<" + tag + ">"):text.index("</" + tag + ">")]
+            text = text.replace(old, "<" + tag + ">" + str(rng.choice(choices)), 1)
+        open(path, "w").write(text)
+        paths.append(path)
+    models = [vo.parse_vxa(p) for p in paths]
+    sims = [vo.OracleSim(m) for m in models]
+    spreads = [_spread(m, (60, 150))[0] for m in models]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.add_vxa_files(paths)
+        for upto in (1, 3, 20, 150):
+            eng.step(upto - sims[0].info().steps)
+            for i, o in enumerate(sims):
+                o.step(upto - o.info().steps)
+                lat = models[i]["lattice_dim"]
+                tol = FLOOR_VOX if upto <= 20 else max(FLOOR_VOX, 20 * spreads[i])
+                err = _pos_err(eng.state(i), o.state(), lat)
+                assert err <= tol, (i, upto, err, tol, paths[i])
+    assert sum(1 for sp in spreads if sp < 1e-10) >= 18      # the strict bar applied to most of them
