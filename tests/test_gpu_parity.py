@@ -499,3 +499,46 @@ def test_parameter_sweep_vs_oracle(eng_mod, tmp_path):
                 err = _pos_err(eng.state(i), o.state(), lat)
                 assert err <= tol, (i, upto, err, tol, paths[i])
     assert sum(1 for sp in spreads if sp < 1e-10) >= 18      # the strict bar applied to most of them
+
+
+def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
+    """The same idea for _voxcad_land_water: fluid on/off, drag coefficient, gravity/floor/temperature switches, phase
+    offsets and evolved stiffness, 16 robots in one batch against the oracle."""
+    from collections import OrderedDict
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    rng = np.random.RandomState(777)
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    paths = []
+    for k in range(16):
+        shape = tuple(int(n) for n in rng.randint(2, 7, size=3))
+        sim = Sim(dt_frac=float(np.round(rng.uniform(0.3, 0.95), 2)), simulation_time=0.05,
+                  fitness_eval_init_time=float(np.round(rng.uniform(0.0, 0.01), 3)), self_collisions_enabled=bool(rng.randint(2)))
+        env = Env(frequency=float(np.round(rng.uniform(2, 8), 1)), gravity_enabled=int(rng.randint(2)), temp_enabled=int(rng.randint(2)),
+                  floor_enabled=int(rng.randint(2)), temp_amp=float(np.round(rng.uniform(26, 45), 0)))
+        if rng.randint(3) > 0:
+            env.add_param("fluid_environment", 1, "<FluidEnvironment>")
+            env.add_param("aggregate_drag_coefficient", float(rng.choice([50.0, 750.0, 3000.0])), "<AggregateDragCoefficient>")
+        layers = OrderedDict()
+        if rng.randint(2):
+            layers["<PhaseOffset>"] = np.round(rng.uniform(-1, 1, size=shape), 3)
+        if rng.randint(2):
+            layers["<Stiffness>"] = np.round(10 ** rng.uniform(6.0, 8.0, size=shape), 0)
+        ind = workloads.make_individual(k, workloads.random_material(shape, 300 + k, 0.2), layers or None)
+        write_voxelyze_file(sim, env, ind, str(tmp_path), "w")
+        paths.append(str(tmp_path / "voxelyzeFiles" / ("w--id_%05i.vxa" % k)))
+    models = [vo.parse_vxa(p, 1) for p in paths]
+    sims = [vo.OracleSim(m) for m in models]
+    spreads = [_spread(m, (60, 150))[0] for m in models]
+    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+        eng.add_vxa_files(paths)
+        for upto in (1, 3, 20, 150):
+            eng.step(upto - sims[0].info().steps)
+            for i, o in enumerate(sims):
+                o.step(upto - o.info().steps)
+                tol = FLOOR_VOX if upto <= 20 else max(FLOOR_VOX, 20 * spreads[i])
+                err = _pos_err(eng.state(i), o.state(), models[i]["lattice_dim"])
+                assert err <= tol, (i, upto, err, tol, paths[i])
+    assert sum(1 for sp in spreads if sp < 1e-10) >= 12
