@@ -245,19 +245,19 @@ void Engine::prepare()
     std::vector<float> dev(any_dev ? (size_t)7 * nv : 7, 0.f);
     std::vector<double> px(nv, 0), py(nv, 0), pz(nv, 0), sc(nv, 0), qw(nv, 1.0);
     std::vector<unsigned char> small((size_t)3 * nv, 1);
-    // land_water fluid robots: drag mesh
+    // land_water robots: deformable surface mesh (fluid drag, RobotVolume tags)
     int total_mv = 0;
     std::vector<int> mv_begin(nr, 0);
-    bool any_fluid = false;
-    for (int r = 0; r < nr; ++r) { mv_begin[r] = total_mv; total_mv += robots_[r].nmv; any_fluid = any_fluid || robots_[r].nmv > 0; }
-    std::vector<int> vert_comp((size_t)8 * std::max(total_mv, 1), -1), corner_vert(any_fluid ? (size_t)8 * nv : 8, -1);
+    bool any_mesh = false;
+    for (int r = 0; r < nr; ++r) { mv_begin[r] = total_mv; total_mv += robots_[r].nmv; any_mesh = any_mesh || robots_[r].nmv > 0; }
+    std::vector<int> vert_comp((size_t)8 * std::max(total_mv, 1), -1), corner_vert(any_mesh ? (size_t)8 * nv : 8, -1);
     std::vector<double> vert_v0((size_t)3 * std::max(total_mv, 1), 0.0);
-    std::vector<unsigned char> open_face(any_fluid ? nv : 1, 0);
+    std::vector<unsigned char> open_face(any_mesh ? nv : 1, 0);
     int total_facet = 0;
     std::vector<int> facet_begin(nr, 0);
     for (int r = 0; r < nr; ++r) { facet_begin[r] = total_facet; total_facet += (int)robots_[r].facet_vox.size(); }
-    std::vector<int> facet_vox(std::max(total_facet, 1), 0), facet_vert((size_t)3 * std::max(total_facet, 1), 0), facet_first(any_fluid ? nv : 1, 0);
-    std::vector<unsigned char> facet_count(any_fluid ? nv : 1, 0);
+    std::vector<int> facet_vox(std::max(total_facet, 1), 0), facet_vert((size_t)3 * std::max(total_facet, 1), 0), facet_first(any_mesh ? nv : 1, 0);
+    std::vector<unsigned char> facet_count(any_mesh ? nv : 1, 0);
     std::vector<DRobotState> rstate(nr);
 
     for (int r = 0; r < nr; ++r) {
@@ -421,8 +421,8 @@ void Engine::prepare()
     B.facet_vert = D.upload(facet_vert);
     B.facet_first = D.upload(facet_first);
     B.facet_count = D.upload(facet_count);
-    B.strain = D.alloc_zero<double>(any_fluid ? (size_t)6 * nv : 1);
-    B.dragf = D.alloc_zero<double>(any_fluid ? (size_t)3 * nv : 1);
+    B.strain = D.alloc_zero<double>(any_mesh ? (size_t)6 * nv : 1);
+    B.dragf = D.alloc_zero<double>(any_mesh ? (size_t)3 * nv : 1);
     B.col_rows = std::max(ns, 1);
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
