@@ -147,7 +147,7 @@ template <int BLOCK, int SCR_DOUBLES>
 __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const double* ps, const double* st, unsigned st_stride, double* sh,
                                          double* scr, bool valid, int v, d3 lm, double mass_inv)
 {
-    const unsigned nv = B.nv, tm = B.total_mv;
+    const unsigned tm = B.total_mv;
     const double nom = R.lat;
     const int nmv = R.nmv;
     struct VertRec { int comp[8]; double v0x, v0y, v0z; };
