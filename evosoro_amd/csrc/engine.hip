@@ -260,11 +260,26 @@ void Engine::prepare()
     std::vector<unsigned char> facet_count(any_mesh ? nv : 1, 0);
     std::vector<DRobotState> rstate(nr);
 
+    // offsets of the per-robot pieces of the shared tables, then the robots are assembled on the host cores (disjoint ranges)
+    std::vector<int> vtab_off(nr + 1, 0), btab_off(nr + 1, 0);
+    std::vector<long long> excl_off(nr + 1, 0);
     for (int r = 0; r < nr; ++r) {
+        const RobotModel& M = robots_[r];
+        if (M.vox_classes.size() > 32767 || M.bond_classes.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one robot");
+        if (M.vxa.fluid_env && variant_ == 1 && (M.nvox > 1024 || !fused_))
+            throw std::invalid_argument("unsupported: fluid drag needs the fused path (robots of at most 1024 voxels)");
+        vtab_off[r + 1] = vtab_off[r] + (int)M.vox_classes.size();
+        btab_off[r + 1] = btab_off[r] + (int)M.bond_classes.size();
+        excl_off[r + 1] = excl_off[r] + (M.vxa.self_col_enabled ? (long long)M.nsurf * ((M.nsurf + 63) / 64) : 0);
+    }
+    vtab.resize(vtab_off[nr]);
+    btab.resize(btab_off[nr]);
+    excl.assign((size_t)excl_off[nr], 0ull);
+    auto assemble = [&](int r) {
         const RobotModel& M = robots_[r];
         const VxaModel& X = M.vxa;
         const int base = D.vox_begin[r];
-        const int vtab_begin = (int)vtab.size(), btab_begin = (int)btab.size();
+        const int vtab_begin = vtab_off[r], btab_begin = btab_off[r];
         for (size_t i = 0; i < M.vox_classes.size(); ++i) {
             const VoxClass& c = M.vox_classes[i];
             DVoxClass d;
@@ -272,7 +287,7 @@ void Engine::prepare()
             d.mass = c.mass; d.mass_inv = c.mass_inv; d.inertia_inv = c.inertia_inv; d.c_lin = c.c_lin; d.c_ang = c.c_ang;
             d.E = c.E; d.k_floor = c.k_floor; d.u_static = c.u_static; d.u_dynamic = c.u_dynamic; d.cte = c.cte;
             d.nom_size = c.nom_size; d.mat = c.mat;
-            vtab.push_back(d);
+            vtab[vtab_begin + i] = d;
         }
         for (size_t i = 0; i < M.bond_classes.size(); ++i) {
             const BondClass& c = M.bond_classes[i];
@@ -286,9 +301,8 @@ void Engine::prepare()
             d.dT1 = c.sq_a2i1 * zh; d.dG1 = c.sq_b2fm1 * zh; d.dH1 = c.sq_b3i1 * zh;
             d.dT2 = c.sq_a2i2 * zh; d.dG2 = c.sq_b2fm2 * zh; d.dH2 = c.sq_b3i2 * zh;
             d.homogeneous = c.homogeneous;
-            btab.push_back(d);
+            btab[btab_begin + i] = d;
         }
-        if (M.vox_classes.size() > 32767 || M.bond_classes.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one robot");
         for (int w = base / 64; w < (base + (M.nvox + 63) / 64 * 64) / 64; ++w) wave_robot[w] = r;
         for (int v = 0; v < M.nvox; ++v) {
             const int g = base + v;
@@ -316,11 +330,10 @@ void Engine::prepare()
         if (X.self_col_enabled)
             for (int i = 0; i < M.nsurf; ++i) { surf[D.surf_begin[r] + i] = base + M.surf[i]; surf_ord[base + M.surf[i]] = i; }
         // CalcNearby exclusion lists as bit rows over surface ordinals
-        long long excl_begin = (long long)excl.size();
+        const long long excl_begin = excl_off[r];
         int wpr = 0;
         if (X.self_col_enabled) {
             wpr = (M.nsurf + 63) / 64;
-            excl.resize(excl.size() + (size_t)M.nsurf * wpr, 0ull);
             std::vector<int> ord(M.nvox, -1);
             for (int i = 0; i < M.nsurf; ++i) ord[M.surf[i]] = i;
             for (int i = 0; i < M.nsurf; ++i) {
@@ -348,8 +361,6 @@ void Engine::prepare()
             for (int k = 0; k < 3; ++k) facet_vert[(size_t)k * std::max(total_facet, 1) + facet_begin[r] + f] = M.facet_vert[f * 3 + k];
         }
         R.vtab_begin = vtab_begin; R.n_vclass = (int)M.vox_classes.size(); R.btab_begin = btab_begin; R.n_bclass = (int)M.bond_classes.size();
-        if (X.fluid_env && variant_ == 1 && (M.nvox > 1024 || !fused_))
-            throw std::invalid_argument("unsupported: fluid drag needs the fused path (robots of at most 1024 voxels)");
         if (M.nmv > 0) {
             const size_t tm = (size_t)std::max(total_mv, 1);
             for (int i = 0; i < M.nmv; ++i) {
@@ -378,6 +389,15 @@ void Engine::prepare()
         std::memset(&S, 0, sizeof(S));
         S.max_disp = (double)FLT_MAX;      // ClearAll, VX_Sim.cpp:369: forces a collision-list build on the first step
         S.status = M.nvox == 0 ? 3 : 0;
+    };
+    {
+        std::atomic<int> next{0};
+        auto worker = [&]() { for (int r = next.fetch_add(1); r < nr; r = next.fetch_add(1)) assemble(r); };
+        const int nthreads = std::max(1, std::min({nr / 8, (int)std::thread::hardware_concurrency(), 32}));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
     }
     DBatch& B = D.B;
     B.n_robots = nr; B.nv = nv; B.dbg = dbg_;
@@ -394,16 +414,13 @@ void Engine::prepare()
     B.act_cb = D.upload(act_cb);
     B.amp_damp = D.upload(amp_damp);
     B.dev = D.upload(dev);
-    {
-        std::vector<double> vs((size_t)18 * nv, 0.0);
-        for (int b = 0; b < 2; ++b) {
-            std::copy(px.begin(), px.end(), vs.begin() + (size_t)(4 * b + 0) * nv);
-            std::copy(py.begin(), py.end(), vs.begin() + (size_t)(4 * b + 1) * nv);
-            std::copy(pz.begin(), pz.end(), vs.begin() + (size_t)(4 * b + 2) * nv);
-            std::copy(sc.begin(), sc.end(), vs.begin() + (size_t)(4 * b + 3) * nv);
-        }
-        std::copy(qw.begin(), qw.end(), vs.begin() + (size_t)8 * nv);
-        B.vs = D.upload(vs);
+    {   // vs[18][nv]: nominal position + scale in both buffers, identity quaternions, zero momenta
+        double* vs = D.alloc_zero<double>((size_t)18 * nv);
+        const std::vector<double>* planes[5] = {&px, &py, &pz, &sc, &qw};
+        for (int k = 0; k < 5; ++k)
+            HIP_OK(hipMemcpy(vs + (size_t)(k < 4 ? k : 8) * nv, planes[k]->data(), sizeof(double) * nv, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(vs + (size_t)4 * nv, vs, sizeof(double) * 4 * nv, hipMemcpyDeviceToDevice));
+        B.vs = vs;
     }
     B.hist = D.alloc_zero<double>((size_t)6 * 3 * nv);
     B.small_angle = D.upload(small);

@@ -242,9 +242,10 @@ if __name__ == "__main__" and "e2e" in sys.argv[1:]:
         os.makedirs(os.path.join(tmp, d))
     sim = Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1)
     env = Env()
+    pop = list(workloads.population(512, (10, 10, 10)))
     t0 = time.perf_counter()
     paths = []
-    for ind in workloads.population(512, (10, 10, 10)):
+    for ind in pop:
         write_voxelyze_file(sim, env, ind, tmp, "t")
         paths.append(os.path.join(tmp, "voxelyzeFiles", "t--id_%05i.vxa" % ind.id))
     t1 = time.perf_counter()
