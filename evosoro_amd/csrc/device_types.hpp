@@ -96,17 +96,16 @@ struct DBatch {
     double* col_a1;                   // same shape: linear stiffness a1 of that collision bond
     // land_water fluid drag (LW/VX_Sim.cpp:1516-1597): deformable surface mesh of every fluid robot
     int total_mv, pad3;               // mesh vertices of all fluid robots
-    const int* vert_comp;             // [8][total_mv] contributing (voxel slot * 8 + corner code) or -1
+    const int* vert_pack;             // [3][total_mv] the <= 7 voxels sharing the vertex, by the corner code (NNN..PPP = 0..7) they
+                                      // touch it with: word0 = l0 | l1 << 10 | l2 << 20, word1 = l3 | l4 << 10 | l5 << 20,
+                                      // word2 = l6 | l7 << 10 | (bit c set when corner c is present) << 20; l = robot-local voxel
     const double* vert_v0;            // [3][total_mv] rest position
-    const int* corner_vert;           // [8][nv] robot-local mesh vertex at each corner of the voxel or -1
-    const unsigned char* open_face;   // [nv] exposed faces PX,NX,PY,NY,PZ,NZ
     int total_facet, pad4;
     const int* facet_vox;             // [total_facet] local voxel owning the facet (reference order: per voxel, per face, two triangles)
     const int* facet_vert;            // [3][total_facet] its three robot-local mesh vertices
     const int* facet_first;           // [nv] first facet of the voxel, relative to the robot's facet_begin
     const unsigned char* facet_count; // [nv]
     double* strain;                   // [6][nv] StrainPosDirsCur xyz, StrainNegDirsCur xyz (fluid robots only)
-    double* dragf;                    // [3][nv] DragForce of the current step
     unsigned long long* prof;         // developer builds (-DVXH_PHASE_TIMING): per-wave phase cycle sums, else null
     // constants from Vec3D.h evaluated by the host libm (thresholds of the small-angle logic)
     double small_angle_w, smallish_angle_w, slthresh_acos2sqrt;

@@ -189,7 +189,9 @@ void Engine::clear()
             if (tot == 0) continue;
             fprintf(stderr, "wave %2d:", w);
             for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %5.1f%%", names[k], 100.0 * h[w * 8 + k] / tot);
-            fprintf(stderr, "  total %.3e cycles\n", tot);
+            fprintf(stderr, "  total %.3e cycles", tot);
+            if (h[w * 8 + 6] + h[w * 8 + 7]) fprintf(stderr, "  (aux: mesh vertices %4.1f%%, facets %4.1f%%)", 100.0 * h[w * 8 + 6] / tot, 100.0 * h[w * 8 + 7] / tot);
+            fprintf(stderr, "\n");
         }
     }
 #endif
@@ -251,9 +253,8 @@ void Engine::prepare()
     std::vector<int> mv_begin(nr, 0);
     bool any_mesh = false;
     for (int r = 0; r < nr; ++r) { mv_begin[r] = total_mv; total_mv += robots_[r].nmv; any_mesh = any_mesh || robots_[r].nmv > 0; }
-    std::vector<int> vert_comp((size_t)8 * std::max(total_mv, 1), -1), corner_vert(any_mesh ? (size_t)8 * nv : 8, -1);
+    std::vector<int> vert_pack((size_t)3 * std::max(total_mv, 1), 0);
     std::vector<double> vert_v0((size_t)3 * std::max(total_mv, 1), 0.0);
-    std::vector<unsigned char> open_face(any_mesh ? nv : 1, 0);
     int total_facet = 0;
     std::vector<int> facet_begin(nr, 0);
     for (int r = 0; r < nr; ++r) { facet_begin[r] = total_facet; total_facet += (int)robots_[r].facet_vox.size(); }
@@ -365,15 +366,18 @@ void Engine::prepare()
         if (M.nmv > 0) {
             const size_t tm = (size_t)std::max(total_mv, 1);
             for (int i = 0; i < M.nmv; ++i) {
+                unsigned w[3] = {0, 0, 0};
                 for (int q = 0; q < 8; ++q) {
                     const int c = M.vert_comp[(size_t)i * 8 + q];
-                    vert_comp[q * tm + mv_begin[r] + i] = c < 0 ? -1 : (base + (c >> 3)) * 8 + (c & 7);
+                    if (c < 0 || M.nvox > 1024) continue;       // (only the fused path, robots <= 1024 voxels, reads it)
+                    const unsigned corner = (unsigned)c & 7u, l = (unsigned)c >> 3;
+                    w[corner / 3] |= l << (10 * (corner % 3));
+                    w[2] |= 1u << (20 + corner);
                 }
+                for (int k = 0; k < 3; ++k) vert_pack[k * tm + mv_begin[r] + i] = (int)w[k];
                 for (int k = 0; k < 3; ++k) vert_v0[k * tm + mv_begin[r] + i] = M.vert_v0[(size_t)i * 3 + k];
             }
             for (int v = 0; v < M.nvox; ++v) {
-                for (int c = 0; c < 8; ++c) corner_vert[(size_t)c * nv + base + v] = M.corner_vert[(size_t)v * 8 + c];
-                open_face[base + v] = M.open_face[v];
                 facet_first[base + v] = M.facet_first[v]; facet_count[base + v] = M.facet_count[v];
             }
         }
@@ -430,17 +434,14 @@ void Engine::prepare()
     B.surf_ord = D.upload(surf_ord);
     B.excl = D.upload(excl);
     B.total_mv = std::max(total_mv, 1);
-    B.vert_comp = D.upload(vert_comp);
+    B.vert_pack = D.upload(vert_pack);
     B.vert_v0 = D.upload(vert_v0);
-    B.corner_vert = D.upload(corner_vert);
-    B.open_face = D.upload(open_face);
     B.total_facet = std::max(total_facet, 1);
     B.facet_vox = D.upload(facet_vox);
     B.facet_vert = D.upload(facet_vert);
     B.facet_first = D.upload(facet_first);
     B.facet_count = D.upload(facet_count);
     B.strain = D.alloc_zero<double>(any_mesh ? (size_t)6 * nv : 1);
-    B.dragf = D.alloc_zero<double>(any_mesh ? (size_t)3 * nv : 1);
     B.col_rows = std::max(ns, 1);
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
@@ -456,17 +457,35 @@ void Engine::prepare()
             if (n == 0) continue;
             if (n > 1024 || M.bond_classes.size() > 2047) { D.fused_ok = false; continue; }
             const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
-            const int fluid = M.nmv > 0 ? 1 : 0;
-            const size_t extra = M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) + (size_t)24 * M.nmv +
-                                 ((fluid && block < 1024) ? (size_t)48 * block : 0);   // class tables, drag mesh, strain tile
-            const int nacc = block < 1024 ? 2 : 1;    // accumulator tiles: a function of the robot's size only
-            if ((size_t)(8 + 6 * nacc + 2) * block * 8 + extra > lds_max) { D.fused_ok = false; continue; }
+            const int fluid = M.nmv > 0 ? 1 : 0;      // (the MESH variants: every land_water robot carries the surface mesh)
+            const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
+            // LDS need: pose tile, accumulator tiles, actuation phases; class tables; the mesh vertices of a robot in a
+            // fluid; with two accumulator tiles the MESH variants also hold the strain tile (with one it stays in HBM)
+            auto need = [&](int nacc) {
+                return (size_t)(8 + 6 * nacc + 2) * block * 8 + M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) +
+                       (in_fluid ? (size_t)24 * M.nmv : 0) + ((fluid && nacc == 2) ? (size_t)48 * block : 0);
+            };
+            // accumulator tiles: two up to 768 voxels, one for 1024 and for the 768-thread MESH variant (two tiles + the
+            // strain tile exceed the 160 KB there) -- a function of the robot alone, never of the batch
+            const int nacc = (block == 1024 || (fluid && block == 768)) ? 1 : 2;
+            if (need(nacc) > lds_max) {
+                if (in_fluid)
+                    throw std::invalid_argument("unsupported: the surface mesh of a robot in a fluid (" + std::to_string(M.nmv) +
+                                                " vertices) does not fit the fused kernel's LDS, and fluid drag exists only there");
+                D.fused_ok = false;
+                continue;
+            }
             Device::Group* g = nullptr;
             for (auto& q : D.groups) if (q.block == block && q.nacc == nacc && q.fluid == fluid) g = &q;
             if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nacc = nacc; g->fluid = fluid; }
             g->robots.push_back(r);
-            g->lds = std::max(g->lds, (size_t)(8 + 6 * nacc + 2) * block * 8 + extra);
+            g->lds = std::max(g->lds, need(nacc));
         }
+        if (!D.fused_ok)
+            for (int r = 0; r < nr; ++r)
+                if (variant_ == 1 && robots_[r].vxa.fluid_env && robots_[r].nvox > 0)
+                    throw std::invalid_argument("unsupported: the batch holds robots that need the streaming kernels (more than 1024 voxels or "
+                                                "2047 bond classes), which have no fluid drag; run the robots in a fluid in their own batch");
         size_t gi = 0;
         for (auto& g : D.groups) {
             std::stable_sort(g.robots.begin(), g.robots.end(), [&](int a, int b) {
@@ -527,7 +546,7 @@ static void launch_group(const DBatch& B, int block, int nacc, const int* list, 
 {
     if (block == 256) launch_variant<256, 2, FLUID>(B, list, count, lds, s, cap, iters);
     else if (block == 512) launch_variant<512, 2, FLUID>(B, list, count, lds, s, cap, iters);
-    else if (block == 768) launch_variant<768, 2, FLUID>(B, list, count, lds, s, cap, iters);
+    else if (block == 768) launch_variant<768, FLUID ? 1 : 2, FLUID>(B, list, count, lds, s, cap, iters);
     else launch_variant<1024, 1, FLUID>(B, list, count, lds, s, cap, iters);
 }
 

@@ -34,10 +34,14 @@ enum { VXH_FUSED_STATIC_LDS = 320 };      // upper bound of the kernel's static 
 #define VXH_T_DECL unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_readcyclecounter();
 #define VXH_T_MARK(k) { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[k] += t_now - t_last; t_last = t_now; }
 #define VXH_T_FLUSH if (B.prof && (threadIdx.x & 63) == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&B.prof[(threadIdx.x >> 6) * 8 + k], t_acc[k]); }
+#define VXH_T_SUB_BEGIN unsigned long long t_sub = __builtin_readcyclecounter();
+#define VXH_T_SUB(k) { const unsigned long long t_now = __builtin_readcyclecounter(); if (B.prof && (threadIdx.x & 63) == 0) atomicAdd(&B.prof[(threadIdx.x >> 6) * 8 + (k)], t_now - t_sub); t_sub = t_now; }
 #else
 #define VXH_T_DECL
 #define VXH_T_MARK(k)
 #define VXH_T_FLUSH
+#define VXH_T_SUB_BEGIN
+#define VXH_T_SUB(k)
 #endif
 
 // plane `plane` (of nv doubles) of a SoA array, element at byte offset voff: uniform 64-bit base + 32-bit lane offset
@@ -141,91 +145,226 @@ __device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * 
 __device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ d3 normalized3(d3 a) { const double l = vsqrt_nn(len2(a)); return l > 0 ? a * vrcp(l) : a; }
 
+// CQuat::RotateVec3D (Vec3D.h:293-299) as a matrix: q f q* = M f for a unit quaternion (|q| = 1 to rounding).  A voxel's eight
+// mesh corners go through the same rotation, so it is expanded once per voxel (§ Numerics).
+struct RotFwd {
+    double m[9];
+    __device__ __forceinline__ RotFwd() {}
+    __device__ __forceinline__ explicit RotFwd(dq q)
+    {
+        const double x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+        const double xx = q.x * x2, yy = q.y * y2, zz = q.z * z2, xy = q.x * y2, xz = q.x * z2, yz = q.y * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+        m[0] = 1 - (yy + zz); m[1] = xy - wz; m[2] = xz + wy;
+        m[3] = xy + wz; m[4] = 1 - (xx + zz); m[5] = yz - wx;
+        m[6] = xz - wy; m[7] = yz + wx; m[8] = 1 - (xx + yy);
+    }
+    __device__ __forceinline__ d3 operator()(d3 f) const
+    { return mk3(m[0] * f.x + m[1] * f.y + m[2] * f.z, m[3] * f.x + m[4] * f.y + m[5] * f.z, m[6] * f.x + m[7] * f.y + m[8] * f.z); }
+};
+
+// Constant index data of the drag pass that a thread needs at the head of its loops (its first two mesh vertices, its first
+// four facets).  Workgroups of up to 512 threads have the registers to keep it for the whole launch; the larger ones
+// reload it every step.
+struct VertRec { unsigned w0, w1, w2; };
+struct FacetRec { int u, ia, ib, ic; };
+__device__ __forceinline__ VertRec load_vert(const DBatch& B, const DRobot& R, int i)
+{
+    VertRec r;
+    const unsigned tm = B.total_mv, gi = R.vert_begin + min(i, R.nmv - 1);
+    r.w0 = B.vert_pack[gi]; r.w1 = B.vert_pack[tm + gi]; r.w2 = B.vert_pack[2u * tm + gi];
+    return r;
+}
+__device__ __forceinline__ d3 load_vert_v0(const DBatch& B, const DRobot& R, int i)
+{
+    const unsigned tm = B.total_mv, gi = R.vert_begin + min(i, R.nmv - 1);
+    return mk3(B.vert_v0[gi], B.vert_v0[tm + gi], B.vert_v0[2u * tm + gi]);
+}
+__device__ __forceinline__ FacetRec load_facet(const DBatch& B, const DRobot& R, int f)   // the four indices of facet f
+{
+    FacetRec r;
+    const unsigned tf = B.total_facet, gf = R.facet_begin + min(f, R.nfacet - 1);
+    r.u = B.facet_vox[gf]; r.ia = B.facet_vert[gf]; r.ib = B.facet_vert[tf + gf]; r.ic = B.facet_vert[2u * tf + gf];
+    return r;
+}
+template <int BLOCK>
+struct DragCache {
+    static constexpr bool KEEP = BLOCK <= 512;
+    VertRec vert0, vert1; d3 v00, v01; FacetRec f0, f1, f2, f3;
+    __device__ __forceinline__ void load(const DBatch& B, const DRobot& R, int tid)
+    {
+        vert0 = load_vert(B, R, tid); vert1 = load_vert(B, R, tid + BLOCK);
+        v00 = load_vert_v0(B, R, tid); v01 = load_vert_v0(B, R, tid + BLOCK);
+        f0 = load_facet(B, R, tid); f1 = load_facet(B, R, tid + BLOCK); f2 = load_facet(B, R, tid + 2 * BLOCK); f3 = load_facet(B, R, tid + 3 * BLOCK);
+    }
+};
+
 // `st`: the voxels' directional strains of the previous step, [6][BLOCK] in LDS (robots up to 768 voxels) or the
 // robot's slice of DBatch::strain with plane stride nv (1024-thread variant, where LDS is full).
+// `scr`: the accumulator tile, idle until the bond rounds: first the voxels' corner positions (four or two of the eight
+// corners at a time: twelve or six planes), then every voxel's velocity (and its direction), then the facets' drag.
 template <int BLOCK, int SCR_DOUBLES>
 __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const double* ps, const double* st, unsigned st_stride, double* sh,
-                                         double* scr, bool valid, int v, d3 lm, double mass_inv)
+                                         double* scr, bool valid, int v, d3 lm, double mass_inv, const DragCache<BLOCK>& kept)
 {
-    const unsigned tm = B.total_mv;
+    constexpr bool WIDE = SCR_DOUBLES >= 12 * BLOCK;
+    constexpr int CPP = WIDE ? 4 : 2;               // voxel corners per pass
+    static_assert(SCR_DOUBLES >= 3 * CPP * BLOCK, "accumulator tile too small for the corner passes");
     const double nom = R.lat;
     const int nmv = R.nmv;
-    struct VertRec { int comp[8]; double v0x, v0y, v0z; };
-    auto load_vert = [&](int i) {               // constant per-vertex data, requested one iteration ahead
-        VertRec r;
-        const int gi = R.vert_begin + min(i, nmv - 1);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r.comp[q] = B.vert_comp[(unsigned)q * tm + gi];
-        r.v0x = B.vert_v0[gi]; r.v0y = B.vert_v0[tm + gi]; r.v0z = B.vert_v0[2 * tm + gi];
-        return r;
-    };
-    VertRec vnext = load_vert(threadIdx.x);
-    for (int i = threadIdx.x; i < nmv; i += BLOCK) {
-        const VertRec vr = vnext;
-        vnext = load_vert(i + BLOCK);
-        const int (&comp)[8] = vr.comp;
-        d3 avg = mk3(0, 0, 0); double tw = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (comp[q] < 0) break;
-            const int l = (comp[q] >> 3) - R.vox_begin, corner = comp[q] & 7;
-            const d3 cp = mk3((1 + st[l]) * nom * 0.5, (1 + st[st_stride + l]) * nom * 0.5, (1 + st[2 * st_stride + l]) * nom * 0.5);
-            const d3 cn = mk3(-(1 + st[3 * st_stride + l]) * nom * 0.5, -(1 + st[4 * st_stride + l]) * nom * 0.5, -(1 + st[5 * st_stride + l]) * nom * 0.5);
-            const d3 off = mk3((corner & 4) ? cp.x : cn.x, (corner & 2) ? cp.y : cn.y, (corner & 1) ? cp.z : cn.z);
-            const d3 p = mk3(ps[l], ps[BLOCK + l], ps[2 * BLOCK + l]) +
-                         rot_fwd(mkq(ps[4 * BLOCK + l], ps[5 * BLOCK + l], ps[6 * BLOCK + l], ps[7 * BLOCK + l]), off);
-            avg = avg + p; tw += 1.0;
-        }
-        const double inv = vrcp(tw);
-        const d3 v0 = mk3(vr.v0x, vr.v0y, vr.v0z);
-        const d3 np = avg * inv;
-        const d3 now = v0 + (np - v0);                               // v + DrawOffset, as the reference stores it
-        sh[i] = now.x; sh[nmv + i] = now.y; sh[2 * nmv + i] = now.z;
-    }
-    // Phase 2, one thread per FACET (the robot's facets in the reference's order: per voxel, faces +X,-X,+Y,-Y,+Z,-Z, two
-    // triangles each), so the wavefronts are full whatever the number of exposed faces of a voxel.  `scr` (the accumulator
-    // tile, idle until the bond rounds) holds every voxel's velocity, then chunk after chunk the facets' contributions,
-    // which each voxel sums in facet order.
-    const int nfac = R.nfacet;
-    constexpr int CHF = (SCR_DOUBLES / BLOCK - 3) * BLOCK / 3;      // facets per chunk
-    double* const spd = scr;                                        // [3][BLOCK] velocity of every voxel
-    double* const fd = scr + 3 * BLOCK;                             // [3][CHF] drag of the facets of the current chunk
     const int tid = threadIdx.x;
-    if (valid) { const d3 sp = lm * mass_inv; spd[tid] = sp.x; spd[BLOCK + tid] = sp.y; spd[2 * BLOCK + tid] = sp.z; }
+    VXH_T_SUB_BEGIN
+    // Phase 1, voxel-parallel then vertex-parallel: every voxel rotates its own eight corner offsets (one rotation matrix),
+    // every vertex adds up the corners that meet in it, in corner-code order (the reference: in voxel order; § Numerics)
+    constexpr bool KEEP = DragCache<BLOCK>::KEEP;
+    constexpr int NKV = KEEP ? 2 : 1, NKF = KEEP ? 4 : 0;           // leading vertex / facet records held in registers
+    VertRec vert0, vert1 = {0, 0, 0};
+    d3 v00 = mk3(0, 0, 0), v01 = mk3(0, 0, 0);
+    if constexpr (KEEP) { vert0 = kept.vert0; vert1 = kept.vert1; v00 = kept.v00; v01 = kept.v01; }
+    else vert0 = load_vert(B, R, tid);
+    // the kept facet records as local scalars, selected by value below (a conditional between members reached through the
+    // reference becomes a load from a selected ADDRESS, which pins the whole cache in scratch memory)
+    const int ku[4] = {kept.f0.u, kept.f1.u, kept.f2.u, kept.f3.u}, ka[4] = {kept.f0.ia, kept.f1.ia, kept.f2.ia, kept.f3.ia};
+    const int kb[4] = {kept.f0.ib, kept.f1.ib, kept.f2.ib, kept.f3.ib}, kc[4] = {kept.f0.ic, kept.f1.ic, kept.f2.ic, kept.f3.ic};
+    // Phase 1.  Every vertex is the mean of the voxel corners that meet in it, corner = Pos + R(Angle) * offset, summed in
+    // corner-code order (the reference: in voxel order; § Numerics).  GATHER: every voxel rotates its own eight corner
+    // offsets into the tile, four (twelve planes) or two (six planes) at a time, and the vertices gather them.  The
+    // 1024-thread variant, short of registers, is faster when every vertex recomputes its corners itself (same operations):
+    // measured 42.4 against 46.5 us per step on dense 10^3 swimmers, the 768-thread variant 72.1 (gather) against 77.9.
+    constexpr bool GATHER = BLOCK < 1024;
+    if constexpr (GATHER) {
+        d3 vp = mk3(0, 0, 0), hp = mk3(0, 0, 0), hn = mk3(0, 0, 0);
+        RotFwd M;
+        if (valid) {
+            vp = mk3(ps[tid], ps[BLOCK + tid], ps[2 * BLOCK + tid]);
+            M = RotFwd(mkq(ps[4 * BLOCK + tid], ps[5 * BLOCK + tid], ps[6 * BLOCK + tid], ps[7 * BLOCK + tid]));
+            // CornerPosCur / CornerNegCur (LW/VXS_Voxel.cpp:472-475)
+            hp = mk3((1 + st[tid]) * nom * 0.5, (1 + st[st_stride + tid]) * nom * 0.5, (1 + st[2 * st_stride + tid]) * nom * 0.5);
+            hn = mk3(-(1 + st[3 * st_stride + tid]) * nom * 0.5, -(1 + st[4 * st_stride + tid]) * nom * 0.5, -(1 + st[5 * st_stride + tid]) * nom * 0.5);
+        }
+    #pragma unroll
+        for (int p0 = 0; p0 < 8; p0 += CPP) {
+            if constexpr (!KEEP) { if (p0 + CPP == 8) v00 = load_vert_v0(B, R, tid); }
+            if (valid) {
+    #pragma unroll
+                for (int c = 0; c < CPP; ++c) {
+                    const int corner = p0 + c;
+                    const d3 p = vp + M(mk3((corner & 4) ? hp.x : hn.x, (corner & 2) ? hp.y : hn.y, (corner & 1) ? hp.z : hn.z));
+                    scr[(3 * c) * BLOCK + tid] = p.x; scr[(3 * c + 1) * BLOCK + tid] = p.y; scr[(3 * c + 2) * BLOCK + tid] = p.z;
+                }
+            }
+            __syncthreads();
+            int k = 0;
+            VertRec vnext = vert1;
+            d3 v0next = v01;
+            for (int i = tid; i < nmv; i += BLOCK, ++k) {
+                const bool s0 = k == 0, s1 = KEEP && k == 1;          // (selects field by field, like the facet records below)
+                VertRec vr;
+                vr.w0 = s0 ? vert0.w0 : (s1 ? vert1.w0 : vnext.w0); vr.w1 = s0 ? vert0.w1 : (s1 ? vert1.w1 : vnext.w1); vr.w2 = s0 ? vert0.w2 : (s1 ? vert1.w2 : vnext.w2);
+                const d3 v0 = mk3(s0 ? v00.x : (s1 ? v01.x : v0next.x), s0 ? v00.y : (s1 ? v01.y : v0next.y), s0 ? v00.z : (s1 ? v01.z : v0next.z));
+                if (k + 1 >= NKV) { vnext = load_vert(B, R, i + BLOCK); if (p0 + CPP == 8) v0next = load_vert_v0(B, R, i + BLOCK); }   // one iteration ahead
+                d3 part = p0 == 0 ? mk3(0, 0, 0) : mk3(sh[i], sh[nmv + i], sh[2 * nmv + i]);
+    #pragma unroll
+                for (int c = 0; c < CPP; ++c) {
+                    const int corner = p0 + c;
+                    if (!((vr.w2 >> (20 + corner)) & 1u)) continue;
+                    const unsigned word = corner < 3 ? vr.w0 : (corner < 6 ? vr.w1 : vr.w2);
+                    const unsigned l = (word >> (10 * (corner % 3))) & 1023u;
+                    part = part + mk3(scr[(3 * c) * BLOCK + l], scr[(3 * c + 1) * BLOCK + l], scr[(3 * c + 2) * BLOCK + l]);
+                }
+                if (p0 + CPP == 8) {
+                    const double inv = vrcp((double)__popc((vr.w2 >> 20) & 255u));
+                    const d3 np = part * inv;
+                    part = v0 + (np - v0);                               // v + DrawOffset, as the reference stores it
+                }
+                sh[i] = part.x; sh[nmv + i] = part.y; sh[2 * nmv + i] = part.z;
+            }
+            __syncthreads();                                             // the corners have been read: scr changes hands
+        }
+    } else {
+        if (nmv > 0) v00 = KEEP ? v00 : load_vert_v0(B, R, tid);
+        int k = 0;
+        VertRec vnext = vert1;
+        d3 v0next = v01;
+        for (int i = tid; i < nmv; i += BLOCK, ++k) {
+            const bool s0 = k == 0, s1 = KEEP && k == 1;
+            VertRec vr;
+            vr.w0 = s0 ? vert0.w0 : (s1 ? vert1.w0 : vnext.w0); vr.w1 = s0 ? vert0.w1 : (s1 ? vert1.w1 : vnext.w1); vr.w2 = s0 ? vert0.w2 : (s1 ? vert1.w2 : vnext.w2);
+            const d3 v0 = mk3(s0 ? v00.x : (s1 ? v01.x : v0next.x), s0 ? v00.y : (s1 ? v01.y : v0next.y), s0 ? v00.z : (s1 ? v01.z : v0next.z));
+            if (k + 1 >= NKV) { vnext = load_vert(B, R, i + BLOCK); v0next = load_vert_v0(B, R, i + BLOCK); }   // one iteration ahead
+            d3 part = mk3(0, 0, 0);
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                if (!((vr.w2 >> (20 + corner)) & 1u)) continue;
+                const unsigned word = corner < 3 ? vr.w0 : (corner < 6 ? vr.w1 : vr.w2);
+                const unsigned l = (word >> (10 * (corner % 3))) & 1023u;
+                const double hx = (1 + st[((corner & 4) ? 0u : 3u) * st_stride + l]) * nom * 0.5;     // CornerPosCur / CornerNegCur
+                const double hy = (1 + st[((corner & 2) ? 1u : 4u) * st_stride + l]) * nom * 0.5;
+                const double hz = (1 + st[((corner & 1) ? 2u : 5u) * st_stride + l]) * nom * 0.5;
+                const RotFwd Ml(mkq(ps[4 * BLOCK + l], ps[5 * BLOCK + l], ps[6 * BLOCK + l], ps[7 * BLOCK + l]));
+                part = part + (mk3(ps[l], ps[BLOCK + l], ps[2 * BLOCK + l]) + Ml(mk3((corner & 4) ? hx : -hx, (corner & 2) ? hy : -hy, (corner & 1) ? hz : -hz)));
+            }
+            const double inv = vrcp((double)__popc((vr.w2 >> 20) & 255u));
+            const d3 np = part * inv;
+            const d3 now = v0 + (np - v0);                           // v + DrawOffset, as the reference stores it
+            sh[i] = now.x; sh[nmv + i] = now.y; sh[2 * nmv + i] = now.z;
+        }
+    }
+    VXH_T_SUB(6)
+    // Phase 2, one thread per FACET (the robot's facets in the reference's order: per voxel, faces +X,-X,+Y,-Y,+Z,-Z, two
+    // triangles each), so the wavefronts are full whatever the number of exposed faces of a voxel.  `scr` holds every
+    // voxel's velocity (and its direction), then chunk after chunk the facets' contributions, which each voxel sums in
+    // facet order.
+    const int nfac = R.nfacet;
+    constexpr int VPL = WIDE ? 6 : 3;                               // planes of per-voxel data
+    constexpr int CHF = (SCR_DOUBLES / BLOCK - VPL) * BLOCK / 3;    // facets per chunk
+    double* const spd = scr;                                        // [VPL][BLOCK]
+    double* const fd = scr + VPL * BLOCK;                           // [3][CHF] drag of the facets of the current chunk
+    if (valid) {
+        const d3 sp = lm * mass_inv;
+        spd[tid] = sp.x; spd[BLOCK + tid] = sp.y; spd[2 * BLOCK + tid] = sp.z;
+        if constexpr (WIDE) { const d3 sd = normalized3(sp); spd[3 * BLOCK + tid] = sd.x; spd[4 * BLOCK + tid] = sd.y; spd[5 * BLOCK + tid] = sd.z; }
+    }
     __syncthreads();
     d3 drag = mk3(0, 0, 0);
     const int my_first = valid ? B.facet_first[v] : 0, my_count = valid ? (int)B.facet_count[v] : 0;
-    const unsigned tf = B.total_facet;
-    struct FacetRec { int u, ia, ib, ic; };
-    auto load_facet = [&](int f) {              // the four indices of facet f (constant data: requested one iteration ahead)
-        FacetRec r;
-        const unsigned gf = R.facet_begin + min(f, nfac - 1);
-        r.u = B.facet_vox[gf]; r.ia = B.facet_vert[gf]; r.ib = B.facet_vert[tf + gf]; r.ic = B.facet_vert[2u * tf + gf];
-        return r;
-    };
+    static_assert(CHF % BLOCK == 0, "a thread's facets are tid + m * BLOCK in every chunk");
     for (int c0 = 0; c0 < nfac; c0 += CHF) {
-        FacetRec next = load_facet(c0 + tid);
-        for (int f = c0 + tid; f < min(nfac, c0 + CHF); f += BLOCK) {
-            const FacetRec rec = next;
-            next = load_facet(f + BLOCK);
+        int m = c0 / BLOCK;
+        FacetRec next = {0, 0, 0, 0};
+        if (m >= NKF) next = load_facet(B, R, c0 + tid);
+        for (int f = c0 + tid; f < min(nfac, c0 + CHF); f += BLOCK, ++m) {
+            FacetRec rec = next;
+            if constexpr (KEEP) {
+                if (m < 4) {
+                    rec.u = m == 0 ? ku[0] : (m == 1 ? ku[1] : (m == 2 ? ku[2] : ku[3]));
+                    rec.ia = m == 0 ? ka[0] : (m == 1 ? ka[1] : (m == 2 ? ka[2] : ka[3]));
+                    rec.ib = m == 0 ? kb[0] : (m == 1 ? kb[1] : (m == 2 ? kb[2] : kb[3]));
+                    rec.ic = m == 0 ? kc[0] : (m == 1 ? kc[1] : (m == 2 ? kc[2] : kc[3]));
+                }
+            }
+            if (m + 1 >= NKF) next = load_facet(B, R, f + BLOCK);     // one iteration ahead
             const int u = rec.u, ia = rec.ia, ib = rec.ib, ic = rec.ic;
             const d3 speed = mk3(spd[u], spd[BLOCK + u], spd[2 * BLOCK + u]);
-            const d3 sdir = normalized3(speed);
+            d3 sdir;
+            if constexpr (WIDE) sdir = mk3(spd[3 * BLOCK + u], spd[4 * BLOCK + u], spd[5 * BLOCK + u]);
+            else sdir = normalized3(speed);
             const d3 A = mk3(sh[ia], sh[nmv + ia], sh[2 * nmv + ia]);
             const d3 AB = mk3(sh[ib], sh[nmv + ib], sh[2 * nmv + ib]) - A, AC = mk3(sh[ic], sh[nmv + ic], sh[2 * nmv + ic]) - A;
             const d3 cr = cross3(AB, AC);
-            const double area = fabs(vsqrt_nn(len2(cr)) / 2.0);
-            const d3 n = normalized3(cr);                       // CalcFaceNormals
-            const d3 nn = normalized3(n);                       // (the reference normalises the stored normal again, twice)
+            const double cl = vsqrt_nn(len2(cr));
+            const double area = cl * 0.5;
+            const d3 n = cl > 0 ? cr * vrcp(cl) : cr;           // CalcFaceNormals; the reference normalises the stored normal
+                                                                // twice more before using it: identity to an ulp, skipped (§ Numerics)
             // LW/VX_Sim.cpp:1556-1559 tests (float)acos(c) < PI/2 with c = v^ . n^.  The largest float below PI/2 is
             // 1.57079625 and acos(c) rounds to it or below iff acos(c) <= 1.570796310901641845703125 (the midpoint
             // to the next float, a tie going to the even mantissa below), i.e. iff c >= cos(midpoint); c > 1
             // (two parallel unit vectors, rounding) makes the reference's acos a NaN and the facet drag-free.
-            const double c = dot3(sdir, nn);
+            const double c = dot3(sdir, n);
             d3 contrib = mk3(0, 0, 0);
             if (c >= 1.5893254773528196e-08 && c <= 1.0) {
-                const d3 proj = nn * dot3(speed, n);            // ProjectOnTo
-                contrib = normalized3(proj) * (-R.drag_coef * area * len2(proj));
+                const d3 proj = n * dot3(speed, n);             // ProjectOnTo
+                // proj^ * (-k * area * |proj|^2) = proj * (-k * area * |proj|)
+                contrib = proj * (-R.drag_coef * area * vsqrt_nn(len2(proj)));
             }
             fd[f - c0] = contrib.x; fd[CHF + (f - c0)] = contrib.y; fd[2 * CHF + (f - c0)] = contrib.z;
         }
@@ -236,6 +375,7 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
     }
     for (int k = tid; k < SCR_DOUBLES; k += BLOCK) scr[k] = 0.0;    // the accumulators must be zero when the bond rounds start
     __syncthreads();
+    VXH_T_SUB(7)
     return drag;
 }
 
@@ -356,7 +496,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // MESH (land_water robots): directional strains of the previous step (inputs of the surface mesh: fluid drag, and the
     // RobotVolumeEnd tag on the host) in LDS next to the tables, then the mesh vertices; the 1024-thread variant has no
     // room for the strains and keeps them in HBM
-    constexpr bool STRAIN_LDS = MESH && BLOCK < 1024;
+    constexpr bool STRAIN_LDS = MESH && NACC == 2;
     double* const st = STRAIN_LDS ? tabs + nbd + nvd : B.strain + R.vox_begin;
     const unsigned st_stride = STRAIN_LDS ? (unsigned)BLOCK : nv;
     double* const mesh = tabs + nbd + nvd + (STRAIN_LDS ? 6 * BLOCK : 0);
@@ -391,6 +531,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #pragma unroll
     for (int k = 0; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;
     const FetchLds<BLOCK> fetch{ps, base};
+    DragCache<BLOCK> dcache;
+    if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) dcache.load(B, R, tid); }
     int ccnt = 0;                             // number of collision partners of my voxel (refreshed after a broad-phase run)
 
     // the control thread sits in the LAST wave: the one with the fewest (often no) voxels, so its serial work hides
@@ -415,7 +557,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (K.rebuild || it == 0) ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;
         d3 drag = mk3(0, 0, 0);
         const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
-        if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK, NACC * 6 * BLOCK>(B, R, ps, st, st_stride, mesh, acc, valid, vv, lm, C.mass_inv); }
+        if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK, NACC * 6 * BLOCK>(B, R, ps, st, st_stride, mesh, acc, valid, vv, lm, C.mass_inv, dcache); }
         const bool damp_on = K.damp_on != 0;
         VXH_T_MARK(1)
 

@@ -222,6 +222,19 @@ def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel
             1e6 * c.kernel_seconds / c.max_steps, c.algorithmic_bytes / c.kernel_seconds / 1e9, st), flush=True)
 
 
+if __name__ == "__main__" and "lwcfgs" in sys.argv[1:]:
+    # swimmers through the four mesh variants of the fused kernel (256, 512, 768, 1024 threads); VXH_LIB=<path> to compare builds
+    if os.environ.get("VXH_LIB"):
+        engine.LIB_PATH = os.environ["VXH_LIB"]
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    timing_cfg(engine.VOXCAD_LAND_WATER, 1024, (6, 6, 6), 0.05, env_w, {}, per_voxel_phase=True)
+    timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.05, env_w, {}, per_voxel_phase=True)
+    timing_cfg(engine.VOXCAD_LAND_WATER, 512, (10, 10, 10), 0.03, env_w, {}, per_voxel_phase=True)
+    timing_cfg(engine.VOXCAD_LAND_WATER, 256, (10, 10, 10), 0.02, env_w, {}, full=True, per_voxel_phase=True)
+
+
 if __name__ == "__main__" and "cfgs" in sys.argv[1:]:
     env_w = Env()
     env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
@@ -276,6 +289,8 @@ if __name__ == "__main__" and "lwphases" in sys.argv[1:]:
     env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
     env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
     timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.03, env_w, {}, per_voxel_phase=True, phases=True)
+    if "10" in sys.argv[1:]:      # the 768-thread variant (swimmers of up to 768 voxels)
+        timing_cfg(engine.VOXCAD_LAND_WATER, 512, (10, 10, 10), 0.03, env_w, {}, per_voxel_phase=True, phases=True)
 
 
 if __name__ == "__main__" and "crosscheck" in sys.argv[1:]:

@@ -285,6 +285,52 @@ def test_every_fused_kernel_variant_vs_oracle(eng_mod, tmp_path):
                 assert np.abs(eng.state(i)[:, 3:14] - o.state()[:, 3:14]).max() < 1e-7, (i, upto)   # quat, scale, vel, angvel
 
 
+def test_every_mesh_kernel_variant_swims_like_the_oracle(eng_mod, tmp_path):
+    """_voxcad_land_water in a fluid, one swimmer per workgroup size of the fused kernel's MESH variants (256 / 512 /
+    768 / 1024 threads; the last two keep the strains in HBM and pass the voxel corners through a six-plane tile) in ONE
+    batch against the oracle.  Without gravity and floor a robot only moves through actuation + drag, so a swimmer that
+    silently lost its drag (e.g. by falling onto the streaming kernels, which have none) cannot pass."""
+    from collections import OrderedDict
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    sim = Sim(dt_frac=0.9, simulation_time=0.02, fitness_eval_init_time=0.002)
+    env = Env()
+    env.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    mats = [workloads.random_material((6, 6, 6), 3), workloads.random_material((8, 8, 8), 4),
+            workloads.random_material((10, 10, 10), 5), workloads.full_material(10, 2)]
+    paths = []
+    for k, m in enumerate(mats):
+        layers = OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(50 + k).uniform(-1, 1, size=m.shape), 3))])
+        write_voxelyze_file(sim, env, workloads.make_individual(k, m, layers), str(tmp_path), "s")
+        paths.append(str(tmp_path / "voxelyzeFiles" / ("s--id_%05i.vxa" % k)))
+    sims = [vo.OracleSim.from_vxa(p, variant=1) for p in paths]
+    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+        eng.add_vxa_files(paths)
+        nv = [eng.dims(i)["nvox"] for i in range(4)]
+        assert nv[0] <= 256 < nv[1] <= 512 < nv[2] <= 768 < nv[3] == 1000
+        for upto in (1, 3, 40, 120):
+            eng.step(upto - sims[0].info().steps)
+            assert eng.counters().dominant_block != 0              # the fused kernels ran (0 = streaming path)
+            for i, o in enumerate(sims):
+                o.step(upto - o.info().steps)
+                assert _pos_err(eng.state(i), o.state(), 0.01) < FLOOR_VOX, (i, upto)
+                assert np.abs(eng.state(i)[:, 3:14] - o.state()[:, 3:14]).max() < 1e-7, (i, upto)
+        moved = [np.abs(o.state()[:, 7:10]).max() for o in sims]       # the swimmers do move (velocities)
+        assert min(moved) > 0
+    # a robot in a fluid next to one that needs the streaming kernels (more than 1024 voxels): refused, not run without drag
+    big = workloads.make_individual(9, workloads.full_material(11, 1), None)
+    write_voxelyze_file(sim, env, big, str(tmp_path), "s")
+    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+        eng.add_vxa_file(paths[0])
+        with pytest.raises(Exception, match="unsupported"):
+            eng.add_vxa_file(str(tmp_path / "voxelyzeFiles" / "s--id_00009.vxa"))
+            eng.step(1)
+
+
 def test_diverging_robot_is_reported_like_the_reference(eng_mod, tmp_path):
     """DtFrac far above the stability limit: the reference's Integrate() stops at the first bond stretched past 100x
     (VX_Sim.cpp:1775) and the run ends 'diverged'; same step, same verdict, and the rest of the batch is unaffected."""
