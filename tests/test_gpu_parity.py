@@ -146,6 +146,22 @@ def test_streaming_path_matches_fused_path(eng_mod, golden_dir):
             states[fused] = [eng.state(i) for i in range(len(names))]
     for a, b in zip(states[1], states[0]):
         assert np.abs(a[:, :8] - b[:, :8]).max() < 1e-12       # same kernels' math, different force-sum order
+    # _voxcad_land_water on land: same check; in a fluid the streaming kernels (no drag) must refuse, not run
+    names, states = ["lw_land6", "lw_stiff5"], {}
+    for fused in (1, 0):
+        with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+            eng.set_option("fused", fused)
+            for n in names:
+                eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))
+            eng.step(300)
+            states[fused] = [eng.state(i) for i in range(len(names))]
+    for a, b in zip(states[1], states[0]):
+        assert np.abs(a[:, :8] - b[:, :8]).max() < 1e-12
+    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+        eng.set_option("fused", 0)
+        with pytest.raises(Exception, match="unsupported"):
+            eng.add_vxa_file(os.path.join(golden_dir, "vxa", "lw_swim6.vxa"))
+            eng.step(1)
 
 
 def test_large_lattice_streaming_vs_oracle(eng_mod, tmp_path):
