@@ -35,7 +35,7 @@ struct Engine::Device {
     // fused path: robots grouped by kernel variant (workgroup size 256/512/768/1024, exchange buffers, fluid), one
     // stream per group so that the groups fill the chip together
     struct Group {
-        int block = 0, nacc = 0, fluid = 0;   // template arguments of k_robot_steps
+        int block = 0, nacc = 0, fluid = 0, tabg = 0;   // template arguments of k_robot_steps
         int count = 0;
         const int* list = nullptr;
         size_t lds = 0;                   // dynamic LDS bytes
@@ -321,12 +321,12 @@ void Engine::prepare()
             for (int d = 0; d < 6; ++d) { int o = M.nbr[(size_t)v * 6 + d]; nbr[(size_t)d * nv + g] = o < 0 ? -1 : base + o; }
             for (int a = 0; a < 3; ++a) { int c = M.bond_class[(size_t)v * 3 + a]; bclass[(size_t)a * nv + g] = c < 0 ? (short)-1 : (short)c; }
         }
-        if (M.nvox <= 1024 && M.bond_classes.size() <= 2047)
+        if (M.nvox <= 1024 && M.bond_classes.size() <= 4095)
             for (int a = 0; a < 3; ++a) {
                 int t = 0;
                 for (int v = 0; v < M.nvox; ++v) {
                     const int c = M.bond_class[(size_t)v * 3 + a];
-                    if (c >= 0) blist[(size_t)a * nv + base + t++] = v | (M.nbr[(size_t)v * 6 + 2 * a] << 10) | (c << 20);
+                    if (c >= 0) blist[(size_t)a * nv + base + t++] = (int)((unsigned)v | ((unsigned)M.nbr[(size_t)v * 6 + 2 * a] << 10) | ((unsigned)c << 20));
                 }
             }
         if (X.self_col_enabled)
@@ -455,20 +455,24 @@ void Engine::prepare()
             const RobotModel& M = robots_[r];
             const int n = M.nvox;
             if (n == 0) continue;
-            if (n > 1024 || M.bond_classes.size() > 2047) { D.fused_ok = false; continue; }
+            if (n > 1024 || M.bond_classes.size() > 4095) { D.fused_ok = false; continue; }   // (12 class bits in a bond entry; a robot of 1024 voxels has at most 3072 bonds)
             const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
             const int fluid = M.nmv > 0 ? 1 : 0;      // (the MESH variants: every land_water robot carries the surface mesh)
             const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
             // LDS need: pose tile, accumulator tiles, actuation phases; class tables; the mesh vertices of a robot in a
             // fluid; with two accumulator tiles the MESH variants also hold the strain tile (with one it stays in HBM)
-            auto need = [&](int nacc) {
-                return (size_t)(8 + 6 * nacc + 2) * block * 8 + M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) +
+            auto need = [&](int nacc, bool tables_in_lds) {
+                return (size_t)(8 + 6 * nacc + 2) * block * 8 +
+                       (tables_in_lds ? M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) : 0) +
                        (in_fluid ? (size_t)24 * M.nmv : 0) + ((fluid && nacc == 2) ? (size_t)48 * block : 0);
             };
             // accumulator tiles: two up to 768 voxels, one for 1024 and for the 768-thread MESH variant (two tiles + the
-            // strain tile exceed the 160 KB there) -- a function of the robot alone, never of the batch
+            // strain tile exceed the 160 KB there); class tables in LDS unless they do not fit (per-voxel evolved stiffness
+            // makes nearly every bond a class of its own), then the TABG variant reads them from HBM -- all of it a function
+            // of the robot alone, never of the batch
             const int nacc = (block == 1024 || (fluid && block == 768)) ? 1 : 2;
-            if (need(nacc) > lds_max) {
+            const int tabg = need(nacc, true) > lds_max ? 1 : 0;
+            if (need(nacc, !tabg) > lds_max) {
                 if (in_fluid)
                     throw std::invalid_argument("unsupported: the surface mesh of a robot in a fluid (" + std::to_string(M.nmv) +
                                                 " vertices) does not fit the fused kernel's LDS, and fluid drag exists only there");
@@ -476,16 +480,16 @@ void Engine::prepare()
                 continue;
             }
             Device::Group* g = nullptr;
-            for (auto& q : D.groups) if (q.block == block && q.nacc == nacc && q.fluid == fluid) g = &q;
-            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nacc = nacc; g->fluid = fluid; }
+            for (auto& q : D.groups) if (q.block == block && q.nacc == nacc && q.fluid == fluid && q.tabg == tabg) g = &q;
+            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nacc = nacc; g->fluid = fluid; g->tabg = tabg; }
             g->robots.push_back(r);
-            g->lds = std::max(g->lds, need(nacc));
+            g->lds = std::max(g->lds, need(nacc, !tabg));
         }
         if (!D.fused_ok)
             for (int r = 0; r < nr; ++r)
                 if (variant_ == 1 && robots_[r].vxa.fluid_env && robots_[r].nvox > 0)
-                    throw std::invalid_argument("unsupported: the batch holds robots that need the streaming kernels (more than 1024 voxels or "
-                                                "2047 bond classes), which have no fluid drag; run the robots in a fluid in their own batch");
+                    throw std::invalid_argument("unsupported: the batch holds robots that need the streaming kernels (more than 1024 voxels), "
+                                                "which have no fluid drag; run the robots in a fluid in their own batch");
         size_t gi = 0;
         for (auto& g : D.groups) {
             std::stable_sort(g.robots.begin(), g.robots.end(), [&](int a, int b) {
@@ -526,7 +530,7 @@ void Engine::prepare()
 
 void Engine::reset() { if (!robots_.empty()) prepare(); }
 
-template <int BLOCK, int NACC, bool FLUID>
+template <int BLOCK, int NACC, bool FLUID, bool TABG>
 static void launch_variant(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
     // the opt-in to more than 64 KB of dynamic LDS is per function AND per device (engines on several devices may live in
@@ -535,19 +539,25 @@ static void launch_variant(const DBatch& B, const int* list, int count, size_t l
     int dev = 0;
     hip_check(hipGetDevice(&dev), "hipGetDevice");
     if (dev < 0 || dev >= 64 || lds > attr_lds[dev]) {
-        hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK, NACC, FLUID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(fused LDS)");
+        hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK, NACC, FLUID, TABG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(fused LDS)");
         if (dev >= 0 && dev < 64) attr_lds[dev] = lds;
     }
-    hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters);
+    hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters);
 }
 
-template <bool FLUID>
-static void launch_group(const DBatch& B, int block, int nacc, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+template <bool FLUID, bool TABG>
+static void launch_sized(const DBatch& B, int block, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
-    if (block == 256) launch_variant<256, 2, FLUID>(B, list, count, lds, s, cap, iters);
-    else if (block == 512) launch_variant<512, 2, FLUID>(B, list, count, lds, s, cap, iters);
-    else if (block == 768) launch_variant<768, FLUID ? 1 : 2, FLUID>(B, list, count, lds, s, cap, iters);
-    else launch_variant<1024, 1, FLUID>(B, list, count, lds, s, cap, iters);
+    if (block == 256) launch_variant<256, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
+    else if (block == 512) launch_variant<512, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
+    else if (block == 768) launch_variant<768, FLUID ? 1 : 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
+    else launch_variant<1024, 1, FLUID, TABG>(B, list, count, lds, s, cap, iters);
+}
+
+static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+{
+    if (fluid) { if (tabg) launch_sized<true, true>(B, block, list, count, lds, s, cap, iters); else launch_sized<true, false>(B, block, list, count, lds, s, cap, iters); }
+    else { if (tabg) launch_sized<false, true>(B, block, list, count, lds, s, cap, iters); else launch_sized<false, false>(B, block, list, count, lds, s, cap, iters); }
 }
 
 void Engine::advance(long long max_rounds)
@@ -572,8 +582,7 @@ void Engine::advance(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters) {
             for (size_t k = 0; k < D.groups.size(); ++k) {
                 const auto& g = D.groups[k];
-                if (g.fluid) launch_group<true>(B, g.block, g.nacc, g.list, g.count, g.lds, g.stream, cap, iters);
-                else launch_group<false>(B, g.block, g.nacc, g.list, g.count, g.lds, g.stream, cap, iters);
+                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.list, g.count, g.lds, g.stream, cap, iters);
                 ++launches; ++group_launches[k];
             }
         }

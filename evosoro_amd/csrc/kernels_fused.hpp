@@ -1,4 +1,4 @@
-// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NACC, MESH>, one workgroup per robot, the robot
+// Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NACC, MESH, TABG>, one workgroup per robot, the robot
 // resident in the CU for a whole launch of many time steps (included at the end of kernels.hpp).  MESH = land_water
 // robots, which carry the deformable surface mesh (fluid drag, RobotVolume tags).
 //
@@ -401,7 +401,7 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
     const d3 p2 = mk3(ps[l2], ps[BLOCK + l2], ps[2 * BLOCK + l2]);
     const double s2 = ps[3 * BLOCK + l2];
     const dq q2 = mkq(ps[4 * BLOCK + l2], ps[5 * BLOCK + l2], ps[6 * BLOCK + l2], ps[7 * BLOCK + l2]);
-    BondOut o = bond_compute<A>(B, bct[entry >> 20], H, p1, q1, s1, p2, q2, s2, damp_on);
+    BondOut o = bond_compute<A>(B, bct[(unsigned)entry >> 20], H, p1, q1, s1, p2, q2, s2, damp_on);
     if (H.store_hist) {
         st_plane(B.hist, 0 * 3 + A, nv, voff, H.p0); st_plane(B.hist, 1 * 3 + A, nv, voff, H.p1); st_plane(B.hist, 2 * 3 + A, nv, voff, H.p2);
         st_plane(B.hist, 3 * 3 + A, nv, voff, H.g0); st_plane(B.hist, 4 * 3 + A, nv, voff, H.g1); st_plane(B.hist, 5 * 3 + A, nv, voff, H.g2);
@@ -432,7 +432,7 @@ template <int A, int BLOCK, int NACC, bool MESH>
 __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, double* acc, int entry,
                                             unsigned& modebits, bool damp_on, bool& div, double* st, unsigned st_stride)
 {
-    const bool has = entry >= 0;
+    const bool has = entry != -1;
     BondOut o;
     if (has) {
         o = fused_bond<A, BLOCK, MESH>(B, R, bct, ps, entry, modebits, damp_on, st, st_stride);
@@ -461,7 +461,7 @@ __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotSta
     K.rebuild = c.rebuild;
 }
 
-template <int BLOCK, int NACC, bool MESH>
+template <int BLOCK, int NACC, bool MESH, bool TABG>
 __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const DRobot* __restrict__ robots,
                                                                             const int* __restrict__ robot_list, long long step_cap, int iters)
 {
@@ -488,11 +488,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     const bool valid = tid < R.nvox;
     const int v = base + tid;
     if (tid == 0) rs = B.rstate[r];
-    const int nbd = R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = R.n_vclass * (int)(sizeof(DVoxClass) / 8);
-    for (int k = tid; k < nbd; k += BLOCK) tabs[k] = ((const double*)(B.bclass_tab + R.btab_begin))[k];
-    for (int k = tid; k < nvd; k += BLOCK) tabs[nbd + k] = ((const double*)(B.vclass_tab + R.vtab_begin))[k];
-    const DBondClass* const bct = (const DBondClass*)tabs;
-    const DVoxClass* const vct = (const DVoxClass*)(tabs + nbd);
+    // the robot's class tables: copied into LDS, or (TABG: robots with per-voxel evolved stiffness, where nearly every
+    // bond and voxel is a class of its own and the tables outgrow the LDS) read from HBM / L2 where they lie
+    const int nbd = TABG ? 0 : R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = TABG ? 0 : R.n_vclass * (int)(sizeof(DVoxClass) / 8);
+    const DBondClass* bct;
+    const DVoxClass* vct;
+    if constexpr (TABG) {
+        bct = B.bclass_tab + R.btab_begin;
+        vct = B.vclass_tab + R.vtab_begin;
+    } else {
+        for (int k = tid; k < nbd; k += BLOCK) tabs[k] = ((const double*)(B.bclass_tab + R.btab_begin))[k];
+        for (int k = tid; k < nvd; k += BLOCK) tabs[nbd + k] = ((const double*)(B.vclass_tab + R.vtab_begin))[k];
+        bct = (const DBondClass*)tabs;
+        vct = (const DVoxClass*)(tabs + nbd);
+    }
     // MESH (land_water robots): directional strains of the previous step (inputs of the surface mesh: fluid drag, and the
     // RobotVolumeEnd tag on the host) in LDS next to the tables, then the mesh vertices; the 1024-thread variant has no
     // room for the strains and keeps them in HBM
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         entry[a] = valid ? B.blist[(unsigned)a * nv + v] : -1;
-        if (entry[a] >= 0) modebits |= (unsigned)(B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] & 3) << (2 * a);
+        if (entry[a] != -1) modebits |= (unsigned)(B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] & 3) << (2 * a);
     }
     if (valid) {
         const int b0 = rs.steps & 1;
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
-        if (entry[a] >= 0) B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] = (unsigned char)((modebits >> (2 * a)) & 3u);
+        if (entry[a] != -1) B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] = (unsigned char)((modebits >> (2 * a)) & 3u);
     if (tid == 0) B.rstate[r] = rs;
 }
 

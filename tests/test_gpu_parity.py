@@ -347,6 +347,42 @@ def test_every_mesh_kernel_variant_swims_like_the_oracle(eng_mod, tmp_path):
             eng.step(1)
 
 
+def test_evolved_stiffness_on_large_robots_vs_oracle(eng_mod, tmp_path):
+    """Per-voxel evolved <Stiffness> makes nearly every bond (and voxel) a class of its own; from a few hundred voxels on
+    the class tables outgrow the LDS and the fused kernel reads them from HBM instead (TABG variants).  Both simulators,
+    small (tables in LDS) and large robots in one batch each, against the oracle; the swimmers must not lose their drag."""
+    from collections import OrderedDict
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    sim = Sim(dt_frac=0.9, simulation_time=0.02, fitness_eval_init_time=0.002)
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    for variant, env, tag, shapes in ((eng_mod.VOXCAD, Env(), "e", [(5, 5, 5), (8, 8, 8), (10, 10, 10)]),
+                                      (eng_mod.VOXCAD_LAND_WATER, env_w, "f", [(4, 4, 4), (6, 6, 6), (8, 8, 8), (10, 10, 10)])):
+        paths = []
+        for k, shape in enumerate(shapes):
+            rng = np.random.RandomState(900 + k)
+            layers = OrderedDict([("<PhaseOffset>", np.round(rng.uniform(-1, 1, size=shape), 3)),
+                                  ("<Stiffness>", np.round(10 ** rng.uniform(6.0, 7.7, size=shape), 0))])
+            write_voxelyze_file(sim, env, workloads.make_individual(k, workloads.random_material(shape, 40 + k), layers), str(tmp_path), tag)
+            paths.append(str(tmp_path / "voxelyzeFiles" / ("%s--id_%05i.vxa" % (tag, k))))
+        sims = [vo.OracleSim.from_vxa(p, variant=1 if variant == eng_mod.VOXCAD_LAND_WATER else 0) for p in paths]
+        with eng_mod.Engine(variant, 0) as eng:
+            eng.add_vxa_files(paths)
+            assert eng.dims(len(shapes) - 1)["nvox"] > 512
+            for upto in (1, 3, 40, 120):
+                eng.step(upto - sims[0].info().steps)
+                assert eng.counters().dominant_block != 0                  # fused kernels, not the streaming path
+                for i, o in enumerate(sims):
+                    o.step(upto - o.info().steps)
+                    assert _pos_err(eng.state(i), o.state(), 0.01) < FLOOR_VOX, (tag, i, upto)
+                    assert np.abs(eng.state(i)[:, 3:14] - o.state()[:, 3:14]).max() < 1e-7, (tag, i, upto)
+
+
 def test_diverging_robot_is_reported_like_the_reference(eng_mod, tmp_path):
     """DtFrac far above the stability limit: the reference's Integrate() stops at the first bond stretched past 100x
     (VX_Sim.cpp:1775) and the run ends 'diverged'; same step, same verdict, and the rest of the batch is unaffected."""
@@ -519,11 +555,13 @@ def test_parameter_sweep_vs_oracle(eng_mod, tmp_path):
     from evosoro_amd.base import Sim, Env
     from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
     from oracle import vxoracle as vo
-    rng = np.random.RandomState(2024)
+    # (VXH_SWEEP_SEED / _COUNT / _MAXDIM: wider one-off campaigns with the same generator)
+    count, maxdim = int(os.environ.get("VXH_SWEEP_COUNT", "24")), int(os.environ.get("VXH_SWEEP_MAXDIM", "7"))
+    rng = np.random.RandomState(int(os.environ.get("VXH_SWEEP_SEED", "2024")))
     os.makedirs(tmp_path / "voxelyzeFiles")
     paths = []
-    for k in range(24):
-        shape = tuple(int(n) for n in rng.randint(2, 7, size=3))
+    for k in range(count):
+        shape = tuple(int(n) for n in rng.randint(2, maxdim, size=3))
         sim = Sim(dt_frac=float(np.round(rng.uniform(0.3, 0.95), 2)), simulation_time=0.05,
                   fitness_eval_init_time=float(np.round(rng.uniform(0.0, 0.01), 3)),
                   self_collisions_enabled=bool(rng.randint(2)), min_temp_fact=float(np.round(rng.uniform(0.1, 0.6), 2)))
@@ -560,7 +598,7 @@ def test_parameter_sweep_vs_oracle(eng_mod, tmp_path):
                 tol = FLOOR_VOX if upto <= 20 else max(FLOOR_VOX, 20 * spreads[i])
                 err = _pos_err(eng.state(i), o.state(), lat)
                 assert err <= tol, (i, upto, err, tol, paths[i])
-    assert sum(1 for sp in spreads if sp < 1e-10) >= 18      # the strict bar applied to most of them
+    assert sum(1 for sp in spreads if sp < 1e-10) >= 0.75 * count      # the strict bar applied to most of them
 
 
 def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
@@ -571,11 +609,12 @@ def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
     from evosoro_amd.base import Sim, Env
     from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
     from oracle import vxoracle as vo
-    rng = np.random.RandomState(777)
+    count, maxdim = int(os.environ.get("VXH_SWEEP_COUNT", "16")), int(os.environ.get("VXH_SWEEP_MAXDIM", "7"))
+    rng = np.random.RandomState(int(os.environ.get("VXH_SWEEP_SEED", "777")))
     os.makedirs(tmp_path / "voxelyzeFiles")
     paths = []
-    for k in range(16):
-        shape = tuple(int(n) for n in rng.randint(2, 7, size=3))
+    for k in range(count):
+        shape = tuple(int(n) for n in rng.randint(2, maxdim, size=3))
         sim = Sim(dt_frac=float(np.round(rng.uniform(0.3, 0.95), 2)), simulation_time=0.05,
                   fitness_eval_init_time=float(np.round(rng.uniform(0.0, 0.01), 3)), self_collisions_enabled=bool(rng.randint(2)))
         env = Env(frequency=float(np.round(rng.uniform(2, 8), 1)), gravity_enabled=int(rng.randint(2)), temp_enabled=int(rng.randint(2)),
@@ -603,4 +642,4 @@ def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
                 tol = FLOOR_VOX if upto <= 20 else max(FLOOR_VOX, 20 * spreads[i])
                 err = _pos_err(eng.state(i), o.state(), models[i]["lattice_dim"])
                 assert err <= tol, (i, upto, err, tol, paths[i])
-    assert sum(1 for sp in spreads if sp < 1e-10) >= 12
+    assert sum(1 for sp in spreads if sp < 1e-10) >= 0.75 * count
