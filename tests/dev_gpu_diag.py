@@ -194,7 +194,7 @@ if __name__ == "__main__" and "spl" in sys.argv[1:]:
         timing2(512, (10, 10, 10), 0.05, True, {"fused": 1, "steps_per_launch": spl})
 
 
-def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel_phase=False, phases=False):
+def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel_phase=False, phases=False, stiffness=False):
     """BASELINE configs[3]/[4]: throughput of other workloads (not the bench line)"""
     from collections import OrderedDict
     tmp = tempfile.mkdtemp()
@@ -208,6 +208,9 @@ def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel
             extra = None
             if per_voxel_phase:
                 extra = OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(i).uniform(-1, 1, size=shape), 3))])
+            if stiffness:      # per-voxel evolved stiffness: nearly every bond its own class (TABG kernel variants from ~300 voxels on)
+                extra = extra or OrderedDict()
+                extra["<Stiffness>"] = np.round(10 ** np.random.RandomState(1000 + i).uniform(6.0, 7.7, size=shape), 0)
             ind = workloads.make_individual(i, mat, extra)
             write_voxelyze_file(sim, env, ind, tmp, "t")
             eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "t--id_%05i.vxa" % i))
@@ -233,6 +236,13 @@ if __name__ == "__main__" and "lwcfgs" in sys.argv[1:]:
     timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.05, env_w, {}, per_voxel_phase=True)
     timing_cfg(engine.VOXCAD_LAND_WATER, 512, (10, 10, 10), 0.03, env_w, {}, per_voxel_phase=True)
     timing_cfg(engine.VOXCAD_LAND_WATER, 256, (10, 10, 10), 0.02, env_w, {}, full=True, per_voxel_phase=True)
+
+
+if __name__ == "__main__" and "stiffcfgs" in sys.argv[1:]:
+    timing_cfg(engine.VOXCAD, 512, (6, 6, 6), 0.03, Env(), {}, stiffness=True)
+    timing_cfg(engine.VOXCAD, 512, (8, 8, 8), 0.03, Env(), {}, stiffness=True)
+    timing_cfg(engine.VOXCAD, 512, (10, 10, 10), 0.02, Env(), {}, stiffness=True)
+    timing_cfg(engine.VOXCAD, 512, (10, 10, 10), 0.02, Env(), {})
 
 
 if __name__ == "__main__" and "cfgs" in sys.argv[1:]:
