@@ -234,6 +234,9 @@ void Engine::prepare()
         D.max_nvox = std::max(D.max_nvox, robots_[r].nvox);
     }
     if (nv == 0) nv = 64;
+    // the kernels address a component plane as 32-bit `plane * nv + slot` (up to 36 planes of bond slots)
+    if ((long long)nv * 36 >= (1LL << 32))
+        throw std::invalid_argument("batch too large for one engine (" + std::to_string(nv) + " voxel slots; limit 119 million): split the population");
     D.total_surf = ns;
 
     std::vector<int> wave_robot(nv / 64, -1), nbr((size_t)6 * nv, -1), surf(std::max(ns, 1), 0), surf_ord(nv, -1);
