@@ -110,6 +110,16 @@ def cases():
         out["bench10_%d" % k] = dict(variant="land", early=False,
                                      sim=Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.05),
                                      env=Env(), ind=workloads.random_robot(20 + k, (10, 10, 10), k))
+    # ---- _voxcad_land_water at BASELINE configs[2] size: a random 10x10x10 swimmer (~700 voxels: the fused kernel's
+    # 768-thread MESH variant) and a full 10x10x10 lattice walking on land (1000 voxels: the 1024-thread one); final
+    # state and result XML (RobotVolumeEnd from the strains of the last step) only
+    phase10 = np.round(np.random.RandomState(17).uniform(-1, 1, size=(10, 10, 10)), 3)
+    out["lw_swim10"] = dict(variant="lw", early=False, sim=Sim(dt_frac=0.9, simulation_time=0.1, fitness_eval_init_time=0.0),
+                            env=env_w, ind=workloads.make_individual(30, workloads.random_material((10, 10, 10), 61),
+                                                                     OrderedDict([("<PhaseOffset>", phase10)])))
+    out["lw_land10"] = dict(variant="lw", early=False, sim=Sim(dt_frac=0.9, simulation_time=0.1, fitness_eval_init_time=0.02),
+                            env=Env(), ind=workloads.make_individual(31, workloads.full_material(10, 62),
+                                                                     OrderedDict([("<PhaseOffset>", phase10)])))
     return out
 
 

@@ -71,7 +71,11 @@ def test_full_run_final_state_and_result(golden_dir, name):
         assert "%.6g" % getattr(result, field) == "%.6g" % expected[tag], tag
 
 
-@pytest.mark.parametrize("name", LW_CASES)
+# BASELINE configs[2] size in _voxcad_land_water: a ~700-voxel swimmer and a full 10x10x10 lattice on land (final state + XML)
+LW_BIG_CASES = ["lw_swim10", "lw_land10"]
+
+
+@pytest.mark.parametrize("name", LW_CASES + LW_BIG_CASES)
 def test_land_water_full_run(golden_dir, name):
     trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".final.bin"))
     sim = _sim(golden_dir, name)
