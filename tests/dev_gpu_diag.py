@@ -236,6 +236,9 @@ if __name__ == "__main__" and "lwcfgs" in sys.argv[1:]:
     timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.05, env_w, {}, per_voxel_phase=True)
     timing_cfg(engine.VOXCAD_LAND_WATER, 512, (10, 10, 10), 0.03, env_w, {}, per_voxel_phase=True)
     timing_cfg(engine.VOXCAD_LAND_WATER, 256, (10, 10, 10), 0.02, env_w, {}, full=True, per_voxel_phase=True)
+    # the same simulator on land (no drag; the MESH variants still record the strains for the RobotVolumeEnd tag)
+    timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.05, Env(), {}, per_voxel_phase=True)
+    timing_cfg(engine.VOXCAD_LAND_WATER, 512, (10, 10, 10), 0.03, Env(), {}, per_voxel_phase=True)
 
 
 if __name__ == "__main__" and "stiffcfgs" in sys.argv[1:]:
