@@ -464,16 +464,17 @@ void Engine::prepare()
             const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
             // LDS need: pose tile, accumulator tiles, actuation phases; class tables; the mesh vertices of a robot in a
             // fluid; with two accumulator tiles the MESH variants also hold the strain tile (with one it stays in HBM)
+            // (mirrors the layout at the top of k_robot_steps; SLIM = the 768-thread MESH variant, phases and strains in HBM)
+            const bool slim = fluid && block == 768;
             auto need = [&](int nacc, bool tables_in_lds) {
-                return (size_t)(8 + 6 * nacc + 2) * block * 8 +
+                return (size_t)(8 + 6 * nacc + (slim ? 0 : 2)) * block * 8 +
                        (tables_in_lds ? M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) : 0) +
-                       (in_fluid ? (size_t)24 * M.nmv : 0) + ((fluid && nacc == 2) ? (size_t)48 * block : 0);
+                       (in_fluid ? (size_t)24 * M.nmv : 0) + ((fluid && nacc == 2 && !slim) ? (size_t)48 * block : 0);
             };
-            // accumulator tiles: two up to 768 voxels, one for 1024 and for the 768-thread MESH variant (two tiles + the
-            // strain tile exceed the 160 KB there); class tables in LDS unless they do not fit (per-voxel evolved stiffness
-            // makes nearly every bond a class of its own), then the TABG variant reads them from HBM -- all of it a function
-            // of the robot alone, never of the batch
-            const int nacc = (block == 1024 || (fluid && block == 768)) ? 1 : 2;
+            // accumulator tiles: two up to 768 voxels, one for 1024; class tables in LDS unless they do not fit (per-voxel
+            // evolved stiffness makes nearly every bond a class of its own), then the TABG variant reads them from HBM -- all
+            // of it a function of the robot alone, never of the batch
+            const int nacc = block == 1024 ? 1 : 2;
             const int tabg = need(nacc, true) > lds_max ? 1 : 0;
             if (need(nacc, !tabg) > lds_max) {
                 if (in_fluid)
@@ -553,7 +554,7 @@ static void launch_sized(const DBatch& B, int block, const int* list, int count,
 {
     if (block == 256) launch_variant<256, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
     else if (block == 512) launch_variant<512, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
-    else if (block == 768) launch_variant<768, FLUID ? 1 : 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
+    else if (block == 768) launch_variant<768, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
     else launch_variant<1024, 1, FLUID, TABG>(B, list, count, lds, s, cap, iters);
 }
 

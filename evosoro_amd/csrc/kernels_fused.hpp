@@ -228,8 +228,8 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
     // Phase 1.  Every vertex is the mean of the voxel corners that meet in it, corner = Pos + R(Angle) * offset, summed in
     // corner-code order (the reference: in voxel order; § Numerics).  GATHER: every voxel rotates its own eight corner
     // offsets into the tile, four (twelve planes) or two (six planes) at a time, and the vertices gather them.  The
-    // 1024-thread variant, short of registers, is faster when every vertex recomputes its corners itself (same operations):
-    // measured 42.4 against 46.5 us per step on dense 10^3 swimmers, the 768-thread variant 72.1 (gather) against 77.9.
+    // 1024-thread variant (six planes, short of registers) is faster when every vertex recomputes its corners itself (same
+    // operations): measured 42.4 against 46.5 us per step on dense 10^3 swimmers.
     constexpr bool GATHER = BLOCK < 1024;
     if constexpr (GATHER) {
         d3 vp = mk3(0, 0, 0), hp = mk3(0, 0, 0), hn = mk3(0, 0, 0);
@@ -468,8 +468,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     extern __shared__ __align__(16) double lds[];
     double* const ps = lds;
     double* const acc = lds + 8 * BLOCK;
-    double* const pht = acc + NACC * 6 * BLOCK;    // sin / cos of every voxel's actuation phase, [2][BLOCK]
-    double* const tabs = pht + 2 * BLOCK;
+    // the 768-thread MESH variant is SLIM: actuation phases and strains stay in HBM, so that two accumulator tiles and the
+    // mesh vertices fit into the 160 KB
+    constexpr bool SLIM = MESH && BLOCK == 768;
+    double* const pht = acc + NACC * 6 * BLOCK;    // sin / cos of every voxel's actuation phase, [2][BLOCK] (not SLIM)
+    double* const tabs = pht + (SLIM ? 0 : 2 * BLOCK);
     // the robot's mutable control block lives in LDS for the whole launch: the per-step control is a serial chain
     // of ~20 dependent accesses executed by one thread while the workgroup waits, so it must not touch HBM
     __shared__ DRobotState rs;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // MESH (land_water robots): directional strains of the previous step (inputs of the surface mesh: fluid drag, and the
     // RobotVolumeEnd tag on the host) in LDS next to the tables, then the mesh vertices; the 1024-thread variant has no
     // room for the strains and keeps them in HBM
-    constexpr bool STRAIN_LDS = MESH && NACC == 2;
+    constexpr bool STRAIN_LDS = MESH && NACC == 2 && !SLIM;
     double* const st = STRAIN_LDS ? tabs + nbd + nvd : B.strain + R.vox_begin;
     const unsigned st_stride = STRAIN_LDS ? (unsigned)BLOCK : nv;
     double* const mesh = tabs + nbd + nvd + (STRAIN_LDS ? 6 * BLOCK : 0);
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         const int b0 = rs.steps & 1;
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
         amp_damp = B.amp_damp[v];
-        pht[tid] = B.act_sb[v]; pht[BLOCK + tid] = B.act_cb[v];
+        if constexpr (!SLIM) { pht[tid] = B.act_sb[v]; pht[BLOCK + tid] = B.act_cb[v]; }
         lm = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v));
         am = mk3(ANGMOM(0, v), ANGMOM(1, v), ANGMOM(2, v));
         ps[tid] = POS(b0, 0, v); ps[BLOCK + tid] = POS(b0, 1, v); ps[2 * BLOCK + tid] = POS(b0, 2, v); ps[3 * BLOCK + tid] = SCALE(b0, v);
@@ -604,7 +607,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             S.lm = lm; S.am = am;
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, fluid, drag, pht[tid], pht[BLOCK + tid], amp_damp);
+            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, fluid, drag,
+                                SLIM ? B.act_sb[vv] : pht[tid], SLIM ? B.act_cb[vv] : pht[BLOCK + tid], amp_damp);
             lm = S.lm; am = S.am;
         }
         if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
