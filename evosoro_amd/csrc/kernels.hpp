@@ -7,7 +7,7 @@
 //   voxel_update    CVXS_Voxel::EulerStep / CalcTotalForce / CalcTotalMoment / CalcFloorEffect (VXS_Voxel.cpp:169-758),
 //                   CVXS_BondCollision::CalcContactForce (VXS_BondCollision.cpp:41-59), MaxVoxVel of UpdateStats
 // Two launch shapes share those device functions:
-//   k_robot_steps<BLOCK,NACC,FLUID>  fused path (kernels_fused.hpp): ONE workgroup per robot (robots up to BLOCK voxels),
+//   k_robot_steps<BLOCK,NACC,MESH,TABG>  fused path (kernels_fused.hpp): ONE workgroup per robot (robots up to BLOCK voxels),
 //                         the robot RESIDENT in the CU for a whole launch of many time steps: voxel momenta in registers,
 //                         poses and force accumulators in LDS, bonds taken from per-axis compacted lists.  Per step only
 //                         the bond history crosses L2/HBM.

@@ -1,6 +1,7 @@
 // Fused path of the batched Voxelyze stepper: k_robot_steps<BLOCK, NACC, MESH, TABG>, one workgroup per robot, the robot
 // resident in the CU for a whole launch of many time steps (included at the end of kernels.hpp).  MESH = land_water
-// robots, which carry the deformable surface mesh (fluid drag, RobotVolume tags).
+// robots, which carry the deformable surface mesh (fluid drag, RobotVolume tags); TABG = the robot's class tables are read
+// from HBM instead of being copied into LDS (robots with per-voxel evolved stiffness, whose tables outgrow it).
 //
 // A step has two kinds of work items mapped onto the same threads:
 //   voxels  thread t owns voxel t: its momenta stay in registers for the whole launch, its pose is published in LDS;
@@ -18,9 +19,9 @@
 //                          the reference's summation order +X -X +Y -Y +Z -Z.
 //                          Also scratch of latch / broad-phase between steps (re-zeroed by the voxel phase).
 //   pht  [2][BLOCK]        sin / cos of 2 pi' * PhaseOffset of every voxel (constants of the launch; kept out of registers
-//                          and out of the step's load queue)
-//   tabs                   this robot's DBondClass and DVoxClass rows
-//   st   [6][BLOCK]        MESH, BLOCK < 1024: directional strains of the previous step (DBatch::strain otherwise)
+//                          and out of the step's load queue; read from HBM by the 768-thread MESH variant)
+//   tabs                   this robot's DBondClass and DVoxClass rows (not TABG)
+//   st   [6][BLOCK]        MESH, BLOCK <= 512: directional strains of the previous step (DBatch::strain otherwise)
 //   mesh [3][nmv]          MESH only: vertices of the drag mesh (robots in a fluid)
 #pragma once
 
