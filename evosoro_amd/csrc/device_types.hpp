@@ -105,7 +105,14 @@ struct DBatch {
     const int* facet_vert;            // [3][total_facet] its three robot-local mesh vertices
     const int* facet_first;           // [nv] first facet of the voxel, relative to the robot's facet_begin
     const unsigned char* facet_count; // [nv]
-    double* strain;                   // [6][nv] StrainPosDirsCur xyz, StrainNegDirsCur xyz (fluid robots only)
+    double* strain;                   // [6][nv] StrainPosDirsCur xyz, StrainNegDirsCur xyz (land_water robots only)
+    // streaming kernels only (robots in a fluid that do not fit the resident kernel): mesh in HBM
+    int n_mv, n_facet;                // real counts (total_mv / total_facet are the plane strides, >= 1)
+    const int* vert_vox;              // [8][total_mv] global voxel slot touching the vertex with corner code c, or -1
+    const int* vert_robot;            // [total_mv]
+    const int* facet_robot;           // [total_facet]
+    double* mesh_pos;                 // [3][total_mv] current vertex positions
+    double* fdrag;                    // [3][total_facet] drag of every facet in the current step
     unsigned long long* prof;         // developer builds (-DVXH_PHASE_TIMING): per-wave phase cycle sums, else null
     // constants from Vec3D.h evaluated by the host libm (thresholds of the small-angle logic)
     double small_angle_w, smallish_angle_w, slthresh_acos2sqrt;

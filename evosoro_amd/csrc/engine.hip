@@ -47,6 +47,7 @@ struct Engine::Device {
     std::vector<hipStream_t> group_streams;   // created on demand, reused across prepare() calls
     std::vector<hipEvent_t> group_events;
     bool fused_ok = true;                 // every robot fits the fused kernel's LDS budget
+    bool any_fluid = false;               // some robot is in a fluid: the streaming rounds include the drag kernels
     std::vector<void*> allocs;
     DBatch B{};
     std::vector<DRobot> h_robot;
@@ -257,12 +258,17 @@ void Engine::prepare()
     bool any_mesh = false;
     for (int r = 0; r < nr; ++r) { mv_begin[r] = total_mv; total_mv += robots_[r].nmv; any_mesh = any_mesh || robots_[r].nmv > 0; }
     std::vector<int> vert_pack((size_t)3 * std::max(total_mv, 1), 0);
+    // robots in a fluid: the same mesh with global indices for the streaming kernels (robots that do not fit the resident one)
+    bool any_fluid = false;
+    for (int r = 0; r < nr; ++r) any_fluid = any_fluid || (variant_ == 1 && robots_[r].vxa.fluid_env && robots_[r].nmv > 0);
+    std::vector<int> vert_vox(any_fluid ? (size_t)8 * std::max(total_mv, 1) : 8, -1), vert_robot(any_fluid ? std::max(total_mv, 1) : 1, 0);
     std::vector<double> vert_v0((size_t)3 * std::max(total_mv, 1), 0.0);
     int total_facet = 0;
     std::vector<int> facet_begin(nr, 0);
     for (int r = 0; r < nr; ++r) { facet_begin[r] = total_facet; total_facet += (int)robots_[r].facet_vox.size(); }
     std::vector<int> facet_vox(std::max(total_facet, 1), 0), facet_vert((size_t)3 * std::max(total_facet, 1), 0), facet_first(any_mesh ? nv : 1, 0);
     std::vector<unsigned char> facet_count(any_mesh ? nv : 1, 0);
+    std::vector<int> facet_robot(any_fluid ? std::max(total_facet, 1) : 1, 0);
     std::vector<DRobotState> rstate(nr);
 
     // offsets of the per-robot pieces of the shared tables, then the robots are assembled on the host cores (disjoint ranges)
@@ -271,8 +277,6 @@ void Engine::prepare()
     for (int r = 0; r < nr; ++r) {
         const RobotModel& M = robots_[r];
         if (M.vox_classes.size() > 32767 || M.bond_classes.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one robot");
-        if (M.vxa.fluid_env && variant_ == 1 && (M.nvox > 1024 || !fused_))
-            throw std::invalid_argument("unsupported: fluid drag needs the fused path (robots of at most 1024 voxels)");
         vtab_off[r + 1] = vtab_off[r] + (int)M.vox_classes.size();
         btab_off[r + 1] = btab_off[r] + (int)M.bond_classes.size();
         excl_off[r + 1] = excl_off[r] + (M.vxa.self_col_enabled ? (long long)M.nsurf * ((M.nsurf + 63) / 64) : 0);
@@ -363,6 +367,7 @@ void Engine::prepare()
         R.facet_begin = facet_begin[r]; R.nfacet = (int)M.facet_vox.size();
         for (size_t f = 0; f < M.facet_vox.size(); ++f) {
             facet_vox[facet_begin[r] + f] = M.facet_vox[f];
+            if (any_fluid) facet_robot[facet_begin[r] + f] = r;
             for (int k = 0; k < 3; ++k) facet_vert[(size_t)k * std::max(total_facet, 1) + facet_begin[r] + f] = M.facet_vert[f * 3 + k];
         }
         R.vtab_begin = vtab_begin; R.n_vclass = (int)M.vox_classes.size(); R.btab_begin = btab_begin; R.n_bclass = (int)M.bond_classes.size();
@@ -378,6 +383,13 @@ void Engine::prepare()
                     w[2] |= 1u << (20 + corner);
                 }
                 for (int k = 0; k < 3; ++k) vert_pack[k * tm + mv_begin[r] + i] = (int)w[k];
+                if (any_fluid) {
+                    vert_robot[mv_begin[r] + i] = r;
+                    for (int q = 0; q < 8; ++q) {
+                        const int c = M.vert_comp[(size_t)i * 8 + q];
+                        if (c >= 0) vert_vox[(size_t)(c & 7) * tm + mv_begin[r] + i] = base + (c >> 3);
+                    }
+                }
                 for (int k = 0; k < 3; ++k) vert_v0[k * tm + mv_begin[r] + i] = M.vert_v0[(size_t)i * 3 + k];
             }
             for (int v = 0; v < M.nvox; ++v) {
@@ -445,6 +457,13 @@ void Engine::prepare()
     B.facet_first = D.upload(facet_first);
     B.facet_count = D.upload(facet_count);
     B.strain = D.alloc_zero<double>(any_mesh ? (size_t)6 * nv : 1);
+    B.n_mv = total_mv; B.n_facet = total_facet;
+    B.vert_vox = D.upload(vert_vox);
+    B.vert_robot = D.upload(vert_robot);
+    B.facet_robot = D.upload(facet_robot);
+    B.mesh_pos = D.alloc_zero<double>(any_fluid ? (size_t)3 * std::max(total_mv, 1) : 1);
+    B.fdrag = D.alloc_zero<double>(any_fluid ? (size_t)3 * std::max(total_facet, 1) : 1);
+    D.any_fluid = any_fluid;
     B.col_rows = std::max(ns, 1);
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
@@ -476,24 +495,13 @@ void Engine::prepare()
             // of it a function of the robot alone, never of the batch
             const int nacc = block == 1024 ? 1 : 2;
             const int tabg = need(nacc, true) > lds_max ? 1 : 0;
-            if (need(nacc, !tabg) > lds_max) {
-                if (in_fluid)
-                    throw std::invalid_argument("unsupported: the surface mesh of a robot in a fluid (" + std::to_string(M.nmv) +
-                                                " vertices) does not fit the fused kernel's LDS, and fluid drag exists only there");
-                D.fused_ok = false;
-                continue;
-            }
+            if (need(nacc, !tabg) > lds_max) { D.fused_ok = false; continue; }   // (e.g. a mesh with thousands of vertices)
             Device::Group* g = nullptr;
             for (auto& q : D.groups) if (q.block == block && q.nacc == nacc && q.fluid == fluid && q.tabg == tabg) g = &q;
             if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nacc = nacc; g->fluid = fluid; g->tabg = tabg; }
             g->robots.push_back(r);
             g->lds = std::max(g->lds, need(nacc, !tabg));
         }
-        if (!D.fused_ok)
-            for (int r = 0; r < nr; ++r)
-                if (variant_ == 1 && robots_[r].vxa.fluid_env && robots_[r].nvox > 0)
-                    throw std::invalid_argument("unsupported: the batch holds robots that need the streaming kernels (more than 1024 voxels), "
-                                                "which have no fluid drag; run the robots in a fluid in their own batch");
         size_t gi = 0;
         for (auto& g : D.groups) {
             std::stable_sort(g.robots.begin(), g.robots.end(), [&](int a, int b) {
@@ -595,6 +603,10 @@ void Engine::advance(long long max_rounds)
         const int nb_b = (3 * B.nv + 255) / 256, nb_v = (B.nv + 255) / 256;
         auto round = [&](long long c) {
             hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, c, 1);
+            if (D.any_fluid) {
+                hipLaunchKernelGGL(k_mesh_vertices, dim3((B.n_mv + 255) / 256), dim3(256), 0, D.stream, B);
+                hipLaunchKernelGGL(k_facets, dim3((B.n_facet + 255) / 256), dim3(256), 0, D.stream, B);
+            }
             hipLaunchKernelGGL(k_bonds, dim3(nb_b + D.reb_blocks), dim3(256), 0, D.stream, B, nb_b, D.reb_robot, D.reb_i0);
             hipLaunchKernelGGL(k_voxels, dim3(nb_v), dim3(256), 0, D.stream, B);
         };
@@ -613,7 +625,7 @@ void Engine::advance(long long max_rounds)
         }
         for (; launched < todo; ++launched) round(cap);
         hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, cap, 0);   // finish the last step
-        launches = 3 * todo + 1;
+        launches = (D.any_fluid ? 5 : 3) * todo + 1;
     }
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(D.ev1, D.stream));
@@ -716,10 +728,10 @@ void Engine::download()
             H.scale[v] = plane(4 * b + 3)[base + v];
         }
     }
-    // land_water robots stepped by the fused kernel: directional strains of the last step (RobotVolumeEnd)
+    // land_water robots: directional strains of the last step (RobotVolumeEnd)
     bool any_mesh = false;
     for (int r = 0; r < nr; ++r) any_mesh = any_mesh || robots_[r].nmv > 0;
-    if (any_mesh && fused_ && D.fused_ok) {
+    if (any_mesh) {
         std::vector<double> st((size_t)6 * nv);
         HIP_OK(hipMemcpy(st.data(), B.strain, sizeof(double) * st.size(), hipMemcpyDeviceToHost));
         for (int r = 0; r < nr; ++r) {

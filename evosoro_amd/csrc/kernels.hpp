@@ -340,6 +340,57 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     return o;
 }
 
+// ---- land_water surface mesh and fluid drag (LW/VX_Sim.cpp:1516-1597), arithmetic shared by the resident kernel
+// (kernels_fused.hpp: fused_drag) and the streaming kernels (k_mesh_vertices / k_facets below).  Every deformable surface
+// vertex = mean over the <= 7 voxels touching that lattice corner of Pos + R(Angle) * corner offset, corner offsets from the
+// bond strains of the PREVIOUS step (CornerPosCur/CornerNegCur, LW/VXS_Voxel.cpp:472-475; GetCurVLoc
+// LW/VX_MeshUtil.cpp:388-428); every voxel sums the quadratic drag of the two triangles on each of its exposed faces, in the
+// reference's facet order.
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 normalized3(d3 a) { const double l = vsqrt_nn(len2(a)); return l > 0 ? a * vrcp(l) : a; }
+
+// CQuat::RotateVec3D (Vec3D.h:293-299) as a matrix: q f q* = M f for a unit quaternion (|q| = 1 to rounding).  A voxel's eight
+// mesh corners go through the same rotation, so it is expanded once per voxel (§ Numerics).
+struct RotFwd {
+    double m[9];
+    __device__ __forceinline__ RotFwd() {}
+    __device__ __forceinline__ explicit RotFwd(dq q)
+    {
+        const double x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+        const double xx = q.x * x2, yy = q.y * y2, zz = q.z * z2, xy = q.x * y2, xz = q.x * z2, yz = q.y * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+        m[0] = 1 - (yy + zz); m[1] = xy - wz; m[2] = xz + wy;
+        m[3] = xy + wz; m[4] = 1 - (xx + zz); m[5] = yz - wx;
+        m[6] = xz - wy; m[7] = yz + wx; m[8] = 1 - (xx + yy);
+    }
+    __device__ __forceinline__ d3 operator()(d3 f) const
+    { return mk3(m[0] * f.x + m[1] * f.y + m[2] * f.z, m[3] * f.x + m[4] * f.y + m[5] * f.z, m[6] * f.x + m[7] * f.y + m[8] * f.z); }
+};
+
+
+// drag of one facet (A, Bv, Cv) on its voxel moving with `speed` (sdir = speed normalised)
+__device__ __forceinline__ d3 facet_drag_force(d3 speed, d3 sdir, d3 A, d3 Bv, d3 Cv, double drag_coef)
+{
+    const d3 AB = Bv - A, AC = Cv - A;
+    const d3 cr = cross3(AB, AC);
+    const double cl = vsqrt_nn(len2(cr));
+    const double area = cl * 0.5;
+    const d3 n = cl > 0 ? cr * vrcp(cl) : cr;           // CalcFaceNormals; the reference normalises the stored normal
+                                                        // twice more before using it: identity to an ulp, skipped
+    // LW/VX_Sim.cpp:1556-1559 tests (float)acos(c) < PI/2 with c = v^ . n^.  The largest float below PI/2 is
+    // 1.57079625 and acos(c) rounds to it or below iff acos(c) <= 1.570796310901641845703125 (the midpoint
+    // to the next float, a tie going to the even mantissa below), i.e. iff c >= cos(midpoint); c > 1
+    // (two parallel unit vectors, rounding) makes the reference's acos a NaN and the facet drag-free.
+    const double c = dot3(sdir, n);
+    d3 contrib = mk3(0, 0, 0);
+    if (c >= 1.5893254773528196e-08 && c <= 1.0) {
+        const d3 proj = n * dot3(speed, n);             // ProjectOnTo
+        // proj^ * (-k * area * |proj|^2) = proj * (-k * area * |proj|)
+        contrib = proj * (-drag_coef * area * vsqrt_nn(len2(proj)));
+    }
+    return contrib;
+}
+
 struct VoxState { d3 pos, lm, am; dq ang; double scale; };
 
 // position + scale of another voxel of the same robot, for the contact forces
@@ -699,10 +750,66 @@ __device__ __forceinline__ void stream_bond(const DBatch& B, const DRobot& R, co
     BondOut o = bond_compute<A>(B, B.bclass_tab[R.btab_begin + bc], H, p1, q1, sc1, p2, q2, sc2, rs.dt_prev != 0);
     store_bond_hist(B, slot, H, old_flags);
     if (o.diverged) atomicOr(&B.rstate[r].diverged, 1);
+    if (R.nmv > 0) {      // land_water: CurStrainV1 / CurStrainV2 (SetStrainDir), inputs of the surface mesh in the next step
+        B.strain[(unsigned)A * B.nv + v1] = o.strain1;
+        B.strain[(unsigned)(3 + A) * B.nv + v2] = o.strain2;
+    }
     BOUT(0, slot) = o.f1.x; BOUT(1, slot) = o.f1.y; BOUT(2, slot) = o.f1.z;
     BOUT(3, slot) = o.m1.x; BOUT(4, slot) = o.m1.y; BOUT(5, slot) = o.m1.z;
     BOUT(6, slot) = o.f2.x; BOUT(7, slot) = o.f2.y; BOUT(8, slot) = o.f2.z;
     BOUT(9, slot) = o.m2.x; BOUT(10, slot) = o.m2.y; BOUT(11, slot) = o.m2.z;
+}
+
+// Fluid drag of the streaming path (robots in a fluid that do not fit the resident kernel): the surface mesh of the step,
+// one thread per vertex, then one thread per facet; k_voxels adds up each voxel's facets.  Launched between k_step_begin
+// and k_bonds: the strains read here are those of the previous step, the poses and momenta those at the start of this one.
+__global__ __launch_bounds__(256) void k_mesh_vertices(DBatch B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.n_mv) return;
+    const int r = B.vert_robot[i];
+    const DRobot& R = B.robot[r];
+    const DRobotState& rs = B.rstate[r];
+    if (!(R.flags & RF_FLUID) || !rs.active) return;
+    const int cur = rs.steps & 1;
+    const unsigned tm = B.total_mv, nv = B.nv;
+    const double nom = R.lat;
+    d3 part = mk3(0, 0, 0);
+    int count = 0;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {              // corner-code order, as in fused_drag
+        const int g = B.vert_vox[(unsigned)corner * tm + i];
+        if (g < 0) continue;
+        const double hx = (1 + B.strain[((corner & 4) ? 0u : 3u) * nv + g]) * nom * 0.5;     // CornerPosCur / CornerNegCur
+        const double hy = (1 + B.strain[((corner & 2) ? 1u : 4u) * nv + g]) * nom * 0.5;
+        const double hz = (1 + B.strain[((corner & 1) ? 2u : 5u) * nv + g]) * nom * 0.5;
+        const RotFwd M(mkq(QUAT(0, g), QUAT(1, g), QUAT(2, g), QUAT(3, g)));
+        part = part + (mk3(POS(cur, 0, g), POS(cur, 1, g), POS(cur, 2, g)) + M(mk3((corner & 4) ? hx : -hx, (corner & 2) ? hy : -hy, (corner & 1) ? hz : -hz)));
+        ++count;
+    }
+    const double inv = vrcp((double)count);
+    const d3 v0 = mk3(B.vert_v0[i], B.vert_v0[tm + i], B.vert_v0[2u * tm + i]);
+    const d3 np = part * inv;
+    const d3 now = v0 + (np - v0);                            // v + DrawOffset, as the reference stores it
+    B.mesh_pos[i] = now.x; B.mesh_pos[tm + i] = now.y; B.mesh_pos[2u * tm + i] = now.z;
+}
+
+__global__ __launch_bounds__(256) void k_facets(DBatch B)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= B.n_facet) return;
+    const int r = B.facet_robot[f];
+    const DRobot& R = B.robot[r];
+    const DRobotState& rs = B.rstate[r];
+    if (!(R.flags & RF_FLUID) || !rs.active) return;
+    const unsigned tm = B.total_mv, tf = B.total_facet;
+    const int u = R.vox_begin + B.facet_vox[f];
+    const d3 speed = mk3(LINMOM(0, u), LINMOM(1, u), LINMOM(2, u)) * B.vclass_tab[R.vtab_begin + B.vclass[u]].mass_inv;
+    const unsigned ia = R.vert_begin + B.facet_vert[f], ib = R.vert_begin + B.facet_vert[tf + f], ic = R.vert_begin + B.facet_vert[2u * tf + f];
+    const d3 contrib = facet_drag_force(speed, normalized3(speed), mk3(B.mesh_pos[ia], B.mesh_pos[tm + ia], B.mesh_pos[2u * tm + ia]),
+                                        mk3(B.mesh_pos[ib], B.mesh_pos[tm + ib], B.mesh_pos[2u * tm + ib]),
+                                        mk3(B.mesh_pos[ic], B.mesh_pos[tm + ic], B.mesh_pos[2u * tm + ic]), R.drag_coef);
+    B.fdrag[f] = contrib.x; B.fdrag[tf + f] = contrib.y; B.fdrag[2u * tf + f] = contrib.z;
 }
 
 // blocks [0, bond_blocks): one thread per bond slot; blocks beyond: collision-list rebuilds (reb_robot/reb_i0 tables),
@@ -775,8 +882,14 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
         int row = -1, ccnt = 0;
         if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) { row = R.surf_begin + so; ccnt = B.col_cnt[row]; } }
         const FetchGlobal fetch{B, cur};
-        vel2 = voxel_update(B, R, C, v, fetch, rs.cur_time, rs.act_sin, rs.act_cos, actuation_prenatal_c(R, rs.cur_time), F, M, vel, S, row, ccnt, false,
-                             mk3(0, 0, 0), B.act_sb[v], B.act_cb[v], B.amp_damp[v]);
+        const bool fluid = (R.flags & RF_FLUID) != 0;
+        d3 drag = mk3(0, 0, 0);
+        if (fluid) {                          // my facets in the reference's order (k_facets ran earlier in this step)
+            const unsigned tf = B.total_facet, f0 = R.facet_begin + B.facet_first[v];
+            for (int j = 0; j < (int)B.facet_count[v]; ++j) drag = drag + mk3(B.fdrag[f0 + j], B.fdrag[tf + f0 + j], B.fdrag[2u * tf + f0 + j]);
+        }
+        vel2 = voxel_update(B, R, C, v, fetch, rs.cur_time, rs.act_sin, rs.act_cos, actuation_prenatal_c(R, rs.cur_time), F, M, vel, S, row, ccnt, fluid,
+                             drag, B.act_sb[v], B.act_cb[v], B.amp_damp[v]);
         POS(nxt, 0, v) = S.pos.x; POS(nxt, 1, v) = S.pos.y; POS(nxt, 2, v) = S.pos.z;
         SCALE(nxt, v) = S.scale;
         LINMOM(0, v) = S.lm.x; LINMOM(1, v) = S.lm.y; LINMOM(2, v) = S.lm.z;

@@ -130,39 +130,8 @@ __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, 
     __syncthreads();
 }
 
-// land_water fluid drag (LW/VX_Sim.cpp:1516-1597).  Phase 1: every deformable surface vertex = mean over the <= 7 voxels
-// touching that lattice corner of Pos + R(Angle) * corner offset, corner offsets from the bond strains of the PREVIOUS step
-// (CornerPosCur/CornerNegCur, LW/VXS_Voxel.cpp:472-475; GetCurVLoc LW/VX_MeshUtil.cpp:388-428) -> LDS.  Phase 2: every voxel
-// sums the quadratic drag of the two triangles on each of its exposed faces, in the reference's facet order.
-__device__ __forceinline__ d3 rot_fwd(dq q, d3 f)      // CQuat::RotateVec3D, Vec3D.h:293-299
-{
-    double tw = f.x * q.x + f.y * q.y + f.z * q.z;
-    double tx = f.x * q.w - f.y * q.z + f.z * q.y;
-    double ty = f.x * q.z + f.y * q.w - f.z * q.x;
-    double tz = -f.x * q.y + f.y * q.x + f.z * q.w;
-    return mk3(q.w * tx + q.x * tw + q.y * tz - q.z * ty, q.w * ty - q.x * tz + q.y * tw + q.z * tx, q.w * tz + q.x * ty - q.y * tx + q.z * tw);
-}
-__device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ d3 normalized3(d3 a) { const double l = vsqrt_nn(len2(a)); return l > 0 ? a * vrcp(l) : a; }
-
-// CQuat::RotateVec3D (Vec3D.h:293-299) as a matrix: q f q* = M f for a unit quaternion (|q| = 1 to rounding).  A voxel's eight
-// mesh corners go through the same rotation, so it is expanded once per voxel (§ Numerics).
-struct RotFwd {
-    double m[9];
-    __device__ __forceinline__ RotFwd() {}
-    __device__ __forceinline__ explicit RotFwd(dq q)
-    {
-        const double x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
-        const double xx = q.x * x2, yy = q.y * y2, zz = q.z * z2, xy = q.x * y2, xz = q.x * z2, yz = q.y * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
-        m[0] = 1 - (yy + zz); m[1] = xy - wz; m[2] = xz + wy;
-        m[3] = xy + wz; m[4] = 1 - (xx + zz); m[5] = yz - wx;
-        m[6] = xz - wy; m[7] = yz + wx; m[8] = 1 - (xx + yy);
-    }
-    __device__ __forceinline__ d3 operator()(d3 f) const
-    { return mk3(m[0] * f.x + m[1] * f.y + m[2] * f.z, m[3] * f.x + m[4] * f.y + m[5] * f.z, m[6] * f.x + m[7] * f.y + m[8] * f.z); }
-};
-
+// land_water fluid drag (LW/VX_Sim.cpp:1516-1597) inside the resident kernel; the per-corner and per-facet arithmetic is
+// shared with the streaming kernels (kernels.hpp: RotFwd, mesh_corner_offset, facet_drag_force).
 // Constant index data of the drag pass that a thread needs at the head of its loops (its first two mesh vertices, its first
 // four facets).  Workgroups of up to 512 threads have the registers to keep it for the whole launch; the larger ones
 // reload it every step.
@@ -350,23 +319,7 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
             if constexpr (WIDE) sdir = mk3(spd[3 * BLOCK + u], spd[4 * BLOCK + u], spd[5 * BLOCK + u]);
             else sdir = normalized3(speed);
             const d3 A = mk3(sh[ia], sh[nmv + ia], sh[2 * nmv + ia]);
-            const d3 AB = mk3(sh[ib], sh[nmv + ib], sh[2 * nmv + ib]) - A, AC = mk3(sh[ic], sh[nmv + ic], sh[2 * nmv + ic]) - A;
-            const d3 cr = cross3(AB, AC);
-            const double cl = vsqrt_nn(len2(cr));
-            const double area = cl * 0.5;
-            const d3 n = cl > 0 ? cr * vrcp(cl) : cr;           // CalcFaceNormals; the reference normalises the stored normal
-                                                                // twice more before using it: identity to an ulp, skipped (§ Numerics)
-            // LW/VX_Sim.cpp:1556-1559 tests (float)acos(c) < PI/2 with c = v^ . n^.  The largest float below PI/2 is
-            // 1.57079625 and acos(c) rounds to it or below iff acos(c) <= 1.570796310901641845703125 (the midpoint
-            // to the next float, a tie going to the even mantissa below), i.e. iff c >= cos(midpoint); c > 1
-            // (two parallel unit vectors, rounding) makes the reference's acos a NaN and the facet drag-free.
-            const double c = dot3(sdir, n);
-            d3 contrib = mk3(0, 0, 0);
-            if (c >= 1.5893254773528196e-08 && c <= 1.0) {
-                const d3 proj = n * dot3(speed, n);             // ProjectOnTo
-                // proj^ * (-k * area * |proj|^2) = proj * (-k * area * |proj|)
-                contrib = proj * (-R.drag_coef * area * vsqrt_nn(len2(proj)));
-            }
+            const d3 contrib = facet_drag_force(speed, sdir, A, mk3(sh[ib], sh[nmv + ib], sh[2 * nmv + ib]), mk3(sh[ic], sh[nmv + ic], sh[2 * nmv + ic]), R.drag_coef);
             fd[f - c0] = contrib.x; fd[CHF + (f - c0)] = contrib.y; fd[2 * CHF + (f - c0)] = contrib.z;
         }
         __syncthreads();

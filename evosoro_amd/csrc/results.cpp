@@ -118,7 +118,7 @@ void compute_result(const RobotModel& M, const HostState& S, vxh_result* r)
         r->robot_volume_start = robot_volume(M, nullptr, nullptr, nullptr);
         if (S.steps == 0) r->robot_volume_end = r->robot_volume_start;
         else r->robot_volume_end = ((int)S.strain.size() == 6 * M.nvox) ? robot_volume(M, S.pos.data(), S.quat.data(), S.strain.data())
-                                                                          : -1.0;   // streaming path: strains are not recorded
+                                                                          : -1.0;
     }
 }
 

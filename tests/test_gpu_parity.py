@@ -146,8 +146,8 @@ def test_streaming_path_matches_fused_path(eng_mod, golden_dir):
             states[fused] = [eng.state(i) for i in range(len(names))]
     for a, b in zip(states[1], states[0]):
         assert np.abs(a[:, :8] - b[:, :8]).max() < 1e-12       # same kernels' math, different force-sum order
-    # _voxcad_land_water on land: same check; in a fluid the streaming kernels (no drag) must refuse, not run
-    names, states = ["lw_land6", "lw_stiff5"], {}
+    # _voxcad_land_water, on land and in a fluid (the streaming path has its own mesh / facet kernels for the drag)
+    names, states = ["lw_land6", "lw_stiff5", "lw_swim6"], {}
     for fused in (1, 0):
         with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
             eng.set_option("fused", fused)
@@ -157,11 +157,6 @@ def test_streaming_path_matches_fused_path(eng_mod, golden_dir):
             states[fused] = [eng.state(i) for i in range(len(names))]
     for a, b in zip(states[1], states[0]):
         assert np.abs(a[:, :8] - b[:, :8]).max() < 1e-12
-    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
-        eng.set_option("fused", 0)
-        with pytest.raises(Exception, match="unsupported"):
-            eng.add_vxa_file(os.path.join(golden_dir, "vxa", "lw_swim6.vxa"))
-            eng.step(1)
 
 
 def test_large_lattice_streaming_vs_oracle(eng_mod, tmp_path):
@@ -363,14 +358,24 @@ def test_every_mesh_kernel_variant_swims_like_the_oracle(eng_mod, tmp_path):
                 assert np.abs(eng.state(i)[:, 3:14] - o.state()[:, 3:14]).max() < 1e-7, (i, upto)
         moved = [np.abs(o.state()[:, 7:10]).max() for o in sims]       # the swimmers do move (velocities)
         assert min(moved) > 0
-    # a robot in a fluid next to one that needs the streaming kernels (more than 1024 voxels): refused, not run without drag
-    big = workloads.make_individual(9, workloads.full_material(11, 1), None)
+    # a swimmer of more than 1024 voxels (full 11x11x11: streaming kernels with the mesh in HBM) next to a small one, which
+    # then streams too: both against the oracle, and the volume tag is still produced
+    big = workloads.make_individual(9, workloads.full_material(11, 1),
+                                    OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(59).uniform(-1, 1, size=(11, 11, 11)), 3))]))
     write_voxelyze_file(sim, env, big, str(tmp_path), "s")
+    both = [paths[0], str(tmp_path / "voxelyzeFiles" / "s--id_00009.vxa")]
+    sims = [vo.OracleSim.from_vxa(p, variant=1) for p in both]
     with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
-        eng.add_vxa_file(paths[0])
-        with pytest.raises(Exception, match="unsupported"):
-            eng.add_vxa_file(str(tmp_path / "voxelyzeFiles" / "s--id_00009.vxa"))
-            eng.step(1)
+        eng.add_vxa_files(both)
+        assert eng.dims(1)["nvox"] == 1331
+        for upto in (1, 3, 40, 120):
+            eng.step(upto - sims[0].info().steps)
+            assert eng.counters().dominant_block == 0                  # streaming path
+            for i, o in enumerate(sims):
+                o.step(upto - o.info().steps)
+                assert _pos_err(eng.state(i), o.state(), 0.01) < FLOOR_VOX, (i, upto)
+        eng.run()
+        assert all(eng.result(i).robot_volume_end > 0 for i in range(2))
 
 
 def test_evolved_stiffness_on_large_robots_vs_oracle(eng_mod, tmp_path):
