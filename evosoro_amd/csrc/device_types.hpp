@@ -106,6 +106,7 @@ struct DBatch {
     const int* facet_first;           // [nv] first facet of the voxel, relative to the robot's facet_begin
     const unsigned char* facet_count; // [nv]
     double* strain;                   // [6][nv] StrainPosDirsCur xyz, StrainNegDirsCur xyz (land_water robots only)
+    const unsigned char* streamed;    // [n_robots] 1 = this robot is stepped by the streaming kernels in the current call
     // streaming kernels only (robots in a fluid that do not fit the resident kernel): mesh in HBM
     int n_mv, n_facet;                // real counts (total_mv / total_facet are the plane strides, >= 1)
     const int* vert_vox;              // [8][total_mv] global voxel slot touching the vertex with corner code c, or -1

@@ -46,7 +46,10 @@ struct Engine::Device {
     std::vector<Group> groups;
     std::vector<hipStream_t> group_streams;   // created on demand, reused across prepare() calls
     std::vector<hipEvent_t> group_events;
-    bool fused_ok = true;                 // every robot fits the fused kernel's LDS budget
+    const unsigned char* streamed_all = nullptr;    // masks for DBatch::streamed: every robot / the robots outside the launch groups
+    const unsigned char* streamed_rest = nullptr;
+    int n_rest = 0;                       // robots (with voxels) that only the streaming kernels can step
+    const unsigned char* graph_mask = nullptr;      // the mask the captured graph was recorded with
     bool any_fluid = false;               // some robot is in a fluid: the streaming rounds include the drag kernels
     std::vector<void*> allocs;
     DBatch B{};
@@ -472,12 +475,11 @@ void Engine::prepare()
         // is a function of the robot alone (size, fluid, LDS need of its own tables), never of the batch.
         const size_t lds_max = 160 * 1024 - VXH_FUSED_STATIC_LDS;
         D.groups.clear();
-        D.fused_ok = true;
         for (int r = 0; r < nr; ++r) {
             const RobotModel& M = robots_[r];
             const int n = M.nvox;
             if (n == 0) continue;
-            if (n > 1024 || M.bond_classes.size() > 4095) { D.fused_ok = false; continue; }   // (12 class bits in a bond entry; a robot of 1024 voxels has at most 3072 bonds)
+            if (n > 1024 || M.bond_classes.size() > 4095) continue;   // streaming kernels (12 class bits in a bond entry; a robot of 1024 voxels has at most 3072 bonds)
             const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
             const int fluid = M.nmv > 0 ? 1 : 0;      // (the MESH variants: every land_water robot carries the surface mesh)
             const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
@@ -495,12 +497,20 @@ void Engine::prepare()
             // of it a function of the robot alone, never of the batch
             const int nacc = block == 1024 ? 1 : 2;
             const int tabg = need(nacc, true) > lds_max ? 1 : 0;
-            if (need(nacc, !tabg) > lds_max) { D.fused_ok = false; continue; }   // (e.g. a mesh with thousands of vertices)
+            if (need(nacc, !tabg) > lds_max) continue;                // streaming kernels (e.g. a mesh with thousands of vertices)
             Device::Group* g = nullptr;
             for (auto& q : D.groups) if (q.block == block && q.nacc == nacc && q.fluid == fluid && q.tabg == tabg) g = &q;
             if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nacc = nacc; g->fluid = fluid; g->tabg = tabg; }
             g->robots.push_back(r);
             g->lds = std::max(g->lds, need(nacc, !tabg));
+        }
+        {
+            std::vector<unsigned char> all(std::max(nr, 1), 1), rest(std::max(nr, 1), 1);
+            for (auto& g : D.groups) for (int r : g.robots) rest[r] = 0;
+            D.n_rest = 0;
+            for (int r = 0; r < nr; ++r) if (rest[r] && robots_[r].nvox > 0) ++D.n_rest;
+            D.streamed_all = D.upload(all);
+            D.streamed_rest = D.upload(rest);
         }
         size_t gi = 0;
         for (auto& g : D.groups) {
@@ -576,12 +586,16 @@ void Engine::advance(long long max_rounds)
 {
     HIP_OK(hipSetDevice(device_id_));
     Device& D = *dev_;
-    const DBatch& B = D.B;
+    DBatch& B = D.B;
     const long long cap_all = 0x7fffffffffffffffLL;
     const long long remaining = std::max(0LL, D.max_planned - rounds_done_);
     const long long todo = std::min(max_rounds, remaining);
     const long long cap = (max_rounds >= remaining) ? cap_all : rounds_done_ + max_rounds;
-    const bool fused = fused_ && D.fused_ok;
+    // robots that fit the resident kernel are stepped by their launch groups, the others (more than 1024 voxels, oversized
+    // mesh) by the streaming kernels, side by side on their own streams; with the option fused = 0 everything streams
+    const bool fused = fused_ && !D.groups.empty();
+    const bool streaming = !fused || D.n_rest > 0;
+    B.streamed = fused ? D.streamed_rest : D.streamed_all;
     // per-robot step counts before, to attribute the work of this call
     std::vector<int> steps_before(robots_.size());
     for (size_t r = 0; r < robots_.size(); ++r) steps_before[r] = host_.size() == robots_.size() ? host_[r].steps : 0;
@@ -598,8 +612,9 @@ void Engine::advance(long long max_rounds)
                 ++launches; ++group_launches[k];
             }
         }
-        for (auto& g : D.groups) { HIP_OK(hipEventRecord(g.t1, g.stream)); HIP_OK(hipStreamWaitEvent(D.stream, g.t1, 0)); }
-    } else {
+        for (auto& g : D.groups) HIP_OK(hipEventRecord(g.t1, g.stream));
+    }
+    if (streaming) {
         const int nb_b = (3 * B.nv + 255) / 256, nb_v = (B.nv + 255) / 256;
         auto round = [&](long long c) {
             hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, c, 1);
@@ -612,7 +627,7 @@ void Engine::advance(long long max_rounds)
         };
         long long launched = 0;
         if (graph_steps_ > 1 && cap == cap_all && todo >= graph_steps_) {
-            if (!D.graph_exec || D.graph_rounds != graph_steps_) {
+            if (!D.graph_exec || D.graph_rounds != graph_steps_ || D.graph_mask != B.streamed) {
                 if (D.graph_exec) { hipGraphExecDestroy(D.graph_exec); D.graph_exec = nullptr; }
                 if (D.graph) { hipGraphDestroy(D.graph); D.graph = nullptr; }
                 HIP_OK(hipStreamBeginCapture(D.stream, hipStreamCaptureModeThreadLocal));
@@ -620,13 +635,15 @@ void Engine::advance(long long max_rounds)
                 HIP_OK(hipStreamEndCapture(D.stream, &D.graph));
                 HIP_OK(hipGraphInstantiate(&D.graph_exec, D.graph, nullptr, nullptr, 0));
                 D.graph_rounds = graph_steps_;
+                D.graph_mask = B.streamed;
             }
             while (todo - launched >= graph_steps_) { HIP_OK(hipGraphLaunch(D.graph_exec, D.stream)); launched += graph_steps_; }
         }
         for (; launched < todo; ++launched) round(cap);
         hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, cap, 0);   // finish the last step
-        launches = (D.any_fluid ? 5 : 3) * todo + 1;
+        launches += (D.any_fluid ? 5 : 3) * todo + 1;
     }
+    if (fused) for (auto& g : D.groups) HIP_OK(hipStreamWaitEvent(D.stream, g.t1, 0));
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(D.ev1, D.stream));
     HIP_OK(hipStreamSynchronize(D.stream));
@@ -652,11 +669,19 @@ void Engine::advance(long long max_rounds)
             for (int r : D.groups[k].robots) work(r, grp_vs[k], grp_ab[k]);
             if (grp_vs[k] > grp_vs[best]) best = k;
         }
-        float cms = 0;
-        HIP_OK(hipEventElapsedTime(&cms, D.groups[best].t0, D.groups[best].t1));
-        counters_.dominant_block = D.groups[best].block; counters_.dominant_robots = D.groups[best].count;
-        counters_.dominant_launches = group_launches[best]; counters_.dominant_seconds = cms * 1e-3;
-        counters_.dominant_alg_bytes = grp_ab[best]; counters_.dominant_voxel_steps = grp_vs[best];
+        double rest_vs = all_vs, rest_ab = all_ab;           // what the streaming kernels did next to the groups
+        for (size_t k = 0; k < D.groups.size(); ++k) { rest_vs -= grp_vs[k]; rest_ab -= grp_ab[k]; }
+        if (streaming && rest_vs > grp_vs[best]) {
+            counters_.dominant_block = 0; counters_.dominant_robots = D.n_rest;
+            counters_.dominant_launches = todo; counters_.dominant_seconds = ms * 1e-3;
+            counters_.dominant_alg_bytes = rest_ab; counters_.dominant_voxel_steps = rest_vs;
+        } else {
+            float cms = 0;
+            HIP_OK(hipEventElapsedTime(&cms, D.groups[best].t0, D.groups[best].t1));
+            counters_.dominant_block = D.groups[best].block; counters_.dominant_robots = D.groups[best].count;
+            counters_.dominant_launches = group_launches[best]; counters_.dominant_seconds = cms * 1e-3;
+            counters_.dominant_alg_bytes = grp_ab[best]; counters_.dominant_voxel_steps = grp_vs[best];
+        }
     } else {
         counters_.dominant_block = 0; counters_.dominant_robots = (int)robots_.size();
         counters_.dominant_launches = todo; counters_.dominant_seconds = ms * 1e-3;

@@ -721,6 +721,7 @@ __device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, D
 __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap, int begin_new_step)
 {
     const int r = blockIdx.x;
+    if (!B.streamed[r]) return;             // (stepped by the resident kernel)
     const DRobot& R = B.robot[r];
     DRobotState& rs = B.rstate[r];
     __shared__ double sh[4 * 256];
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(256) void k_mesh_vertices(DBatch B)
     const int r = B.vert_robot[i];
     const DRobot& R = B.robot[r];
     const DRobotState& rs = B.rstate[r];
-    if (!(R.flags & RF_FLUID) || !rs.active) return;
+    if (!B.streamed[r] || !(R.flags & RF_FLUID) || !rs.active) return;
     const int cur = rs.steps & 1;
     const unsigned tm = B.total_mv, nv = B.nv;
     const double nom = R.lat;
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(256) void k_facets(DBatch B)
     const int r = B.facet_robot[f];
     const DRobot& R = B.robot[r];
     const DRobotState& rs = B.rstate[r];
-    if (!(R.flags & RF_FLUID) || !rs.active) return;
+    if (!B.streamed[r] || !(R.flags & RF_FLUID) || !rs.active) return;
     const unsigned tm = B.total_mv, tf = B.total_facet;
     const int u = R.vox_begin + B.facet_vox[f];
     const d3 speed = mk3(LINMOM(0, u), LINMOM(1, u), LINMOM(2, u)) * B.vclass_tab[R.vtab_begin + B.vclass[u]].mass_inv;
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(256) void k_bonds(DBatch B, int bond_blocks, const 
         const int k = blockIdx.x - bond_blocks;
         const int r = reb_robot[k];
         DRobotState& rs = B.rstate[r];
-        if (!rs.active || !rs.rebuild_now) return;
+        if (!B.streamed[r] || !rs.active || !rs.rebuild_now) return;
         rebuild_rows(B, B.robot[r], rs, rs.steps & 1, reb_i0[k], sh, 512);
         return;
     }
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256) void k_bonds(DBatch B, int bond_blocks, const 
     const int axis = tid / B.nv;            // wave-uniform: nv is a multiple of 64
     const int v1 = tid - axis * B.nv;
     const int r = robot_of(B, v1);
-    if (r < 0) return;
+    if (r < 0 || !B.streamed[r]) return;
     const DRobotState& rs = B.rstate[r];
     if (!rs.active) return;
     const int bc = B.bclass[tid];
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= B.nv) return;
     const int r = robot_of(B, v);
-    if (r < 0) return;
+    if (r < 0 || !B.streamed[r]) return;
     DRobotState& rs = B.rstate[r];
     if (!rs.active || rs.diverged) return;    // Integrate() returns before the voxel loop when a bond diverged
     const DRobot& R = B.robot[r];

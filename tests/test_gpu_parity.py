@@ -306,14 +306,15 @@ def test_every_fused_kernel_variant_vs_oracle(eng_mod, tmp_path):
     from oracle import vxoracle as vo
     sim, env = Sim(dt_frac=0.9, simulation_time=0.02, fitness_eval_init_time=0.002), Env()
     mats = [workloads.random_material((6, 6, 6), 3), workloads.random_material((8, 8, 8), 4),
-            workloads.random_material((10, 10, 10), 5), workloads.full_material(10, 2)]
+            workloads.random_material((10, 10, 10), 5), workloads.full_material(10, 2),
+            workloads.full_material(11, 3)]      # and one beyond a workgroup: streaming kernels, side by side with the others
     paths = [_write_robot(tmp_path, k, m, sim, env, "v") for k, m in enumerate(mats)]
     sims = [vo.OracleSim.from_vxa(p) for p in paths]
     with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
         for p in paths:
             eng.add_vxa_file(p)
-        nv = [eng.dims(i)["nvox"] for i in range(4)]
-        assert nv[0] <= 256 < nv[1] <= 512 < nv[2] <= 768 < nv[3] == 1000
+        nv = [eng.dims(i)["nvox"] for i in range(5)]
+        assert nv[0] <= 256 < nv[1] <= 512 < nv[2] <= 768 < nv[3] == 1000 and nv[4] == 1331
         for upto in (1, 3, 40, 120):
             eng.step(upto - sims[0].info().steps)
             for i, o in enumerate(sims):
@@ -358,8 +359,8 @@ def test_every_mesh_kernel_variant_swims_like_the_oracle(eng_mod, tmp_path):
                 assert np.abs(eng.state(i)[:, 3:14] - o.state()[:, 3:14]).max() < 1e-7, (i, upto)
         moved = [np.abs(o.state()[:, 7:10]).max() for o in sims]       # the swimmers do move (velocities)
         assert min(moved) > 0
-    # a swimmer of more than 1024 voxels (full 11x11x11: streaming kernels with the mesh in HBM) next to a small one, which
-    # then streams too: both against the oracle, and the volume tag is still produced
+    # a swimmer of more than 1024 voxels (full 11x11x11: streaming kernels with the mesh in HBM) next to a small one (resident
+    # kernel, side by side in the same call): both against the oracle, and the volume tag is still produced
     big = workloads.make_individual(9, workloads.full_material(11, 1),
                                     OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(59).uniform(-1, 1, size=(11, 11, 11)), 3))]))
     write_voxelyze_file(sim, env, big, str(tmp_path), "s")
@@ -370,7 +371,7 @@ def test_every_mesh_kernel_variant_swims_like_the_oracle(eng_mod, tmp_path):
         assert eng.dims(1)["nvox"] == 1331
         for upto in (1, 3, 40, 120):
             eng.step(upto - sims[0].info().steps)
-            assert eng.counters().dominant_block == 0                  # streaming path
+            assert eng.counters().dominant_block == 0                  # most of the work was done by the streaming kernels
             for i, o in enumerate(sims):
                 o.step(upto - o.info().steps)
                 assert _pos_err(eng.state(i), o.state(), 0.01) < FLOOR_VOX, (i, upto)
