@@ -68,6 +68,33 @@ int vxh_inspect_vxa_buffer(const char* xml, size_t len, int variant, vxh_model_i
     }
 }
 
+int vxh_plan_tiles_buffer(const char* xml, size_t len, int variant, int k_request, vxh_tiling_info* out, int* tile_of_out, int capacity,
+                          char* errbuf, size_t errcap)
+{
+    if (!xml || !out || k_request < 1 || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;
+    auto fail = [&](int code, const char* what) {
+        if (errbuf && errcap) { std::strncpy(errbuf, what, errcap - 1); errbuf[errcap - 1] = 0; }
+        return code;
+    };
+    try {
+        vxh::VxaModel vxa = vxh::read_vxa(xml, len, variant);
+        if (!vxa.unsupported.empty()) return fail(VXH_ERR_UNSUPPORTED, vxa.unsupported.front().c_str());
+        const vxh::RobotModel m = vxh::build_robot(vxa);
+        const vxh::TilePlan plan = vxh::plan_tiles(m, k_request);
+        std::memset(out, 0, sizeof(*out));
+        out->k = plan.k; out->kx = plan.kx; out->ky = plan.ky; out->kz = plan.kz;
+        out->max_own = plan.max_own; out->max_local = plan.max_local; out->max_bonds = plan.max_bonds;
+        for (const auto& t : plan.tiles) out->total_bonds += (int)t.bond_v1.size();
+        if (tile_of_out) {
+            if (capacity < m.nvox) return fail(VXH_ERR_ARG, "tile_of buffer too small");
+            for (int v = 0; v < m.nvox; ++v) tile_of_out[v] = plan.tile_of[v];
+        }
+        return VXH_OK;
+    } catch (const std::exception& ex) {
+        return fail(VXH_ERR_PARSE, ex.what());
+    }
+}
+
 int vxh_create(vxh_engine** out, int variant, int device_id)
 {
     if (!out || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;

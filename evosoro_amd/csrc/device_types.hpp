@@ -47,14 +47,62 @@ struct DRobotState {          // mutable per robot
     double act_sin, act_cos;      // streaming path: sincos of the actuation phase of the current step (actuation_sincos)
     unsigned long long maxvel2_bits;
     int steps, status, cm_init, active, diverged, col_overflow, rebuild_now, rebuilds;
+    int col_tiled, pad0;          // the contact rows were built by the tiled kernel (DBatch::col_code / tile_xh are valid for them)
 };
+
+// Tiled path (kernels_tiled.hpp): a robot cut into `ntiles` tiles, one workgroup each.  A tile OWNS n_own voxels (it
+// integrates them) and mirrors n_halo more (the far ends of the bonds that leave the tile, owned by neighbour tiles); its
+// bond list holds every bond with at least one owned end, so a bond that crosses a tile boundary is evaluated by both tiles
+// (same inputs, same code, same bits) and no force ever travels between tiles -- only poses do.
+struct DTile {
+    int robot;            // robot index
+    int tile0, ntiles;    // first tile of the robot in the batch-wide tile numbering (flags, mv) and their number
+    int n_own, n_halo;    // voxels: DBatch::tile_vox[vox_off ..) holds the n_own owned global slots, then the n_halo mirrored ones
+    int nb;               // bonds: DBatch::tile_bond / tile_bcls / tile_bslot [bond_off ..)
+    int vox_off, bond_off;
+    int xoff, pad;        // first exchange slot of the tile's owned voxels (DBatch::xch), a multiple of 64
+};
+
+// dynamic LDS of a tile's workgroup, in doubles from the base; the host sizes the launch with the same function
+#if defined(__HIP__)
+#define VXH_HD __host__ __device__
+#else
+#define VXH_HD
+#endif
+enum { VXH_TILE_BLOCK = 256,          // worker threads of a tile's workgroup = most voxels a tile can own
+       VXH_TILE_THREADS = 320,        // ... plus the service wavefront (per-robot barrier and control block, concurrent with the bond phase)
+       VXH_TILE_HASH_BITS = 9, VXH_TILE_HASH = 512,   // broad-phase: LDS hash set of the contact partners owned by other tiles
+       VXH_TILE_MAX_TILES = 256,      // most tiles of one robot (its max-|v|^2 words are polled by one wavefront)
+       VXH_TILE_MV_STRIDE = 512,      // granules between the max-|v|^2 words of two tiles: 4 KB, so that the wavefronts polling them
+                                      // (one per tile, all at once) spread over the memory channels instead of queueing at one
+       VXH_TILE_ROWPOOL = 1024,       // contact-row entries (partner code + pair stiffness) a tile keeps in LDS (rows beyond: read from memory)
+       VXH_TILE_XH = 192,             // most contact partners owned by other tiles that a tile mirrors in LDS (the rest: fetched from memory)
+       VXH_TILE_CH = 128,             // chunk of the whole-robot passes (latch, broad-phase) staged through LDS
+       VXH_TILE_STATIC_LDS = 1024 };   // upper bound of the kernel's static __shared__ variables
+struct TileLayout { int np, no, nbp, o_ps, o_pl, o_hl, o_pht, o_sc, o_px, o_rc, o_tab, o_int, total; };
+VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doubles)
+{
+    TileLayout L;
+    L.np = (n_own + n_halo + 1) & ~1; L.no = (n_own + 1) & ~1; L.nbp = (nb + 1) & ~1;
+    L.o_ps = 0;
+    L.o_pl = L.o_ps + 8 * L.np;
+    L.o_hl = L.o_pl + 36 * L.no;
+    L.o_pht = L.o_hl + 6 * L.nbp;
+    L.o_sc = L.o_pht + 2 * L.no;
+    L.o_px = L.o_sc + 5 * VXH_TILE_CH + VXH_TILE_CH / 2;
+    L.o_rc = L.o_px + 4 * VXH_TILE_XH;
+    L.o_tab = L.o_rc + VXH_TILE_ROWPOOL;
+    L.o_int = L.o_tab + ((tab_doubles + 1) & ~1);
+    L.total = L.o_int + (3 * L.nbp + VXH_TILE_XH + 2 * VXH_TILE_HASH + VXH_TILE_ROWPOOL + 1) / 2;
+    return L;
+}
 
 enum { VXH_MAXCOL = 64 };     // collision partners kept per surface voxel (overflow -> VXH_ROBOT_COL_OVERFLOW)
 
 // all device pointers of a batch; passed to kernels by value
 struct DBatch {
     int n_robots, nv;                 // nv = total padded voxel slots (multiple of 64 per robot)
-    int dbg, pad1;                    // developer switches (tests/dev_gpu_diag.py), 0 in production
+    int dbg, pad1;                    // developer switches (scripts/dev_gpu_diag.py), 0 in production
     const DRobot* robot;
     DRobotState* rstate;
     const int* wave_robot;            // [nv/64] robot of each 64-voxel group
@@ -114,6 +162,29 @@ struct DBatch {
     const int* facet_robot;           // [total_facet]
     double* mesh_pos;                 // [3][total_mv] current vertex positions
     double* fdrag;                    // [3][total_facet] drag of every facet in the current step
+    // tiled path (robots stepped by k_tile_steps; all null / zero otherwise)
+    const DTile* tiles;
+    const int* tile_vox;              // per tile: owned voxels (ascending global slot), then the EXCHANGE slots of its halo voxels
+    const int* tile_bond;             // per tile and bond: local index of the negative end | local index of the positive end << 10
+                                      // | axis << 20 (local = position in the tile's voxel list, halo entries after the owned ones)
+    const int* tile_bcls;             // ... its bond class (robot-local)
+    const int* tile_bslot;            // ... its canonical slot axis * nv + negative-end voxel (DBatch::hist, small_angle)
+    // Exchange between the tiles of a robot, in 8-byte GRANULES {32 data bits, 32-bit tag}: a double travels as two granules
+    // (low word, high word), each written by one write-through store, so a granule is never torn and validates itself -- the
+    // tag names the launch and the publication (kernels_tiled.hpp tile_tag) -- and no flag, fence or drain orders anything.
+    const int* xslot;                 // [nv] exchange slot of every voxel of a tiled robot: owner tile's xoff + its index there
+    int nx, pad6;                     // exchange slots in all (every tile's range padded to a multiple of 64)
+    unsigned long long* xch;          // [3][16][nx] poses, a ring of three buffers, slot = step count mod 3: planes 2c / 2c+1 = low / high granule of component c
+                                      // (pos xyz, scale, quaternion wxyz) of every voxel of a tiled robot, published by its owner
+    unsigned long long* tile_mv;      // [3][total tiles][VXH_TILE_MV_STRIDE] first two words: low / high granule of the max |v|^2 of the tile's voxels in the step
+                                      // that produced the published poses (negative: a bond of the tile diverged in that step)
+    int n_tiles, pad5;
+    const int* tile_of;               // [nv] owner tile (batch-wide numbering) and position among its owned voxels, -1 = not tiled
+    const int* tile_lidx;
+    int* col_code;                    // same shape as col_partner: where the tile that owns the row finds the partner's position in its
+                                      // LDS (owned voxel: its index; mirrored partner: np + entry of tile_xh), -1 = fetch from memory
+    int* tile_xh;                     // [total tiles][VXH_TILE_XH] contact partners owned by other tiles that the tile mirrors (global slots)
+    int* tile_xhn;                    // [total tiles] their number
     unsigned long long* prof;         // developer builds (-DVXH_PHASE_TIMING): per-wave phase cycle sums, else null
     // constants from Vec3D.h evaluated by the host libm (thresholds of the small-angle logic)
     double small_angle_w, smallish_angle_w, slthresh_acos2sqrt;

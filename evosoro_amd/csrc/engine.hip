@@ -6,10 +6,12 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <exception>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -48,7 +50,7 @@ struct Engine::Device {
     std::vector<hipEvent_t> group_events;
     const unsigned char* streamed_all = nullptr;    // masks for DBatch::streamed: every robot / the robots outside the launch groups
     const unsigned char* streamed_rest = nullptr;
-    int n_rest = 0;                       // robots (with voxels) that only the streaming kernels can step
+    int n_rest = 0, n_all = 0;            // robots (with voxels) that only the streaming kernels can step / that they step with fused = 0
     const unsigned char* graph_mask = nullptr;      // the mask the captured graph was recorded with
     bool any_fluid = false;               // some robot is in a fluid: the streaming rounds include the drag kernels
     std::vector<void*> allocs;
@@ -62,6 +64,19 @@ struct Engine::Device {
     hipGraphExec_t graph_exec = nullptr;
     int graph_rounds = 0;
     int max_nvox = 0;                     // largest robot of the batch (selects the fused block size)
+    // tiled path: the robots cut into tiles, packed into launches that fit the chip (all tiles of a robot in one launch)
+    struct TileLaunch {
+        int tabg = 0, count = 0;
+        const int* list = nullptr;        // tile ids
+        size_t lds = 0;
+        std::vector<int> tile_ids, robots;
+    };
+    std::vector<TileLaunch> tile_launches;
+    std::vector<unsigned char> robot_tiled;   // per robot
+    std::vector<int> robot_tiles;             // per robot: number of tiles (0 = not tiled)
+    hipStream_t tile_stream = nullptr;        // ONE stream for every tiled launch: two of them must never share the chip
+    hipEvent_t tile_t0 = nullptr, tile_t1 = nullptr;
+    int n_cu = 0;
     int reb_blocks = 0;                   // streaming path: collision-rebuild blocks appended to k_bonds
     const int* reb_robot = nullptr;
     const int* reb_i0 = nullptr;
@@ -107,6 +122,23 @@ Engine::Engine(int variant, int device_id) : variant_(variant), device_id_(devic
     HIP_OK(hipStreamCreateWithFlags(&dev_->stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&dev_->ev0));
     HIP_OK(hipEventCreate(&dev_->ev1));
+    HIP_OK(hipStreamCreateWithFlags(&dev_->tile_stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreate(&dev_->tile_t0));
+    HIP_OK(hipEventCreate(&dev_->tile_t1));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device_id));
+    dev_->n_cu = prop.multiProcessorCount;
+    // VXH_ENGINE_OPTIONS="key=value,key=value": defaults of vxh_set_option for every engine of the process, so that a caller
+    // that cannot pass options (the voxelyze command line, a test matrix) still selects e.g. tiled=0
+    if (const char* env = std::getenv("VXH_ENGINE_OPTIONS")) {
+        std::stringstream list(env);
+        std::string item;
+        while (std::getline(list, item, ',')) {
+            const size_t eq = item.find('=');
+            if (eq == std::string::npos || eq == 0) throw std::runtime_error("VXH_ENGINE_OPTIONS: expected key=value, got '" + item + "'");
+            set_option(item.substr(0, eq), std::stod(item.substr(eq + 1)));
+        }
+    }
 }
 
 Engine::~Engine()
@@ -117,6 +149,9 @@ Engine::~Engine()
         if (dev_->ev0) hipEventDestroy(dev_->ev0);
         if (dev_->ev1) hipEventDestroy(dev_->ev1);
         if (dev_->stream) hipStreamDestroy(dev_->stream);
+        if (dev_->tile_stream) hipStreamDestroy(dev_->tile_stream);
+        if (dev_->tile_t0) hipEventDestroy(dev_->tile_t0);
+        if (dev_->tile_t1) hipEventDestroy(dev_->tile_t1);
         for (hipStream_t st : dev_->group_streams) hipStreamDestroy(st);
         for (hipEvent_t ev : dev_->group_events) hipEventDestroy(ev);
     }
@@ -185,16 +220,26 @@ void Engine::clear()
     HIP_OK(hipSetDevice(device_id_));
 #ifdef VXH_PHASE_TIMING
     if (dev_->B.prof) {
-        unsigned long long h[16 * 8];
+        unsigned long long h[16 * 8 + 256 * 8];
         HIP_OK(hipMemcpy(h, dev_->B.prof, sizeof(h), hipMemcpyDeviceToHost));
+        if (std::getenv("VXH_PROF_TILES"))      // wave 0 of each of the first tiles: cycles per phase
+            for (int t = 0; t < std::min(256, dev_->B.n_tiles); ++t) {
+                fprintf(stderr, "tile %3d:", t);
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %9llu", h[128 + t * 8 + k]);
+                fprintf(stderr, "\n");
+            }
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
-        for (int w = 0; w < 16; ++w) {
-            double tot = 0; for (int k = 0; k < 6; ++k) tot += (double)h[w * 8 + k];
+        static const char* tnames[8] = {"halo-wait", "bond", "svc:poll", "barB", "latch/rebuild", "voxel", "barC+mv", "svc:reduce+horizon"};
+        const bool tiled = !dev_->tile_launches.empty();
+        if (tiled && h[121]) fprintf(stderr, "robot barrier: %.2f poll rounds per barrier, %.0f cycles per barrier\n", (double)h[120] / h[121], (double)h[122] / h[121]);
+        for (int w = 0; w < 15; ++w) {
+            double tot = 0; for (int k = 0; k < (tiled ? 8 : 6); ++k) tot += (double)h[w * 8 + k];
             if (tot == 0) continue;
             fprintf(stderr, "wave %2d:", w);
-            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %5.1f%%", names[k], 100.0 * h[w * 8 + k] / tot);
+            if (tiled) for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %5.1f%%", tnames[k], 100.0 * h[w * 8 + k] / tot);
+            else for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %5.1f%%", names[k], 100.0 * h[w * 8 + k] / tot);
             fprintf(stderr, "  total %.3e cycles", tot);
-            if (h[w * 8 + 6] + h[w * 8 + 7]) fprintf(stderr, "  (aux: mesh vertices %4.1f%%, facets %4.1f%%)", 100.0 * h[w * 8 + 6] / tot, 100.0 * h[w * 8 + 7] / tot);
+            if (!tiled && h[w * 8 + 6] + h[w * 8 + 7]) fprintf(stderr, "  (aux: mesh vertices %4.1f%%, facets %4.1f%%)", 100.0 * h[w * 8 + 6] / tot, 100.0 * h[w * 8 + 7] / tot);
             fprintf(stderr, "\n");
         }
     }
@@ -208,10 +253,19 @@ void Engine::clear()
 
 void Engine::set_option(const std::string& key, double value)
 {
-    if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; }
-    else if (key == "fused") fused_ = value != 0;
-    else if (key == "steps_per_launch") steps_per_launch_ = (int)value;
-    else if (key == "graph_steps") { graph_steps_ = (int)value; if (dev_->graph_exec) { hipGraphExecDestroy(dev_->graph_exec); dev_->graph_exec = nullptr; } }
+#ifdef VXH_PHASE_TIMING
+    if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; }    // physics-skipping what-if switches: developer library only
+    else
+#endif
+    if (key == "fused") fused_ = value != 0;
+    else if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); steps_per_launch_ = (int)value; }
+    else if (key == "tiled" || key == "tiles_per_robot") {
+        // the tiling is part of the uploaded batch: set before the first vxh_run / vxh_step, or follow with vxh_reset
+        if (prepared_) throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or call vxh_reset after it)");
+        if (key == "tiled") { if (value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2"); tiled_ = (int)value; }
+        else { if (!(value >= 0 && value <= 4096)) throw std::invalid_argument("tiles_per_robot out of range"); tiles_per_robot_ = (int)value; }
+    }
+    else if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); graph_steps_ = (int)value; if (dev_->graph_exec) { hipGraphExecDestroy(dev_->graph_exec); dev_->graph_exec = nullptr; } }
     else throw std::invalid_argument("unknown option " + key);
 }
 
@@ -471,44 +525,169 @@ void Engine::prepare()
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
     B.col_a1 = D.alloc_zero<double>((size_t)std::max(ns, 1) * VXH_MAXCOL);
-    {   // fused path: launch groups by kernel variant; inside a group the longest-running robots first.  The variant
-        // is a function of the robot alone (size, fluid, LDS need of its own tables), never of the batch.
+    // Which kernel steps which robot.  Resident kernel (kernels_fused.hpp), one workgroup per robot: its variant is a function
+    // of the robot alone (size, fluid, LDS need of its own tables), never of the batch.
+    struct FusedVariant { int block = 0, nacc = 0, fluid = 0, tabg = 0; size_t lds = 0; };
+    auto fused_variant = [&](const RobotModel& M) {
+        FusedVariant fv;
         const size_t lds_max = 160 * 1024 - VXH_FUSED_STATIC_LDS;
-        D.groups.clear();
+        const int n = M.nvox;
+        if (n == 0 || n > 1024 || M.bond_classes.size() > 4095) return fv;   // (12 class bits in a bond entry; a robot of 1024 voxels has at most 3072 bonds)
+        const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
+        const int fluid = M.nmv > 0 ? 1 : 0;      // (the MESH variants: every land_water robot carries the surface mesh)
+        const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
+        // LDS need: pose tile, accumulator tiles, actuation phases; class tables; the mesh vertices of a robot in a
+        // fluid; with two accumulator tiles the MESH variants also hold the strain tile (with one it stays in HBM)
+        // (mirrors the layout at the top of k_robot_steps; SLIM = the 768-thread MESH variant, phases and strains in HBM)
+        const bool slim = fluid && block == 768;
+        auto need = [&](int nacc, bool tables_in_lds) {
+            return (size_t)(8 + 6 * nacc + (slim ? 0 : 2)) * block * 8 +
+                   (tables_in_lds ? M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) : 0) +
+                   (in_fluid ? (size_t)24 * M.nmv : 0) + ((fluid && nacc == 2 && !slim) ? (size_t)48 * block : 0);
+        };
+        // accumulator tiles: two up to 768 voxels, one for 1024; class tables in LDS unless they do not fit (per-voxel
+        // evolved stiffness makes nearly every bond a class of its own), then the TABG variant reads them from HBM
+        const int nacc = block == 1024 ? 1 : 2;
+        const int tabg = need(nacc, true) > lds_max ? 1 : 0;
+        if (need(nacc, !tabg) > lds_max) return fv;                   // (e.g. a mesh with thousands of vertices)
+        fv.block = block; fv.nacc = nacc; fv.fluid = fluid; fv.tabg = tabg; fv.lds = need(nacc, !tabg);
+        return fv;
+    };
+    // Tiled kernel (kernels_tiled.hpp), several workgroups per robot: for robots the resident kernel cannot take, and for
+    // populations too small to give every CU a robot.  The number of tiles depends on the population (the results do not:
+    // the tiled kernel's arithmetic per bond and per voxel, and its summation orders, are those of the resident kernel).
+    D.robot_tiled.assign(nr, 0);
+    D.robot_tiles.assign(nr, 0);
+    D.tile_launches.clear();
+    std::vector<DTile> h_tiles;
+    std::vector<int> tile_vox, tile_bond, tile_bcls, tile_bslot, xslot(nv, 0);
+    int nx_total = 0;
+    if (tiled_ > 0) {
+        const size_t lds_cap = 160 * 1024 - VXH_TILE_STATIC_LDS;
+        int n_work = 0;
+        for (int r = 0; r < nr; ++r) if (robots_[r].nvox > 0) ++n_work;
+        const bool small_population = n_work * 4 <= D.n_cu * 3;
+        std::vector<int> cand;
         for (int r = 0; r < nr; ++r) {
             const RobotModel& M = robots_[r];
-            const int n = M.nvox;
-            if (n == 0) continue;
-            if (n > 1024 || M.bond_classes.size() > 4095) continue;   // streaming kernels (12 class bits in a bond entry; a robot of 1024 voxels has at most 3072 bonds)
-            const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
-            const int fluid = M.nmv > 0 ? 1 : 0;      // (the MESH variants: every land_water robot carries the surface mesh)
-            const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
-            // LDS need: pose tile, accumulator tiles, actuation phases; class tables; the mesh vertices of a robot in a
-            // fluid; with two accumulator tiles the MESH variants also hold the strain tile (with one it stays in HBM)
-            // (mirrors the layout at the top of k_robot_steps; SLIM = the 768-thread MESH variant, phases and strains in HBM)
-            const bool slim = fluid && block == 768;
-            auto need = [&](int nacc, bool tables_in_lds) {
-                return (size_t)(8 + 6 * nacc + (slim ? 0 : 2)) * block * 8 +
-                       (tables_in_lds ? M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) : 0) +
-                       (in_fluid ? (size_t)24 * M.nmv : 0) + ((fluid && nacc == 2 && !slim) ? (size_t)48 * block : 0);
-            };
-            // accumulator tiles: two up to 768 voxels, one for 1024; class tables in LDS unless they do not fit (per-voxel
-            // evolved stiffness makes nearly every bond a class of its own), then the TABG variant reads them from HBM -- all
-            // of it a function of the robot alone, never of the batch
-            const int nacc = block == 1024 ? 1 : 2;
-            const int tabg = need(nacc, true) > lds_max ? 1 : 0;
-            if (need(nacc, !tabg) > lds_max) continue;                // streaming kernels (e.g. a mesh with thousands of vertices)
+            if (M.nvox == 0 || M.nmv > 0) continue;                   // (robots with the land_water surface mesh: resident / streaming kernels)
+            if (tiled_ == 2 || small_population || !fused_ || fused_variant(M).block == 0) cand.push_back(r);
+        }
+        // tiles per robot: one bond per lane if the CUs allow it (a step then costs one bond evaluation + one voxel update + the
+        // barrier), fewer when the candidates outnumber the CUs
+        auto k_latency = [&](const RobotModel& M) { return std::max(1, (int)((M.nbond * 5LL / 4 + VXH_TILE_BLOCK - 1) / VXH_TILE_BLOCK)); };
+        long long sum_lat = 0;
+        for (int r : cand) sum_lat += k_latency(robots_[r]);
+        struct Planned { int r; TilePlan plan; int tabg; size_t lds; };
+        std::vector<Planned> planned;
+        for (int r : cand) {
+            const RobotModel& M = robots_[r];
+            const int tab_doubles = (int)(M.bond_classes.size() * sizeof(DBondClass) / 8 + M.vox_classes.size() * sizeof(DVoxClass) / 8);
+            const int tabg = (size_t)tab_doubles * 8 > 32 * 1024 ? 1 : 0;
+            int k = tiles_per_robot_ > 0 ? tiles_per_robot_
+                                         : (sum_lat <= D.n_cu ? k_latency(M) : std::max(1, (int)(k_latency(M) * (long long)D.n_cu / sum_lat)));
+            k = std::max(1, std::min(k, M.nvox / 8));
+            for (;;) {
+                TilePlan P = plan_tiles(M, k);
+                size_t lds = 0;
+                for (const auto& t : P.tiles)
+                    lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles).total * 8);
+                if (P.k > VXH_TILE_MAX_TILES) break;                  // (left to the other kernels)
+                if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds}); break; }
+                if (k >= M.nvox / 8) break;                           // cannot be tiled: left to the other kernels
+                k = std::min(std::max(k + 1, k * 5 / 4 + 1), std::max(1, M.nvox / 8));
+            }
+        }
+        // launches: all tiles of a robot in one launch, a launch no larger than what the chip keeps resident (the tiles of a
+        // robot wait for each other); 226 vector registers: at most two workgroups per CU
+        for (int tabg = 0; tabg < 2; ++tabg) {
+            Device::TileLaunch cur;
+            cur.tabg = tabg;
+            auto capacity = [&](size_t lds) { return (long long)D.n_cu * std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)(lds + VXH_TILE_STATIC_LDS))); };
+            for (auto& q : planned) {
+                if (q.tabg != tabg) continue;
+                const int k = q.plan.k;
+                if (k > capacity(q.lds)) continue;                    // more tiles than the chip holds: not tiled
+                const size_t lds = std::max(cur.lds, q.lds);
+                if (cur.count > 0 && cur.count + k > capacity(lds)) { D.tile_launches.push_back(cur); cur = Device::TileLaunch(); cur.tabg = tabg; }
+                cur.lds = std::max(cur.lds, q.lds);
+                const int tile0 = (int)h_tiles.size(), base = D.vox_begin[q.r];
+                for (int t = 0; t < k; ++t) {
+                    const TilePlan::Tile& T = q.plan.tiles[t];
+                    DTile d;
+                    d.robot = q.r; d.tile0 = tile0; d.ntiles = k;
+                    d.n_own = (int)T.own.size(); d.n_halo = (int)T.halo.size(); d.nb = (int)T.bond_v1.size();
+                    d.vox_off = (int)tile_vox.size(); d.bond_off = (int)tile_bond.size();
+                    d.xoff = nx_total; d.pad = 0;
+                    for (size_t i = 0; i < T.own.size(); ++i) { tile_vox.push_back(base + T.own[i]); xslot[base + T.own[i]] = nx_total + (int)i; }
+                    nx_total += ((int)T.own.size() + 63) / 64 * 64;
+                    for (int v : T.halo) tile_vox.push_back(-(base + v) - 1);      // (exchange slots once every tile of the robot has its range)
+                    for (size_t b = 0; b < T.bond_v1.size(); ++b) {
+                        tile_bond.push_back(T.bond_entry[b]);
+                        tile_bcls.push_back(robots_[q.r].bond_class[(size_t)T.bond_v1[b] * 3 + T.bond_axis[b]]);
+                        tile_bslot.push_back(T.bond_axis[b] * nv + base + T.bond_v1[b]);
+                    }
+                    cur.tile_ids.push_back((int)h_tiles.size());
+                    h_tiles.push_back(d);
+                }
+                for (int t = 0; t < k; ++t) {                          // halo voxels: global slot -> exchange slot
+                    const DTile& d = h_tiles[tile0 + t];
+                    for (int i = 0; i < d.n_halo; ++i) { int& e = tile_vox[d.vox_off + d.n_own + i]; e = xslot[-(e + 1)]; }
+                }
+                cur.count += k;
+                cur.robots.push_back(q.r);
+                D.robot_tiled[q.r] = 1;
+                D.robot_tiles[q.r] = k;
+            }
+            if (cur.count > 0) D.tile_launches.push_back(cur);
+        }
+        for (auto& L : D.tile_launches) {
+            L.list = D.upload(L.tile_ids);
+            // a launch with no more tiles than CUs: a CU to every tile.  Two tiles that share a CU share its SIMDs, run at half
+            // speed, and the whole robot waits for them at every barrier; asking for more than half of the LDS keeps them apart.
+            if (L.count <= D.n_cu) L.lds = std::max(L.lds, (size_t)(81 * 1024));
+        }
+    }
+    {
+        std::vector<int> tile_of(h_tiles.empty() ? 1 : nv, -1), tile_lidx(h_tiles.empty() ? 1 : nv, 0);
+        for (size_t t = 0; t < h_tiles.size(); ++t)
+            for (int k = 0; k < h_tiles[t].n_own; ++k) { const int g = tile_vox[h_tiles[t].vox_off + k]; tile_of[g] = (int)t; tile_lidx[g] = k; }
+        B.tile_of = D.upload(tile_of);
+        B.tile_lidx = D.upload(tile_lidx);
+        B.col_code = D.alloc_zero<int>(h_tiles.empty() ? 1 : (size_t)std::max(ns, 1) * VXH_MAXCOL);
+        B.tile_xh = D.alloc_zero<int>(std::max<size_t>(1, h_tiles.size()) * VXH_TILE_XH);
+        B.tile_xhn = D.alloc_zero<int>(std::max<size_t>(1, h_tiles.size()));
+    }
+    B.n_tiles = (int)h_tiles.size();
+    B.tiles = D.upload(h_tiles);
+    B.tile_vox = D.upload(tile_vox);
+    B.tile_bond = D.upload(tile_bond);
+    B.tile_bcls = D.upload(tile_bcls);
+    B.tile_bslot = D.upload(tile_bslot);
+    B.nx = std::max(nx_total, 64);
+    B.xslot = D.upload(xslot);
+    B.xch = D.alloc_zero<unsigned long long>(h_tiles.empty() ? 1 : (size_t)48 * B.nx);
+    B.tile_mv = D.alloc_zero<unsigned long long>(std::max<size_t>(1, h_tiles.size()) * 3 * VXH_TILE_MV_STRIDE);
+    {   // fused path: launch groups by kernel variant; inside a group the longest-running robots first
+        D.groups.clear();
+        for (int r = 0; r < nr; ++r) {
+            if (D.robot_tiled[r]) continue;
+            const FusedVariant fv = fused_variant(robots_[r]);
+            if (fv.block == 0) continue;                              // streaming kernels
             Device::Group* g = nullptr;
-            for (auto& q : D.groups) if (q.block == block && q.nacc == nacc && q.fluid == fluid && q.tabg == tabg) g = &q;
-            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = block; g->nacc = nacc; g->fluid = fluid; g->tabg = tabg; }
+            for (auto& q : D.groups) if (q.block == fv.block && q.nacc == fv.nacc && q.fluid == fv.fluid && q.tabg == fv.tabg) g = &q;
+            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = fv.block; g->nacc = fv.nacc; g->fluid = fv.fluid; g->tabg = fv.tabg; }
             g->robots.push_back(r);
-            g->lds = std::max(g->lds, need(nacc, !tabg));
+            g->lds = std::max(g->lds, fv.lds);
         }
         {
+            // masks of the robots the streaming kernels step: everything the other kernels do not take / (option fused = 0)
+            // everything but the tiled robots
             std::vector<unsigned char> all(std::max(nr, 1), 1), rest(std::max(nr, 1), 1);
             for (auto& g : D.groups) for (int r : g.robots) rest[r] = 0;
-            D.n_rest = 0;
-            for (int r = 0; r < nr; ++r) if (rest[r] && robots_[r].nvox > 0) ++D.n_rest;
+            for (int r = 0; r < nr; ++r) if (D.robot_tiled[r]) all[r] = rest[r] = 0;
+            D.n_rest = D.n_all = 0;
+            for (int r = 0; r < nr; ++r) { if (rest[r] && robots_[r].nvox > 0) ++D.n_rest; if (all[r] && robots_[r].nvox > 0) ++D.n_all; }
             D.streamed_all = D.upload(all);
             D.streamed_rest = D.upload(rest);
         }
@@ -538,7 +717,7 @@ void Engine::prepare()
         D.reb_i0 = D.upload(ri);
     }
 #ifdef VXH_PHASE_TIMING
-    B.prof = D.alloc_zero<unsigned long long>(16 * 8);
+    B.prof = D.alloc_zero<unsigned long long>(16 * 8 + 256 * 8);
 #endif
     B.small_angle_w = std::cos(VXH_SMALL_ANGLE_RAD * 0.5);                    // Vec3D.h:55-59
     B.smallish_angle_w = std::cos(VXH_HYST * VXH_SMALL_ANGLE_RAD * 0.5);
@@ -552,19 +731,34 @@ void Engine::prepare()
 
 void Engine::reset() { if (!robots_.empty()) prepare(); }
 
+// The opt-in to more than 64 KB of dynamic LDS is per function AND per device (engines on several devices and threads may live in
+// one process): the largest size granted on each device is remembered per kernel, under a lock.
+static void grant_dynamic_lds(const void* kernel, size_t (&granted)[64], size_t lds)
+{
+    static std::mutex lock;
+    int dev = 0;
+    hip_check(hipGetDevice(&dev), "hipGetDevice");
+    std::lock_guard<std::mutex> hold(lock);
+    if (dev < 0 || dev >= 64 || lds > granted[dev]) {
+        hip_check(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
+        if (dev >= 0 && dev < 64) granted[dev] = lds;
+    }
+}
+
 template <int BLOCK, int NACC, bool FLUID, bool TABG>
 static void launch_variant(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
-    // the opt-in to more than 64 KB of dynamic LDS is per function AND per device (engines on several devices may live in
-    // one process); remember the largest size granted on each
-    static size_t attr_lds[64] = {};
-    int dev = 0;
-    hip_check(hipGetDevice(&dev), "hipGetDevice");
-    if (dev < 0 || dev >= 64 || lds > attr_lds[dev]) {
-        hip_check(hipFuncSetAttribute((const void*)k_robot_steps<BLOCK, NACC, FLUID, TABG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(fused LDS)");
-        if (dev >= 0 && dev < 64) attr_lds[dev] = lds;
-    }
+    static size_t granted[64] = {};
+    grant_dynamic_lds((const void*)k_robot_steps<BLOCK, NACC, FLUID, TABG>, granted, lds);
     hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters);
+}
+
+template <bool TABG>
+static void launch_tiles(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
+{
+    static size_t granted[64] = {};
+    grant_dynamic_lds((const void*)k_tile_steps<TABG>, granted, lds);
+    hipLaunchKernelGGL((k_tile_steps<TABG>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
 }
 
 template <bool FLUID, bool TABG>
@@ -594,7 +788,8 @@ void Engine::advance(long long max_rounds)
     // robots that fit the resident kernel are stepped by their launch groups, the others (more than 1024 voxels, oversized
     // mesh) by the streaming kernels, side by side on their own streams; with the option fused = 0 everything streams
     const bool fused = fused_ && !D.groups.empty();
-    const bool streaming = !fused || D.n_rest > 0;
+    const bool tiled = !D.tile_launches.empty();
+    const bool streaming = fused ? D.n_rest > 0 : D.n_all > 0;
     B.streamed = fused ? D.streamed_rest : D.streamed_all;
     // per-robot step counts before, to attribute the work of this call
     std::vector<int> steps_before(robots_.size());
@@ -613,6 +808,22 @@ void Engine::advance(long long max_rounds)
             }
         }
         for (auto& g : D.groups) HIP_OK(hipEventRecord(g.t1, g.stream));
+    }
+    long long tile_launch_count = 0;
+    if (tiled) {
+        // every tiled launch on the one tile stream: the tiles of a robot wait for each other, so two such launches must never
+        // compete for the CUs
+        const int iters = std::max(1, steps_per_launch_);
+        HIP_OK(hipStreamWaitEvent(D.tile_stream, D.ev0, 0));
+        HIP_OK(hipEventRecord(D.tile_t0, D.tile_stream));
+        for (long long done = 0; done < todo || done == 0; done += iters)
+            for (const auto& L : D.tile_launches) {
+                ++tile_gen_;
+                if (L.tabg) launch_tiles<true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                else launch_tiles<false>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                ++launches; ++tile_launch_count;
+            }
+        HIP_OK(hipEventRecord(D.tile_t1, D.tile_stream));
     }
     if (streaming) {
         const int nb_b = (3 * B.nv + 255) / 256, nb_v = (B.nv + 255) / 256;
@@ -644,6 +855,7 @@ void Engine::advance(long long max_rounds)
         launches += (D.any_fluid ? 5 : 3) * todo + 1;
     }
     if (fused) for (auto& g : D.groups) HIP_OK(hipStreamWaitEvent(D.stream, g.t1, 0));
+    if (tiled) HIP_OK(hipStreamWaitEvent(D.stream, D.tile_t1, 0));
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(D.ev1, D.stream));
     HIP_OK(hipStreamSynchronize(D.stream));
@@ -663,13 +875,25 @@ void Engine::advance(long long max_rounds)
         vs += ds * robots_[r].nvox; ab += ds * (224.0 * robots_[r].nvox + 144.0 * robots_[r].nbond);
     };
     for (size_t r = 0; r < robots_.size(); ++r) if (robots_[r].nvox) work((int)r, all_vs, all_ab);
-    if (fused && !D.groups.empty()) {
+    double tile_vs = 0, tile_ab = 0;                        // what the tiled kernel did
+    int n_tiled = 0;
+    for (size_t r = 0; r < robots_.size(); ++r) if (D.robot_tiled[r]) { work((int)r, tile_vs, tile_ab); ++n_tiled; }
+    double grp_best = 0;
+    if (fused) for (size_t k = 0; k < D.groups.size(); ++k) { double v = 0, a = 0; for (int r : D.groups[k].robots) work(r, v, a); grp_best = std::max(grp_best, v); }
+    if (tiled && tile_vs >= grp_best && tile_vs >= all_vs - tile_vs - grp_best) {
+        float cms = 0;
+        HIP_OK(hipEventElapsedTime(&cms, D.tile_t0, D.tile_t1));
+        counters_.dominant_block = 1;                      // (1 = k_tile_steps; the resident kernel reports its workgroup size)
+        counters_.dominant_robots = n_tiled;
+        counters_.dominant_launches = tile_launch_count; counters_.dominant_seconds = cms * 1e-3;
+        counters_.dominant_alg_bytes = tile_ab; counters_.dominant_voxel_steps = tile_vs;
+    } else if (fused && !D.groups.empty()) {
         size_t best = 0;
         for (size_t k = 0; k < D.groups.size(); ++k) {
             for (int r : D.groups[k].robots) work(r, grp_vs[k], grp_ab[k]);
             if (grp_vs[k] > grp_vs[best]) best = k;
         }
-        double rest_vs = all_vs, rest_ab = all_ab;           // what the streaming kernels did next to the groups
+        double rest_vs = all_vs - tile_vs, rest_ab = all_ab - tile_ab;   // what the streaming kernels did next to the groups
         for (size_t k = 0; k < D.groups.size(); ++k) { rest_vs -= grp_vs[k]; rest_ab -= grp_ab[k]; }
         if (streaming && rest_vs > grp_vs[best]) {
             counters_.dominant_block = 0; counters_.dominant_robots = D.n_rest;
@@ -683,9 +907,9 @@ void Engine::advance(long long max_rounds)
             counters_.dominant_alg_bytes = grp_ab[best]; counters_.dominant_voxel_steps = grp_vs[best];
         }
     } else {
-        counters_.dominant_block = 0; counters_.dominant_robots = (int)robots_.size();
+        counters_.dominant_block = 0; counters_.dominant_robots = (int)robots_.size() - n_tiled;
         counters_.dominant_launches = todo; counters_.dominant_seconds = ms * 1e-3;
-        counters_.dominant_alg_bytes = all_ab; counters_.dominant_voxel_steps = all_vs;
+        counters_.dominant_alg_bytes = all_ab - tile_ab; counters_.dominant_voxel_steps = all_vs - tile_vs;
     }
 }
 
@@ -724,6 +948,9 @@ void Engine::download_control()
         H.eol_post_y = S.eol_post_y;
         for (int k = 0; k < 3; ++k) H.ini_cm[k] = S.ini_cm[k];
         if (S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
+        if (S.status == 5)
+            throw std::runtime_error("HIP: the tiles of robot " + std::to_string(r) + " timed out waiting for each other (is another process "
+                                     "using this GPU? set the engine option tiled = 0 then)");
         vs += (double)M.nvox * S.steps; bs += (double)M.nbond * S.steps; ab += (224.0 * M.nvox + 144.0 * M.nbond) * S.steps;
         mx = std::max(mx, (long long)S.steps);
     }

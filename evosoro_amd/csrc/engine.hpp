@@ -49,7 +49,11 @@ private:
     int graph_steps_ = 32;                     // streaming path: step rounds captured per hipGraph launch (0 = plain launches)
     int dbg_ = 0;
     bool fused_ = true;                        // one-workgroup-per-robot fused kernel when every robot has <= 1024 voxels
-    int steps_per_launch_ = 256;               // fused path: time steps per kernel launch
+    int steps_per_launch_ = 256;               // fused and tiled paths: time steps per kernel launch
+    int tiled_ = 1;                            // several workgroups per robot (kernels_tiled.hpp): 0 never, 1 when the population is too
+                                               // small to fill the CUs one robot each or a robot has more than 1024 voxels, 2 always
+    int tiles_per_robot_ = 0;                  // 0 = chosen from the population size; > 0: requested for every tiled robot (tests)
+    unsigned tile_gen_ = 0;                    // launch generation of the tiled kernel (high half of the tiles' flag words)
     vxh_counters counters_{};
 };
 

@@ -245,17 +245,14 @@ __device__ __forceinline__ void store_bond_hist(const DBatch& B, int slot, const
     if (h.flags != old_flags) B.small_angle[slot] = (unsigned char)h.flags;
 }
 
-// One internal bond along axis A between voxel 1 (negative side) and voxel 2: pure arithmetic, `H` in/out.
+// One internal bond in the BOND frame (the bond lies along +x: the caller has applied ToXDirBond to the relative position and
+// to both orientations): pure arithmetic, `H` in/out.  The outputs are still in the permuted global frame (the caller applies
+// ToOrigDirBond); f2 is only computed for heterogeneous bonds (F2 = -F1 is enforced after the back-rotation otherwise).
 // damp_on = a previous step exists (no damping on the first one, dt == 0 then: VXS_BondInternal.cpp:311).
-template <int A>
-__device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClass& C, BondHist& H,
-                                                d3 p1, dq q1, double s1, d3 p2, dq q2, double s2,
-                                                bool damp_on)
+__device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DBondClass& C, BondHist& H,
+                                                       d3 xrel, dq a1, dq a2, double nom_dist, bool damp_on)
 {
     BondOut o;
-    const double nom_dist = (s1 + s2) * 0.5;
-    d3 xrel = to_xdir<A>(p2 - p1);
-    dq a1 = to_xdir<A>(q1), a2 = to_xdir<A>(q2);
     d3 rel = rotinv(a1, xrel);
     dq new2 = qmul(conj(a1), a2);
 
@@ -333,10 +330,40 @@ __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClas
     // back to the global frame (:158-171): three or four vectors go through the same RotateVec3DInv(rot, .), so the
     // rotation is expanded once into its matrix (conj(q) v q = R^T v for a unit quaternion; |rot| = 1 to rounding)
     const RotInv T(rot);
-    o.f1 = to_orig<A>(T(f1));
-    o.f2 = C.homogeneous ? -o.f1 : to_orig<A>(T(f2));
-    o.m1 = to_orig<A>(T(m1));
-    o.m2 = to_orig<A>(T(m2));
+    o.f1 = T(f1);
+    if (!C.homogeneous) o.f2 = T(f2);
+    o.m1 = T(m1);
+    o.m2 = T(m2);
+    return o;
+}
+
+// ... along axis A between voxel 1 (negative side) and voxel 2, the axis a compile-time constant (fused and streaming kernels)
+template <int A>
+__device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClass& C, BondHist& H,
+                                                d3 p1, dq q1, double s1, d3 p2, dq q2, double s2,
+                                                bool damp_on)
+{
+    BondOut o = bond_compute_xframe(B, C, H, to_xdir<A>(p2 - p1), to_xdir<A>(q1), to_xdir<A>(q2), (s1 + s2) * 0.5, damp_on);
+    o.f1 = to_orig<A>(o.f1);
+    o.f2 = C.homogeneous ? -o.f1 : to_orig<A>(o.f2);
+    o.m1 = to_orig<A>(o.m1);
+    o.m2 = to_orig<A>(o.m2);
+    return o;
+}
+
+// ... the axis a per-lane run-time value (tiled kernel: one flat bond list per tile, all axes in one round).  The same
+// permutations as to_xdir<A> / to_orig<A> written with selects: bit-identical results (negation is exact).
+__device__ __forceinline__ d3 to_xdir_rt(int a, d3 p) { return mk3(a == 0 ? p.x : (a == 1 ? p.y : p.z), a == 1 ? -p.x : p.y, a == 2 ? -p.x : p.z); }
+__device__ __forceinline__ dq to_xdir_rt(int a, dq q) { return mkq(q.w, a == 0 ? q.x : (a == 1 ? q.y : q.z), a == 1 ? -q.x : q.y, a == 2 ? -q.x : q.z); }
+__device__ __forceinline__ d3 to_orig_rt(int a, d3 p) { return mk3(a == 0 ? p.x : (a == 1 ? -p.y : -p.z), a == 1 ? p.x : p.y, a == 2 ? p.x : p.z); }
+__device__ __forceinline__ BondOut bond_compute_rt(int axis, const DBatch& B, const DBondClass& C, BondHist& H,
+                                                   d3 p1, dq q1, double s1, d3 p2, dq q2, double s2, bool damp_on)
+{
+    BondOut o = bond_compute_xframe(B, C, H, to_xdir_rt(axis, p2 - p1), to_xdir_rt(axis, q1), to_xdir_rt(axis, q2), (s1 + s2) * 0.5, damp_on);
+    o.f1 = to_orig_rt(axis, o.f1);
+    o.f2 = C.homogeneous ? -o.f1 : to_orig_rt(axis, o.f2);
+    o.m1 = to_orig_rt(axis, o.m1);
+    o.m2 = to_orig_rt(axis, o.m2);
     return o;
 }
 
@@ -393,6 +420,22 @@ __device__ __forceinline__ d3 facet_drag_force(d3 speed, d3 sdir, d3 A, d3 Bv, d
 
 struct VoxState { d3 pos, lm, am; dq ang; double scale; };
 
+// CalcContactForce (VXS_BondCollision.cpp:41-59) of one listed partner at (qx, qy, qz), scale qs, on the voxel at `pos`: Force2 =
+// unit(p2 - p1) * a1 * overlap on Vox2 (the later surface voxel), -Force2 on Vox1.  Seen from this voxel that is
+// -unit(partner - me) * a1 * overlap in both roles, bit for bit (negation is exact, the sums commute).
+__device__ __forceinline__ d3 contact_force_add(d3 F, d3 pos, double scale, double qx, double qy, double qz, double qs, double a1)
+{
+    const d3 d = mk3(qx - pos.x, qy - pos.y, qz - pos.z);
+    const double nom = (qs + scale) * 0.75;
+    const double d2 = len2(d);
+    if (d2 < nom * nom) {                                  // cheap reject: most listed partners are out of reach
+        const double l = vsqrt_nn(d2);
+        const double reld = nom - l;
+        if (reld > 0) F = F - ((d * vrcp(l)) * a1) * reld;
+    }
+    return F;
+}
+
 // position + scale of another voxel of the same robot, for the contact forces
 struct FetchGlobal {       // streaming path: previous-step buffer in HBM
     const DBatch& B; int cur;
@@ -424,6 +467,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
                                                double t, double act_sin, double act_cos, double prenatal_c, d3 F, d3 M, d3 vel,
                                                VoxState& S, int row, int ccnt, bool fluid, d3 drag, double ph_sin, double ph_cos, float amp_damp)
 {
+    // (v: global voxel slot = what the contact rows and `fetch` speak)
     const int flags = R.flags;
     const double dt = R.dt;
     if (ccnt > 0) {
@@ -443,17 +487,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (o[j] < 0) continue;
-                // CalcContactForce: Force2 = unit(p2 - p1) * a1 * overlap on Vox2 (the later surface voxel), -Force2 on
-                // Vox1.  Seen from this voxel that is -unit(partner - me) * a1 * overlap in both roles, bit for bit
-                // (negation is exact, the sums commute).
-                const d3 d = mk3(qx[j] - S.pos.x, qy[j] - S.pos.y, qz[j] - S.pos.z);
-                const double nom = (qs[j] + S.scale) * 0.75;
-                const double d2 = len2(d);
-                if (d2 < nom * nom) {                                  // cheap reject: most listed partners are out of reach
-                    const double l = vsqrt_nn(d2);
-                    const double reld = nom - l;
-                    if (reld > 0) F = F - ((d * vrcp(l)) * a1[j]) * reld;
-                }
+                F = contact_force_add(F, S.pos, S.scale, qx[j], qy[j], qz[j], qs[j], a1[j]);
             }
         }
     }
@@ -603,10 +637,12 @@ __device__ __forceinline__ StepCtl step_control_begin(const DRobot& R, DRobotSta
 __device__ __forceinline__ void step_control_horizon(const DRobot& R, DRobotState& rs, StepCtl& c)
 {
     if (c.go && (R.flags & RF_SELF_COL)) {                                       // UpdateCollisions :1729-1755
-        const double mv = sqrt(__longlong_as_double((long long)rs.maxvel2_bits));
-        rs.max_disp += fabs(mv * rs.dt_prev / R.lat);
+        // (lean sqrt / divide: bit-identical for the finite non-negative operands here, a third of the instructions -- this runs
+        // on one thread while its workgroup waits)
+        const double mv = vsqrt_nn(__longlong_as_double((long long)rs.maxvel2_bits));
+        rs.max_disp += fabs(vdiv(mv * rs.dt_prev, R.lat));
         rs.maxvel2_bits = 0ull;
-        if (!(R.flags & RF_HORIZON_COL) || rs.max_disp > (R.col_horizon - 1.0) / 2) { c.rebuild = 1; rs.max_disp = 0.0; rs.rebuilds += 1; }
+        if (!(R.flags & RF_HORIZON_COL) || rs.max_disp > (R.col_horizon - 1.0) / 2) { c.rebuild = 1; rs.max_disp = 0.0; rs.rebuilds += 1; rs.col_tiled = 0; }
     }
     rs.rebuild_now = c.rebuild;
 }
@@ -618,33 +654,45 @@ __device__ __forceinline__ StepCtl step_control(const DRobot& R, DRobotState& rs
 }
 
 // ================================================================================================ streaming path
+// where the whole-robot passes (IniCM latch, broad-phase) read position + scale of an arbitrary voxel of the robot
+struct PoseFromState {     // streaming path: the state planes, buffer `cur`
+    const DBatch& B; int cur;
+    __device__ __forceinline__ void operator()(int slot, double& x, double& y, double& z, double& s) const
+    { x = POS(cur, 0, slot); y = POS(cur, 1, slot); z = POS(cur, 2, slot); s = SCALE(cur, slot); }
+};
 // IniCM latch (= SS.CurCM of the previous step: mass-weighted SEQUENTIAL sum in voxel order, GetCM VX_Sim.cpp:2415-2430)
-// and EndOfLifetimePosteriorY (getPosteriorY :2640-2656).  Whole workgroup; `sh` holds 4*CH doubles of LDS scratch.
-__device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobotState& rs, int cur, bool latch, bool eol, double* sh, int CH)
+// and EndOfLifetimePosteriorY (getPosteriorY :2640-2656).  Whole workgroup; `sh` holds 5*CH doubles of LDS scratch.
+template <class Pose>
+__device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobotState& rs, const Pose& pose, bool latch, bool eol, double* sh, int CH)
 {
+    // The sums keep the reference's order (one thread adds voxel after voxel), but only the additions are serial: the products
+    // x * m are formed by the staging threads (the same single rounding), and the y / lat of getPosteriorY is taken once, of the
+    // smallest y (v -> v / lat is monotone for lat > 0, so the minimum of the rounded quotients is the rounded quotient of the minimum)
     const int tid = threadIdx.x, T = blockDim.x, base = R.vox_begin;
-    double sx = 0, sy = 0, sz = 0, sm = 0, miny = 100000.0;
+    double sx = 0, sy = 0, sz = 0, sm = 0, miny = 1.0e300;
     for (int c0 = 0; c0 < R.nvox; c0 += CH) {
         for (int k = tid; k < CH && c0 + k < R.nvox; k += T) {
             const int g = base + c0 + k;
             const DVoxClass& C = B.vclass_tab[R.vtab_begin + B.vclass[g]];
-            sh[k] = POS(cur, 0, g); sh[CH + k] = POS(cur, 1, g); sh[2 * CH + k] = POS(cur, 2, g);
-            sh[3 * CH + k] = (C.mat == 5) ? -C.mass : C.mass;   // sign marks the material excluded from PosteriorY
+            double x, y, z, unused_scale;
+            pose(g, x, y, z, unused_scale);
+            sh[k] = __dmul_rn(x, C.mass); sh[CH + k] = __dmul_rn(y, C.mass); sh[2 * CH + k] = __dmul_rn(z, C.mass);
+            sh[3 * CH + k] = C.mass;
+            sh[4 * CH + k] = (C.mat == 5) ? 1.0e300 : y;        // material 5 is excluded from PosteriorY
         }
         __syncthreads();
         if (tid == 0) {
             const int n = min(CH, R.nvox - c0);
             for (int k = 0; k < n; ++k) {
-                const double m = fabs(sh[3 * CH + k]);
-                sx = __dadd_rn(sx, __dmul_rn(sh[k], m)); sy = __dadd_rn(sy, __dmul_rn(sh[CH + k], m)); sz = __dadd_rn(sz, __dmul_rn(sh[2 * CH + k], m)); sm += m;
-                if (!(sh[3 * CH + k] < 0)) { const double y = sh[CH + k] / R.lat; if (y < miny) miny = y; }
+                sx = __dadd_rn(sx, sh[k]); sy = __dadd_rn(sy, sh[CH + k]); sz = __dadd_rn(sz, sh[2 * CH + k]); sm += sh[3 * CH + k];
+                miny = sh[4 * CH + k] < miny ? sh[4 * CH + k] : miny;
             }
         }
         __syncthreads();
     }
     if (tid == 0) {
         if (latch) { const double inv = 1.0 / sm; rs.ini_cm[0] = inv * sx; rs.ini_cm[1] = inv * sy; rs.ini_cm[2] = inv * sz; rs.cm_init = 1; }
-        if (eol) rs.eol_post_y = miny;
+        if (eol) { const double q = miny / R.lat; rs.eol_post_y = q < 100000.0 ? q : 100000.0; }
     }
 }
 
@@ -657,32 +705,30 @@ __device__ __forceinline__ double contact_a1(const DVoxClass& C1, const DVoxClas
     return E * (L * L) / L;
 }
 
-// CalcL1Bonds (VX_Sim.cpp:2357-2413).  The calling workgroup builds the partner rows of surface voxels
-// [i_begin, i_begin + blockDim.x) of robot R: every surface voxel tests all others (staged through LDS in chunks of
+// CalcL1Bonds (VX_Sim.cpp:2357-2413).  The calling workgroup builds the partner rows of the surface voxels its
+// threads own: every surface voxel tests all others (staged through LDS in chunks of
 // CH) and keeps, in ascending partner order = creation order of its collision bonds in the reference, those that
 // pass the distance filter, are more than `hops` bonds away and lie within CollisionHorizon scaled voxel sizes.
 // `sh`: 4*CH doubles + CH ints of LDS.
-__device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, DRobotState& rs, int cur, int i_begin, double* sh, int CH)
+// Thread `tid` owns surface ordinal i (`mine` = it has one).
+template <class Pose>
+__device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, DRobotState& rs, const Pose& pose, int i, bool mine, double* sh, int CH)
 {
     const int tid = threadIdx.x, T = blockDim.x;
     int* shv = (int*)(sh + 4 * CH);
-    const int i = i_begin + tid;
-    const bool mine = i < R.nsurf;
     int vi = 0, cnt = 0;
     const unsigned long long* row = B.excl + R.excl_begin + (long long)(mine ? i : 0) * R.excl_wpr;
     d3 pi = mk3(0, 0, 0); double si = 0;
     if (mine) {
         vi = B.surf[R.surf_begin + i];
-        pi = mk3(POS(cur, 0, vi), POS(cur, 1, vi), POS(cur, 2, vi));
-        si = SCALE(cur, vi);
+        pose(vi, pi.x, pi.y, pi.z, si);
     }
     const double H = R.col_horizon;
     for (int c0 = 0; c0 < R.nsurf; c0 += CH) {
         const int n = min(CH, R.nsurf - c0);
         for (int k = tid; k < n; k += T) {
             const int vj = B.surf[R.surf_begin + c0 + k];
-            sh[k] = POS(cur, 0, vj); sh[CH + k] = POS(cur, 1, vj); sh[2 * CH + k] = POS(cur, 2, vj);
-            sh[3 * CH + k] = SCALE(cur, vj); shv[k] = vj;
+            pose(vj, sh[k], sh[CH + k], sh[2 * CH + k], sh[3 * CH + k]); shv[k] = vj;
         }
         __syncthreads();
         if (mine) {
@@ -724,7 +770,7 @@ __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap
     if (!B.streamed[r]) return;             // (stepped by the resident kernel)
     const DRobot& R = B.robot[r];
     DRobotState& rs = B.rstate[r];
-    __shared__ double sh[4 * 256];
+    __shared__ double sh[5 * 256];
     __shared__ int s_go, s_latch, s_eol;
     if (threadIdx.x == 0) {
         StepCtl c = step_control(R, rs, step_cap, begin_new_step);
@@ -733,7 +779,7 @@ __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap
     }
     __syncthreads();
     if (!s_go) return;
-    if (s_latch || s_eol) latch_cm(B, R, rs, rs.steps & 1, s_latch != 0, s_eol != 0, sh, 256);
+    if (s_latch || s_eol) latch_cm(B, R, rs, PoseFromState{B, rs.steps & 1}, s_latch != 0, s_eol != 0, sh, 256);
 }
 
 template <int A>
@@ -823,7 +869,8 @@ __global__ __launch_bounds__(256) void k_bonds(DBatch B, int bond_blocks, const 
         const int r = reb_robot[k];
         DRobotState& rs = B.rstate[r];
         if (!B.streamed[r] || !rs.active || !rs.rebuild_now) return;
-        rebuild_rows(B, B.robot[r], rs, rs.steps & 1, reb_i0[k], sh, 512);
+        const int i = reb_i0[k] + (int)threadIdx.x;
+        rebuild_rows(B, B.robot[r], rs, PoseFromState{B, rs.steps & 1}, i, i < B.robot[r].nsurf, sh, 512);
         return;
     }
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -907,3 +954,4 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
 }  // namespace vxh
 
 #include "kernels_fused.hpp"
+#include "kernels_tiled.hpp"

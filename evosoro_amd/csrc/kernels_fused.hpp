@@ -29,8 +29,14 @@ namespace vxh {
 
 enum { VXH_FUSED_STATIC_LDS = 320 };      // upper bound of the kernel's static __shared__ variables
 
-// developer instrumentation (tests/dev_gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
+// developer instrumentation (scripts/dev_gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
 // of the phases of a step
+// what-if switches (contact forces off, MaxVoxVel reduction off): developer library only, compiled out of libvxhip.so
+#ifdef VXH_PHASE_TIMING
+#define VXH_DBG(bit) (B.dbg & (bit))
+#else
+#define VXH_DBG(bit) false
+#endif
 #ifdef VXH_PHASE_TIMING
 #define VXH_T_DECL unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long t_last = __builtin_readcyclecounter();
 #define VXH_T_MARK(k) { const unsigned long long t_now = __builtin_readcyclecounter(); t_acc[k] += t_now - t_last; t_last = t_now; }
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (K.rebuild) { fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct); scratch_used = true; }
         if (scratch_used) { acc[tid] = 0.0; __syncthreads(); }
         // the partner count only changes when the broad-phase ran; no global load sits at the head of the step's queue
-        if (K.rebuild || it == 0) ccnt = (rowv >= 0 && !(B.dbg & 1)) ? B.col_cnt[rowv] : 0;
+        if (K.rebuild || it == 0) ccnt = (rowv >= 0 && !VXH_DBG(1)) ? B.col_cnt[rowv] : 0;
         d3 drag = mk3(0, 0, 0);
         const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
         if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK, NACC * 6 * BLOCK>(B, R, ps, st, st_stride, mesh, acc, valid, vv, lm, C.mass_inv, dcache); }
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             lm = S.lm; am = S.am;
         }
         if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
-        if ((R.flags & RF_SELF_COL) && !(B.dbg & 2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
+        if ((R.flags & RF_SELF_COL) && !VXH_DBG(2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { double o2 = __shfl_xor(vel2, off); vel2 = o2 > vel2 ? o2 : vel2; }
             if ((tid & 63) == 0) atomicMax(&rs.maxvel2_bits, (unsigned long long)__double_as_longlong(vel2));

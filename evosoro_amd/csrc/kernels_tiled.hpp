@@ -1,0 +1,766 @@
+// Tiled path of the batched Voxelyze stepper: k_tile_steps<TABG>, SEVERAL workgroups per robot, all of them resident for a
+// whole launch of many time steps (included at the end of kernels.hpp).  It serves the cases the one-workgroup-per-robot
+// kernel (kernels_fused.hpp) cannot fill the chip with: a lattice of more than 1024 voxels (BASELINE configs[4], one
+// 20x20x20 robot), and populations smaller than the number of CUs (64 robots on 256 CUs).  Loop being tiled:
+// CVX_Sim::Integrate, VX_Sim.cpp:1763-1933.
+//
+// A robot is cut into tiles (model.cpp plan_tiles: a grid of boxes with equal voxel counts).  A tile's workgroup
+//   * OWNS n_own voxels: momenta in registers (thread t = owned voxel t), poses in its LDS pose tile;
+//   * MIRRORS n_halo voxels: the far ends of the bonds that leave the tile, refreshed every step from the owners;
+//   * evaluates every bond with at least one owned end, all three axes in ONE round (flat bond list, axis per lane at run
+//     time: bond_compute_rt), history and mode bits resident in LDS.  A bond that crosses a tile boundary is evaluated by
+//     both tiles from the same poses with the same code -- the same bits -- so forces never travel between tiles;
+//   * sums each owned voxel's six bond forces from per-direction LDS planes (one writer per entry, no atomics) in the same
+//     order as the fused kernel of the robot's size class, so a robot's trajectory does not depend on how it was tiled.
+// What leaves the CU per step: the owned poses (8 doubles per voxel) and one max-|v|^2 word per tile, as self-validating
+// 8-byte granules {32 data bits, 32-bit tag} (DBatch::xch, tile_mv), each one write-through store (global_store_dwordx2 sc1 =
+// a relaxed agent-scope atomic store), read with L1-bypassing loads of the same kind.  A granule is never torn and its tag
+// (launch generation, redo epoch, publication count) says which step it belongs to, so nothing needs ordering: no flag, no
+// fence, no vmcnt drain (cdna_hip_programming.md Guideline 16, form R2).  A step n of a tile (five wavefronts: four of
+// workers, one of SERVICE):
+//   1. every worker wave polls the granules of ITS halo voxels (and of the contact partners the tile mirrors) until they carry
+//      this step's tag -- the neighbours' previous voxel phase -- and writes the poses into LDS;      -> workgroup barrier
+//   2. bond phase on the workers;                                                                     -> workgroup barrier
+//   3. voxel phase on the workers: forces from the planes, contact partners from LDS, integration; the new pose goes out at
+//      once (granules).  It runs SPECULATIVELY: the per-robot barrier of the step -- every tile has published its max |v|^2 of
+//      the previous step, i.e. finished it -- is awaited meanwhile by the service wavefront, which reduces the words (the
+//      replicated control block needs MaxVoxVel for the collision horizon, VX_Sim.cpp:1729-1755), learns whether a bond
+//      diverged in the previous step, and decides whether the contact lists were due for a rebuild BEFORE this voxel phase
+//      (UpdateCollisions precedes Integrate, VX_Sim.cpp:1100-1110);                                     -> workgroup barrier
+//   4. the usual case -- no rebuild due -- commits: new poses into the pose tile, the tile's max |v|^2 goes out.  If a rebuild
+//      was due (a few times per thousand steps), the voxel phase is REDONE from the kept momenta after the broad-phase
+//      (the pose tile still holds the old poses); the redo epoch in the tags makes the neighbours ignore the poses of the
+//      discarded attempt.  Steps with a whole-robot pass that is known in advance (IniCM latch, the end of a launch), and
+//      robots whose lists are rebuilt every step (ColSystem without horizon), wait for the barrier before the voxel phase.
+// The exchange buffers form a ring of three: step n writes P(n+1) over P(n-2), and every tile is past reading P(n-2) -- it
+// published its max |v|^2 of step n-1, which this tile saw at the barrier of step n-1, after its own reads.
+// A diverging bond (strain > 100, VX_Sim.cpp:1775) stops the robot BEFORE the voxel loop of that step; the other tiles learn
+// of it at the next per-robot barrier: the voxel phase that ran meanwhile is rolled back (momenta kept a step, poses still in
+// the ring); the bond history of a stopped robot is dead.
+// The control block (time, stop rule, collision horizon) is replicated: every tile runs the same serial control code on the
+// same inputs.  Residency: all tiles of a robot must be on the chip at the same time; the host sizes every launch to what the
+// CUs admit and issues the tiled launches of an engine on ONE stream.  Spins are bounded (VXH_ROBOT_SYNC_TIMEOUT).
+#pragma once
+
+namespace vxh {
+
+enum { VXH_TILE_SPIN_LIMIT = 1 << 22 };      // polls of one wait before the robot is given up (each costs a memory round trip: seconds)
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define VXH_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// tag of the granules of publication `pub` (1 = the poses a launch starts from, i + 2 = those its i-th step produced) in redo
+// epoch `ep` of launch generation `gen`; never 0, the value of never-written memory (pub >= 1)
+__device__ __forceinline__ unsigned tile_tag(unsigned gen, unsigned ep, int pub) { return ((gen & 0xffu) << 24) | ((ep & 0x3fu) << 18) | ((unsigned)pub & 0x3ffffu); }
+
+// a double as two granules {data, tag}: planes lo / hi are `stride` granules apart
+__device__ __forceinline__ void st_gran2(unsigned long long* lo, size_t stride, double x, unsigned tag)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x), t = (unsigned long long)tag << 32;
+    __hip_atomic_store((gu64*)lo, t | (b & 0xffffffffull), VXH_RLX_AGENT);
+    __hip_atomic_store((gu64*)(lo + stride), t | (b >> 32), VXH_RLX_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_gran(const unsigned long long* p) { return __hip_atomic_load((const gu64*)p, VXH_RLX_AGENT); }
+__device__ __forceinline__ double gran2_value(unsigned long long lo, unsigned long long hi)
+{ return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32))); }
+
+// max of a non-negative double over the 64 lanes of a (fully active) wavefront, returned in every lane: four DPP row shifts, two
+// row broadcasts (VALU speed; a shuffle through the LDS crossbar costs ten times as much per stage, an LDS atomic on one address
+// serialises its 64 lanes)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_stage(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    const double o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));     // 0.0 where no lane feeds this one
+    return o > v ? o : v;
+}
+__device__ __forceinline__ double wave_max_nonneg(double v)
+{
+    v = dpp_max_stage<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_max_stage<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_max_stage<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_max_stage<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row of 16 holds the row's maximum
+    v = dpp_max_stage<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_max_stage<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// position + scale of any voxel of the robot as its owner published it for the current step (broad-phase, latch, contact
+// partners the tile does not mirror).  Called behind the step's per-robot barrier, when every tile has stored these granules;
+// stored is not yet visible (nothing orders one wavefront's max-|v|^2 word behind another's pose granules), so this read, like
+// every read of the exchange buffer, goes by the tags and repeats until they are this step's (bounded: `abort_flag`).
+struct PoseFromXch {
+    const unsigned long long* xq; unsigned nx;          // xq = exchange buffer of the step: [16][nx]
+    const int* xslot;                                   // exchange slot of every voxel (DBatch::xslot)
+    unsigned tag; int* abort_flag;
+    __device__ __forceinline__ void at(int xs, double& x, double& y, double& z, double& s) const
+    {
+        unsigned long long g[8];
+        for (int spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = ld_gran(xq + (size_t)k * nx + xs);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
+            if (ok) break;
+            if (spins > VXH_TILE_SPIN_LIMIT) { *abort_flag = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        x = gran2_value(g[0], g[1]); y = gran2_value(g[2], g[3]); z = gran2_value(g[4], g[5]); s = gran2_value(g[6], g[7]);
+    }
+    __device__ __forceinline__ void operator()(int voxel_slot, double& x, double& y, double& z, double& s) const { at(xslot[voxel_slot], x, y, z, s); }
+};
+
+// contact partner of an owned voxel: from the tile's LDS when the broad-phase found it there (`code`: an owned voxel's index in
+// the pose tile, or np + entry of the mirrored-partner planes px), else (-1) from the exchange buffer; -2 = the voxel itself
+// (lanes without a partner in this round of the contact loop)
+struct FetchTile {
+    static constexpr bool USES_CODE = true;
+    const double* ps; const double* px; int np, self;
+    bool live;                              // the codes are valid (rows built by this kernel); else every partner comes from memory
+    PoseFromXch remote;
+    __device__ __forceinline__ bool in_memory(int code) const { return code == -1 || !live; }
+    __device__ __forceinline__ void memory(int slot, double& x, double& y, double& z, double& s) const { remote(slot, x, y, z, s); }
+    __device__ __forceinline__ void local(int code, double& x, double& y, double& z, double& s) const
+    {
+        const int l = code == -2 ? self : code;
+        if (l < np) { x = ps[l]; y = ps[np + l]; z = ps[2 * np + l]; s = ps[3 * np + l]; }
+        else { const int e = l - np; x = px[e]; y = px[VXH_TILE_XH + e]; z = px[2 * VXH_TILE_XH + e]; s = px[3 * VXH_TILE_XH + e]; }
+    }
+};
+
+// The contact forces of an owned voxel (the head of voxel_update, same arithmetic: contact_force_add), from the tile's copy of
+// its contact row in LDS (codes + stiffnesses at rc_code / rc_a1 [roff ..), every partner in LDS too), or, for a row that does
+// not fit or has a partner the tile does not mirror, from the rows in memory like the other kernels (the memory requests of a
+// round issued together, and only by wavefronts that have any).
+__device__ __forceinline__ d3 tile_contacts(const DBatch& B, const FetchTile& fetch, d3 F, const VoxState& S, int v, int row, int ccnt, int roff,
+                                            const int* rc_code, const double* rc_a1)
+{
+    if (ccnt <= 0) return F;
+    if (roff >= 0) {
+        for (int k0 = 0; k0 < ccnt; k0 += 4) {
+            int code[4]; double a1[4], qx[4], qy[4], qz[4], qs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const bool on = k0 + j < ccnt; code[j] = on ? rc_code[roff + k0 + j] : -2; a1[j] = on ? rc_a1[roff + k0 + j] : 0.0; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fetch.local(code[j], qx[j], qy[j], qz[j], qs[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (code[j] != -2) F = contact_force_add(F, S.pos, S.scale, qx[j], qy[j], qz[j], qs[j], a1[j]);
+        }
+        return F;
+    }
+    for (int k0 = 0; k0 < ccnt; k0 += 4) {
+        int o[4], code[4]; double a1[4], qx[4], qy[4], qz[4], qs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = k0 + j < ccnt;
+            const size_t at = (size_t)(k0 + j) * B.col_rows + row;
+            o[j] = on ? B.col_partner[at] : -1;
+            a1[j] = on ? B.col_a1[at] : 0.0;
+            code[j] = on ? B.col_code[at] : -2;
+        }
+        bool from_memory = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) from_memory = from_memory || (o[j] >= 0 && fetch.in_memory(code[j]));
+        if (__any(from_memory)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fetch.memory(o[j] < 0 ? v : o[j], qx[j], qy[j], qz[j], qs[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!(o[j] >= 0 && fetch.in_memory(code[j]))) fetch.local(o[j] < 0 ? -2 : code[j], qx[j], qy[j], qz[j], qs[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (o[j] >= 0) F = contact_force_add(F, S.pos, S.scale, qx[j], qy[j], qz[j], qs[j], a1[j]);
+    }
+    return F;
+}
+
+// CalcL1Bonds (VX_Sim.cpp:2357-2413) for the surface voxels a tile owns (worker thread t: surface ordinal `i` of its voxel, -1 =
+// none; every thread of the workgroup calls).  Like rebuild_rows (kernels.hpp) every row tests all surface voxels of the robot,
+// staged through LDS in chunks of CH from the exchange buffer, and keeps the accepted ones in ascending order.  Differences:
+//  * a chunk whose bounding box lies farther than the distance filter from the bounding box of the tile's own surface voxels is
+//    skipped by the whole workgroup (every pair in it would fail the filter: exact);
+//  * every accepted partner gets a CODE, the place where the voxel phase will find its position in LDS: the pose tile entry
+//    of a partner the tile owns, or a mirrored-partner entry (DBatch::tile_xh) -- the partners owned by other tiles are
+//    collected in an LDS hash set, numbered once the rows are complete, and the codes written in a second pass; beyond
+//    VXH_TILE_XH distinct ones (or a full set): -1, fetched from memory.
+// `sh`: 5 * CH doubles + CH ints; `hkey` / `hval`: VXH_TILE_HASH ints each.  Returns the thread's partner count.
+__device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, int ti, const PoseFromXch& pose,
+                                            const double* ps, int np, int i, int* xh, int* s_xhn, double* s_box, double* sh, int* hkey, int* hval)
+{
+    constexpr int CH = VXH_TILE_CH, NT = VXH_TILE_THREADS, NW = VXH_TILE_THREADS / 64;
+    const int tid = threadIdx.x;
+    int* shv = (int*)(sh + 4 * CH);
+    const bool mine = i >= 0;
+    int vi = 0, cnt = 0;
+    d3 pi = mk3(0, 0, 0); double si = 0;
+    const int row = R.surf_begin + (mine ? i : 0);
+    if (mine) { vi = B.surf[R.surf_begin + i]; pi = mk3(ps[tid], ps[np + tid], ps[2 * np + tid]); si = ps[3 * np + tid]; }
+    for (int h = tid; h < VXH_TILE_HASH; h += NT) hkey[h] = 0;
+    // bounding box of the tile's own surface voxels (s_box[0..5] = min xyz, max xyz), through two rounds of wave reductions
+    {
+        double lo[3] = {mine ? pi.x : 1e300, mine ? pi.y : 1e300, mine ? pi.z : 1e300}, hi[3] = {mine ? pi.x : -1e300, mine ? pi.y : -1e300, mine ? pi.z : -1e300};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const double l = __shfl_xor(lo[a], off), h = __shfl_xor(hi[a], off); lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a]; }
+        if ((tid & 63) == 0) { for (int a = 0; a < 3; ++a) { s_box[12 + (tid >> 6) * 6 + a] = lo[a]; s_box[12 + (tid >> 6) * 6 + 3 + a] = hi[a]; } }
+        if (tid == 0) *s_xhn = 0;
+        __syncthreads();
+        if (tid < 3) {
+            double l = s_box[12 + tid], h = s_box[12 + 3 + tid];
+            for (int w = 1; w < NW; ++w) { l = fmin(l, s_box[12 + w * 6 + tid]); h = fmax(h, s_box[12 + w * 6 + 3 + tid]); }
+            s_box[tid] = l; s_box[3 + tid] = h;
+        }
+        __syncthreads();
+    }
+    const double fd = vsqrt(R.filter_dist2) * (1.0 + 1e-12);      // (a hair more than the filter distance: the cull must never reject a pair the filter would pass)
+    const double tlo[3] = {s_box[0] - fd, s_box[1] - fd, s_box[2] - fd}, thi[3] = {s_box[3] + fd, s_box[4] + fd, s_box[5] + fd};
+    const double H = R.col_horizon;
+    const unsigned long long* xrow = B.excl + R.excl_begin + (long long)(mine ? i : 0) * R.excl_wpr;
+    for (int c0 = 0; c0 < R.nsurf; c0 += CH) {
+        const int n = min(CH, R.nsurf - c0);
+        double cx = 0, cy = 0, cz = 0;
+        if (tid < n) {
+            const int vj = B.surf[R.surf_begin + c0 + tid];
+            double cs;
+            pose(vj, cx, cy, cz, cs);
+            sh[tid] = cx; sh[CH + tid] = cy; sh[2 * CH + tid] = cz; sh[3 * CH + tid] = cs; shv[tid] = vj;
+        }
+        if (tid < CH) {                       // the chunk's bounding box (CH = two wavefronts)
+            double lo[3] = {tid < n ? cx : 1e300, tid < n ? cy : 1e300, tid < n ? cz : 1e300}, hi[3] = {tid < n ? cx : -1e300, tid < n ? cy : -1e300, tid < n ? cz : -1e300};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const double l = __shfl_xor(lo[a], off), h = __shfl_xor(hi[a], off); lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a]; }
+            if ((tid & 63) == 0) { for (int a = 0; a < 3; ++a) { s_box[12 + (tid >> 6) * 6 + a] = lo[a]; s_box[12 + (tid >> 6) * 6 + 3 + a] = hi[a]; } }
+        }
+        __syncthreads();
+        bool far = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double l = fmin(s_box[12 + a], s_box[18 + a]), h = fmax(s_box[12 + 3 + a], s_box[18 + 3 + a]);
+            far = far || l > thi[a] || h < tlo[a];
+        }
+        if (mine && !far) {
+            const unsigned long long w0 = xrow[c0 >> 6], w1 = (c0 + 64 < R.nsurf) ? xrow[(c0 >> 6) + 1] : 0ull;   // chunk starts are multiples of 128
+            for (int k0 = 0; k0 < n; k0 += 4) {
+                double qx[4], qy[4], qz[4], qs[4], d2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int k = min(k0 + u, n - 1); qx[u] = sh[k]; qy[u] = sh[CH + k]; qz[u] = sh[2 * CH + k]; qs[u] = sh[3 * CH + k]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d2[u] = len2(pi - mk3(qx[u], qy[u], qz[u]));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + u, j = c0 + k;
+                    if (k >= n || j == i) continue;
+                    if (!(d2[u] < R.filter_dist2)) continue;
+                    if (((k < 64 ? w0 : w1) >> (k & 63)) & 1ull) continue;          // !pV1->IsNearbyVox(SIndex2)
+                    const double s1 = (j > i) ? si : qs[u];                          // scale of Vox1 = the earlier one, used twice (:2382)
+                    const double act = H * (s1 + s1) * 0.5;
+                    if (d2[u] < act * act) {
+                        if (cnt < VXH_MAXCOL) {
+                            const int vj = shv[k];
+                            const DVoxClass& Ci = B.vclass_tab[R.vtab_begin + B.vclass[vi]];
+                            const DVoxClass& Cj = B.vclass_tab[R.vtab_begin + B.vclass[vj]];
+                            const size_t at = (size_t)cnt * B.col_rows + row;
+                            B.col_partner[at] = vj;
+                            B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
+                            if (B.tile_of[vj] != ti) {                               // into the set of partners to mirror (linear probing)
+                                unsigned h = ((unsigned)vj * 2654435761u) >> (32 - VXH_TILE_HASH_BITS);
+                                for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (VXH_TILE_HASH - 1)) {
+                                    const int old = atomicCAS(&hkey[h], 0, vj + 1);
+                                    if (old == 0 || old == vj + 1) break;
+                                }
+                            }
+                        }
+                        ++cnt;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (mine) {
+        if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
+        B.col_cnt[row] = cnt;
+    }
+    for (int h = tid; h < VXH_TILE_HASH; h += NT) {               // number the distinct partners to mirror
+        if (hkey[h] == 0) continue;
+        const int e = atomicAdd(s_xhn, 1);
+        if (e < VXH_TILE_XH) { xh[e] = B.xslot[hkey[h] - 1]; hval[h] = np + e; } else hval[h] = -1;
+    }
+    __syncthreads();
+    if (mine) {                                                    // second pass: the codes of my row
+        for (int k = 0; k < cnt; ++k) {
+            const size_t at = (size_t)k * B.col_rows + row;
+            const int vj = B.col_partner[at];
+            int code = -1;
+            if (B.tile_of[vj] == ti) code = B.tile_lidx[vj];
+            else {
+                unsigned h = ((unsigned)vj * 2654435761u) >> (32 - VXH_TILE_HASH_BITS);
+                for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (VXH_TILE_HASH - 1)) {
+                    if (hkey[h] == vj + 1) { code = hval[h]; break; }
+                    if (hkey[h] == 0) break;
+                }
+            }
+            B.col_code[at] = code;
+        }
+    }
+    if (tid == 0) { if (*s_xhn > VXH_TILE_XH) *s_xhn = VXH_TILE_XH; rs.col_tiled = 1; }
+    __syncthreads();
+    for (int e = tid; e < *s_xhn; e += NT) B.tile_xh[(size_t)ti * VXH_TILE_XH + e] = xh[e];   // for the launches to come
+    if (tid == 0) B.tile_xhn[ti] = *s_xhn;
+    return cnt;
+}
+
+// developer instrumentation (library built with -DVXH_PHASE_TIMING): per-wave cycle sums of the phases of a step
+#ifdef VXH_PHASE_TIMING
+#define VXH_TT_DECL unsigned long long tt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter();
+#define VXH_TT_MARK(k) { const unsigned long long tt_now = __builtin_readcyclecounter(); tt_acc[k] += tt_now - tt_last; tt_last = tt_now; }
+#define VXH_TT_FLUSH if (B.prof && (threadIdx.x & 63) == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&B.prof[(threadIdx.x >> 6) * 8 + k], tt_acc[k]); }
+#else
+#define VXH_TT_DECL
+#define VXH_TT_MARK(k)
+#define VXH_TT_FLUSH
+#endif
+
+
+template <bool TABG>
+__global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const DRobot* __restrict__ robots, const DTile* __restrict__ tiles,
+                                                                 const int* __restrict__ tile_list, long long step_cap, int iters, unsigned gen)
+{
+    constexpr int BLOCK = VXH_TILE_BLOCK, NT = VXH_TILE_THREADS;   // worker threads (one per owned voxel), all threads
+    extern __shared__ __align__(16) double lds[];
+    __shared__ DRobotState rs, rs_bak;
+    __shared__ FusedCtl s_ctl[2];
+    __shared__ double s_wmax[BLOCK / 64];
+    __shared__ double s_box[12 + 6 * (NT / 64)];
+    __shared__ int s_div, s_divprev, s_abort, s_xhn, s_pool;
+    static_assert(2 * sizeof(DRobotState) + 2 * sizeof(FusedCtl) + sizeof(double) * (BLOCK / 64) + sizeof(double) * (12 + 6 * (NT / 64)) + 5 * sizeof(int) + 32 <= VXH_TILE_STATIC_LDS, "static LDS bound");
+
+    const int tid = threadIdx.x;
+    const bool svc = tid >= BLOCK;            // the service wavefront: per-robot barrier, control block
+    const int ti = __builtin_amdgcn_readfirstlane(tile_list[blockIdx.x]);
+    const DTile& T = tiles[ti];
+    const int r = T.robot;
+    const DRobot& R = robots[r];
+    const unsigned nv = B.nv;                 // (the SoA macros)
+    (void)nv;
+    const int n_own = T.n_own, n_halo = T.n_halo, nb = T.nb, k_tiles = T.ntiles;
+    const int nbd = TABG ? 0 : R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = TABG ? 0 : R.n_vclass * (int)(sizeof(DVoxClass) / 8);
+    const TileLayout L = tile_layout(n_own, n_halo, nb, nbd + nvd);
+    const int np = L.np, no = L.no, nbp = L.nbp;
+    double* const ps = lds + L.o_ps;          // [8][np] pose tile: owned voxels, then halo voxels
+    double* const pl = lds + L.o_pl;          // [6 directions][6][no] bond force / minus bond moment on every owned voxel
+    double* const hl = lds + L.o_hl;          // [6][nbp] bond history
+    double* const pht = lds + L.o_pht;        // [2][no] sin / cos of the actuation phase offsets
+    double* const sc = lds + L.o_sc;          // scratch of latch / broad-phase
+    double* const px = lds + L.o_px;          // [4][VXH_TILE_XH] position + scale of the mirrored contact partners
+    double* const rc_a1 = lds + L.o_rc;       // [VXH_TILE_ROWPOOL] the tile's contact rows: pair stiffnesses ...
+    double* const tabs = lds + L.o_tab;
+    int* const bent = (int*)(lds + L.o_int);  // [nbp] packed bond entries
+    int* const bcls = bent + nbp;             // [nbp] bond classes
+    int* const hf = bcls + nbp;               // [nbp] mode bits (bit 0 SmallAngle, bit 1 history layout)
+    int* const xh = hf + nbp;                 // [VXH_TILE_XH] contact partners owned by other tiles, mirrored in px (their exchange slots)
+    int* const hkey = xh + VXH_TILE_XH;       // [VXH_TILE_HASH] broad-phase: set of the partners to mirror
+    int* const hval = hkey + VXH_TILE_HASH;
+    int* const rc_code = hval + VXH_TILE_HASH;   // [VXH_TILE_ROWPOOL] ... and partner codes
+    const unsigned nx = B.nx;                 // exchange slots (every tile's owned voxels contiguous: its pose stores fill whole lines)
+    const size_t xbuf = (size_t)16 * nx;      // granules per exchange buffer (a ring of three)
+    const int xs_own = T.xoff + tid;          // exchange slot of my owned voxel
+    const size_t mvbuf = (size_t)VXH_TILE_MV_STRIDE * B.n_tiles;
+
+    if (svc) __builtin_amdgcn_s_setprio(3);   // its few instructions sit on the critical path of the whole robot; it shares a SIMD with a worker
+    if (tid == 0) { rs = B.rstate[r]; s_div = 0; s_divprev = 0; s_abort = 0; s_pool = 0; s_xhn = B.rstate[r].col_tiled ? B.tile_xhn[ti] : 0; }
+    bool codes_live = B.rstate[r].col_tiled != 0;      // contact rows built by this kernel (else: every partner from memory until the next broad-phase)
+    for (int e = tid; e < VXH_TILE_XH; e += NT) xh[e] = B.tile_xh[(size_t)ti * VXH_TILE_XH + e];
+    const DBondClass* bct;
+    const DVoxClass* vct;
+    if constexpr (TABG) {
+        bct = B.bclass_tab + R.btab_begin;
+        vct = B.vclass_tab + R.vtab_begin;
+    } else {
+        for (int k = tid; k < nbd; k += NT) tabs[k] = ((const double*)(B.bclass_tab + R.btab_begin))[k];
+        for (int k = tid; k < nvd; k += NT) tabs[nbd + k] = ((const double*)(B.vclass_tab + R.vtab_begin))[k];
+        bct = (const DBondClass*)tabs;
+        vct = (const DVoxClass*)(tabs + nbd);
+    }
+    for (int b = tid; b < nb; b += NT) {
+        bent[b] = B.tile_bond[T.bond_off + b];
+        bcls[b] = B.tile_bcls[T.bond_off + b];
+        const int slot = B.tile_bslot[T.bond_off + b];
+        hf[b] = B.small_angle[slot] & 3;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) hl[k * nbp + b] = HIST(k, slot);
+    }
+    for (int k = tid; k < 36 * no; k += NT) pl[k] = 0.0;         // directions without a bond stay zero for the whole launch
+
+    // ---- this thread's owned voxel: momenta -> registers, pose -> LDS and -> the exchange buffer of the current step
+    const int n0 = B.rstate[r].steps;                              // steps taken before this launch (every tile reads the same)
+    unsigned ring = (unsigned)n0 % 3u;                             // ring slot of the poses of the current step
+    unsigned ep = 0;                                               // redo epoch (voxel phases redone in this launch so far)
+    const bool valid = tid < n_own;
+    const int gv = valid ? B.tile_vox[T.vox_off + tid] : R.vox_begin;
+    const DVoxClass& C = vct[valid ? B.vclass[gv] : 0];
+    int row = -1;
+    int my_ord = -1;                          // my ordinal in the robot's surface list (broad-phase)
+    float amp_damp = 1.f;
+    d3 lm = mk3(0, 0, 0), am = mk3(0, 0, 0);
+    if (valid) {
+        const int b0 = n0 & 1;
+        if (R.flags & RF_SELF_COL) { my_ord = B.surf_ord[gv]; if (my_ord >= 0) row = R.surf_begin + my_ord; }
+        amp_damp = B.amp_damp[gv];
+        pht[tid] = B.act_sb[gv]; pht[no + tid] = B.act_cb[gv];
+        lm = mk3(LINMOM(0, gv), LINMOM(1, gv), LINMOM(2, gv));
+        am = mk3(ANGMOM(0, gv), ANGMOM(1, gv), ANGMOM(2, gv));
+        const double q8[8] = {POS(b0, 0, gv), POS(b0, 1, gv), POS(b0, 2, gv), SCALE(b0, gv), QUAT(0, gv), QUAT(1, gv), QUAT(2, gv), QUAT(3, gv)};
+        unsigned long long* const xq0 = B.xch + (size_t)ring * xbuf + xs_own;
+        const unsigned tag1 = tile_tag(gen, 0, 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ps[k * np + tid] = q8[k]; st_gran2(xq0 + (size_t)(2 * k) * nx, nx, q8[k], tag1); }
+    }
+    d3 lm_bak = lm, am_bak = am;              // momenta before the last committed voxel phase (a diverged step is undone)
+    // the halo voxels are spread over the worker threads from the last one down: wave 0, which owns the first voxels, gets them last
+    const int hslot0 = svc ? (1 << 30) : BLOCK - 1 - tid;
+    const int hv0 = hslot0 < n_halo ? B.tile_vox[T.vox_off + n_own + hslot0] : 0;      // my (first) halo voxel: its exchange slot
+    __syncthreads();
+    const bool ctl_thread = tid == BLOCK;     // first lane of the service wavefront
+    if (tid == 0)   // the pending max |v|^2 of the last step before this launch travels like a step's: every tile publishes the robot-wide value
+        st_gran2(B.tile_mv + (size_t)ring * mvbuf + (size_t)ti * VXH_TILE_MV_STRIDE, 1, __longlong_as_double((long long)rs.maxvel2_bits), tile_tag(gen, 0, 1));
+    if (ctl_thread) fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]);
+    // my contact row: its length, and a copy in LDS when the rows were built by this kernel and fit
+    int ccnt = 0, roff = -1;
+    auto rows_to_lds = [&]() {                // (every thread calls: workgroup barriers inside)
+        if (tid == 0) s_pool = 0;
+        __syncthreads();
+        roff = -1;
+        if (valid && codes_live && ccnt > 0) {
+            bool all_local = true;
+            for (int k = 0; k < ccnt; ++k) all_local = all_local && B.col_code[(size_t)k * B.col_rows + row] != -1;
+            if (all_local) {
+                const int off = atomicAdd(&s_pool, ccnt);
+                if (off + ccnt <= VXH_TILE_ROWPOOL) {
+                    roff = off;
+                    for (int k = 0; k < ccnt; ++k) { const size_t at = (size_t)k * B.col_rows + row; rc_code[off + k] = B.col_code[at]; rc_a1[off + k] = B.col_a1[at]; }
+                }
+            }
+        }
+        __syncthreads();
+    };
+    if (valid) ccnt = row >= 0 ? B.col_cnt[row] : 0;
+    rows_to_lds();
+    // robots whose lists are rebuilt every step (no horizon logic) cannot speculate on "no rebuild due"
+    const bool can_speculate = !(R.flags & RF_SELF_COL) || (R.flags & RF_HORIZON_COL) != 0;
+
+    // the service wavefront's part of a step: wait until every tile of the robot has published its max |v|^2 for this step (= has
+    // finished the previous one), reduce, note a divergence, else take the collision-horizon decision of the step
+    constexpr int MVC = VXH_TILE_MAX_TILES / 64;
+    auto robot_barrier = [&](const unsigned long long* mvq, unsigned tag, unsigned long long (&mg)[2 * MVC], bool go, FusedCtl& K) {
+        const int lane = tid - BLOCK;
+        int spins = 0;
+#ifdef VXH_PHASE_TIMING
+        int polls = 0;
+        const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
+        for (;;) {
+#ifdef VXH_PHASE_TIMING
+            ++polls;
+#endif
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < MVC; ++c)
+                if (lane + 64 * c < k_tiles) ok = ok && (unsigned)(mg[2 * c] >> 32) == tag && (unsigned)(mg[2 * c + 1] >> 32) == tag;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > VXH_TILE_SPIN_LIMIT) { s_abort = 1; break; }
+#pragma unroll
+            for (int c = 0; c < MVC; ++c)
+                if (lane + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(lane + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
+        }
+#ifdef VXH_PHASE_TIMING
+        if (B.prof && ctl_thread) { atomicAdd(&B.prof[120], (unsigned long long)polls); atomicAdd(&B.prof[121], 1ull); atomicAdd(&B.prof[122], __builtin_readcyclecounter() - tp0); }
+#endif
+        double mvmax = 0.0;                   // max |v|^2 over the tiles; a negative word marks a tile in which a bond diverged
+        bool neg = false;
+#pragma unroll
+        for (int c = 0; c < MVC; ++c)
+            if (lane + 64 * c < k_tiles) { const double m = gran2_value(mg[2 * c], mg[2 * c + 1]); neg = neg || m < 0.0; mvmax = m > mvmax ? m : mvmax; }
+        neg = __any(neg) != 0;
+        mvmax = wave_max_nonneg(mvmax);
+        if (ctl_thread && !s_abort) {
+            s_divprev = neg ? 1 : 0;
+            if (!neg) {
+                rs.maxvel2_bits = (unsigned long long)__double_as_longlong(mvmax);
+                if (go) fused_control_horizon(R, rs, K);
+            }
+        }
+        return neg;
+    };
+
+    VXH_TT_DECL
+    for (int it = 0;; ++it) {
+        FusedCtl& K = s_ctl[it & 1];
+        FusedCtl& Knext = s_ctl[(it + 1) & 1];
+        VXH_TT_MARK(6)
+        const unsigned ringn = ring == 2 ? 0 : ring + 1, ringp = ring == 0 ? 2 : ring - 1;
+        const unsigned long long* const xq = B.xch + (size_t)ring * xbuf;      // poses at the start of this step
+        unsigned long long* const xqn = B.xch + (size_t)ringn * xbuf;          // ... of the next one
+        const unsigned tag = tile_tag(gen, ep, it + 1);
+        const bool go = K.go != 0;
+        // does this step's voxel phase run ahead of the per-robot barrier?  Not when a whole-robot pass is known to come (latch),
+        // not at the end of the launch (the control block written back needs the reduced max |v|^2)
+        const bool speculate = can_speculate && go && !K.latch && !K.eol;
+        int spins = 0;
+        // the service wavefront requests the robot's max-|v|^2 words at once (tiles lane, lane + 64, ...)
+        unsigned long long mg[2 * MVC];
+        const unsigned long long* const mvq = B.tile_mv + (size_t)ring * mvbuf + (size_t)T.tile0 * VXH_TILE_MV_STRIDE;
+        if (svc) {
+#pragma unroll
+            for (int c = 0; c < MVC; ++c) {
+                mg[2 * c] = mg[2 * c + 1] = 0;
+                if (tid - BLOCK + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(tid - BLOCK + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
+            }
+        }
+        // ---- 1. halo poses of this step: every worker wave waits for the granules of its own halo voxels
+        if (go) {
+            for (int h = hslot0; h < n_halo; h += BLOCK) {
+                const int hv = h == hslot0 ? hv0 : B.tile_vox[T.vox_off + n_own + h];
+                unsigned long long g[16];
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) g[k] = ld_gran(xq + (size_t)k * nx + hv);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > VXH_TILE_SPIN_LIMIT) { s_abort = 1; break; }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ps[k * np + n_own + h] = gran2_value(g[2 * k], g[2 * k + 1]);
+            }
+            // ... and the contact partners the tile mirrors (position + scale: 8 granules), same protocol
+            for (int e = hslot0; e < s_xhn; e += BLOCK) {
+                const int hv = xh[e];
+                unsigned long long g[8];
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) g[k] = ld_gran(xq + (size_t)k * nx + hv);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > VXH_TILE_SPIN_LIMIT) { s_abort = 1; break; }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) px[k * VXH_TILE_XH + e] = gran2_value(g[2 * k], g[2 * k + 1]);
+            }
+        }
+        if (tid == 0) s_div = 0;
+        __syncthreads();
+        VXH_TT_MARK(0)
+        const bool damp_on = K.damp_on != 0;
+
+        // ---- 2. workers: bond phase, every bond with an owned end, all axes in one round.  Service wavefront, on steps that do
+        // not speculate: the per-robot barrier
+        bool div = false;
+        if (svc) {
+            if (!speculate) { robot_barrier(mvq, tag, mg, go, K); VXH_TT_MARK(2) }
+        } else if (go && !s_abort) {
+            for (int b = tid; b < nb; b += BLOCK) {
+                const int e = bent[b];
+                const int l1 = e & 1023, l2 = (e >> 10) & 1023, axis = (e >> 20) & 3;
+                BondHist H;
+                H.p0 = hl[b]; H.p1 = hl[nbp + b]; H.p2 = hl[2 * nbp + b]; H.g0 = hl[3 * nbp + b]; H.g1 = hl[4 * nbp + b]; H.g2 = hl[5 * nbp + b];
+                H.flags = (unsigned)hf[b];
+                H.store_hist = false;
+                const d3 p1 = mk3(ps[l1], ps[np + l1], ps[2 * np + l1]);
+                const double s1 = ps[3 * np + l1];
+                const dq q1 = mkq(ps[4 * np + l1], ps[5 * np + l1], ps[6 * np + l1], ps[7 * np + l1]);
+                const d3 p2 = mk3(ps[l2], ps[np + l2], ps[2 * np + l2]);
+                const double s2 = ps[3 * np + l2];
+                const dq q2 = mkq(ps[4 * np + l2], ps[5 * np + l2], ps[6 * np + l2], ps[7 * np + l2]);
+                const BondOut o = bond_compute_rt(axis, B, bct[bcls[b]], H, p1, q1, s1, p2, q2, s2, damp_on);
+                if (H.store_hist) { hl[b] = H.p0; hl[nbp + b] = H.p1; hl[2 * nbp + b] = H.p2; hl[3 * nbp + b] = H.g0; hl[4 * nbp + b] = H.g1; hl[5 * nbp + b] = H.g2; }
+                hf[b] = (int)H.flags;
+                div = div || o.diverged;
+                if (l1 < n_own) {
+                    double* e1 = pl + (2 * axis) * 6 * no + l1;
+                    e1[0] = o.f1.x; e1[no] = o.f1.y; e1[2 * no] = o.f1.z; e1[3 * no] = -o.m1.x; e1[4 * no] = -o.m1.y; e1[5 * no] = -o.m1.z;
+                }
+                if (l2 < n_own) {
+                    double* e2 = pl + (2 * axis + 1) * 6 * no + l2;
+                    e2[0] = o.f2.x; e2[no] = o.f2.y; e2[2 * no] = o.f2.z; e2[3 * no] = -o.m2.x; e2[4 * no] = -o.m2.y; e2[5 * no] = -o.m2.z;
+                }
+            }
+            VXH_TT_MARK(1)
+        }
+        if (div) s_div = 1;
+        __syncthreads();                       // (B)
+        VXH_TT_MARK(3)
+        const PoseFromXch pose{xq, nx, B.xslot, tag, &s_abort};
+        if (!speculate) {
+            if (s_abort) break;
+            if (s_divprev) break;              // (undone below)
+            if (!go) break;
+            // ---- whole-robot passes (rare): IniCM latch by the robot's first tile (the others only note that it happened), broad-phase
+            if (K.latch || K.eol) {
+                if (ti == T.tile0) latch_cm(B, R, rs, pose, K.latch != 0, K.eol != 0, sc, VXH_TILE_CH);
+                else if (tid == 0) { if (K.latch) rs.cm_init = 1; if (K.eol) rs.eol_post_y = 1.0; }
+            }
+            if (K.rebuild) {
+                ccnt = tile_rebuild(B, R, rs, ti, pose, ps, np, my_ord, xh, &s_xhn, s_box, sc, hkey, hval);
+                codes_live = true;
+                // the partners mirrored from now on: their poses of THIS step (every tile is past publishing them)
+                for (int e = tid; e < s_xhn; e += NT) { double x, y, z, s1; pose.at(xh[e], x, y, z, s1); px[e] = x; px[VXH_TILE_XH + e] = y; px[2 * VXH_TILE_XH + e] = z; px[3 * VXH_TILE_XH + e] = s1; }
+                rows_to_lds();
+            }
+        }
+        VXH_TT_MARK(4)
+
+        // ---- 3. voxel phase; on a speculating step the service wavefront resolves the per-robot barrier meanwhile, and the phase
+        // is redone (attempt 1) after the broad-phase if the lists turn out to have been due for a rebuild
+        const bool diverged_here = s_div != 0;
+        double p8[8];
+        d3 lm_new = lm, am_new = am;
+        bool stop = false;
+        for (int attempt = 0;; ++attempt) {
+            double vel2 = 0;
+            const unsigned tagn = tile_tag(gen, ep, it + 2);
+            if (valid) {
+                // the six bond forces in the order of the fused kernel of the robot's size class: up to 768 voxels the bonds in which
+                // the voxel is the negative end first (+X +Y +Z), then those in which it is the positive end; above, +X -X +Y -Y +Z -Z
+                double a6[6];
+                const bool two_tiles = R.nvox <= 768;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double* q = pl + c * no + tid;
+                    const double pX = q[0], nX = q[6 * no], pY = q[12 * no], nY = q[18 * no], pZ = q[24 * no], nZ = q[30 * no];
+                    a6[c] = two_tiles ? ((pX + pY) + pZ) + ((nX + nY) + nZ) : ((((pX + nX) + pY) + nY) + pZ) + nZ;
+                }
+                d3 F = mk3(a6[0], a6[1], a6[2]), M = mk3(a6[3], a6[4], a6[5]);
+                VoxState S;
+                S.pos = mk3(ps[tid], ps[np + tid], ps[2 * np + tid]); S.scale = ps[3 * np + tid];
+                S.ang = mkq(ps[4 * np + tid], ps[5 * np + tid], ps[6 * np + tid], ps[7 * np + tid]);
+                S.lm = lm; S.am = am;
+                if (!diverged_here) {
+                    const d3 vel = S.lm * C.mass_inv;
+                    F = F + (vel * (-R.slow_z)) * C.c_lin;
+                    const FetchTile fetch{ps, px, np, tid, codes_live, pose};
+                    F = tile_contacts(B, fetch, F, S, gv, row, ccnt, roff, rc_code, rc_a1);
+                    vel2 = voxel_update(B, R, C, gv, pose, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, row, 0, false, mk3(0, 0, 0),
+                                        pht[tid], pht[no + tid], amp_damp);
+                }
+                lm_new = S.lm; am_new = S.am;
+                // out at once: the neighbours' next bond phase waits for exactly these granules (the pose tile keeps the old pose until
+                // every voxel of the tile has read its contact partners, and until the step is known to stand)
+                p8[0] = S.pos.x; p8[1] = S.pos.y; p8[2] = S.pos.z; p8[3] = S.scale; p8[4] = S.ang.w; p8[5] = S.ang.x; p8[6] = S.ang.y; p8[7] = S.ang.z;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_own, nx, p8[k], tagn);
+            }
+            if (svc && attempt == 0) {
+                bool neg = false;
+                if (speculate) { neg = robot_barrier(mvq, tag, mg, go, K); VXH_TT_MARK(2) }
+                // next step's control, off the critical path (not when the robot turns out to have stopped a step ago)
+                if (ctl_thread && !neg && !s_abort) { rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
+                VXH_TT_MARK(7)
+            }
+            if (!svc) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const double o2 = __shfl_xor(vel2, off); vel2 = o2 > vel2 ? o2 : vel2; }
+                if ((tid & 63) == 0) s_wmax[tid >> 6] = vel2;
+            }
+            VXH_TT_MARK(5)
+            __syncthreads();                   // (C) the voxel phase is complete and, on a speculating step, the per-robot barrier resolved
+            if (s_abort || s_divprev) { stop = true; break; }
+            if (speculate && attempt == 0 && K.rebuild) {
+                // mis-speculated: UpdateCollisions would have rebuilt the lists before this voxel phase.  Broad-phase on the poses
+                // of the step (all published: the barrier has been passed), then the phase again; its poses go out under a new epoch
+                ++ep;
+                ccnt = tile_rebuild(B, R, rs, ti, pose, ps, np, my_ord, xh, &s_xhn, s_box, sc, hkey, hval);
+                codes_live = true;
+                for (int e = tid; e < s_xhn; e += NT) { double x, y, z, s1; pose.at(xh[e], x, y, z, s1); px[e] = x; px[VXH_TILE_XH + e] = y; px[2 * VXH_TILE_XH + e] = z; px[3 * VXH_TILE_XH + e] = s1; }
+                rows_to_lds();
+                continue;
+            }
+            break;
+        }
+        if (stop) break;
+        // ---- 4. commit
+        lm_bak = lm; am_bak = am;
+        lm = lm_new; am = am_new;
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ps[k * np + tid] = p8[k];
+        }
+        if (tid == 0) {
+            double mv = 0.0;
+            if (R.flags & RF_SELF_COL) {       // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
+#pragma unroll
+                for (int w = 0; w < BLOCK / 64; ++w) mv = s_wmax[w] > mv ? s_wmax[w] : mv;
+            }
+            if (diverged_here) mv = -1.0;
+            st_gran2(B.tile_mv + (size_t)ringn * mvbuf + (size_t)ti * VXH_TILE_MV_STRIDE, 1, mv, tile_tag(gen, ep, it + 2));
+            if (B.dbg & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        ring = ringn;
+        (void)ringp;
+    }
+    VXH_TT_FLUSH
+    __syncthreads();
+    if (s_abort) {
+        if (tid == 0) atomicExch(&B.rstate[r].status, 5);                       // VXH_ROBOT_SYNC_TIMEOUT
+        return;
+    }
+    if (s_divprev) {
+        // a bond diverged in the last step whose poses are in the pose tile: Integrate() returned before its voxel loop
+        // (VX_Sim.cpp:1777), so that step's voxel phase is undone -- momenta from the copy kept a step, poses from the ring
+        lm = lm_bak; am = am_bak;
+        const unsigned long long* const xqp = B.xch + (size_t)(ring == 0 ? 2 : ring - 1) * xbuf;
+        if (valid) {
+            unsigned long long g[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) g[k] = ld_gran(xqp + (size_t)k * nx + xs_own);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ps[k * np + tid] = gran2_value(g[2 * k], g[2 * k + 1]);
+        }
+        if (ctl_thread) { rs = rs_bak; rs.diverged = 1; FusedCtl dummy; fused_control_begin(R, rs, step_cap, 0, dummy); }   // -> status diverged
+        __syncthreads();
+    }
+
+    // ---- back to HBM: state into the buffer the step count selects, bond history, control block (the robot's first tile)
+    if (valid) {
+        const int b1 = rs.steps & 1;
+        POS(b1, 0, gv) = ps[tid]; POS(b1, 1, gv) = ps[np + tid]; POS(b1, 2, gv) = ps[2 * np + tid];
+        SCALE(b1, gv) = ps[3 * np + tid];
+        QUAT(0, gv) = ps[4 * np + tid]; QUAT(1, gv) = ps[5 * np + tid]; QUAT(2, gv) = ps[6 * np + tid]; QUAT(3, gv) = ps[7 * np + tid];
+        LINMOM(0, gv) = lm.x; LINMOM(1, gv) = lm.y; LINMOM(2, gv) = lm.z;
+        ANGMOM(0, gv) = am.x; ANGMOM(1, gv) = am.y; ANGMOM(2, gv) = am.z;
+    }
+    for (int b = tid; b < nb; b += NT) {
+        if ((bent[b] & 1023) >= n_own) continue;                  // a bond is written back by the tile that owns its negative end
+        const int slot = B.tile_bslot[T.bond_off + b];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) HIST(k, slot) = hl[k * nbp + b];
+        B.small_angle[slot] = (unsigned char)(hf[b] & 3);
+    }
+    if (tid == 0) {
+        if (rs.col_overflow) atomicOr(&B.rstate[r].col_overflow, 1);
+        if (ti == T.tile0) {
+            const DRobotState out = rs;
+            DRobotState& g = B.rstate[r];
+            g.cur_time = out.cur_time; g.dt_prev = out.dt_prev; g.max_disp = out.max_disp;
+            g.ini_cm[0] = out.ini_cm[0]; g.ini_cm[1] = out.ini_cm[1]; g.ini_cm[2] = out.ini_cm[2];
+            g.eol_post_y = out.eol_post_y; g.act_sin = out.act_sin; g.act_cos = out.act_cos; g.maxvel2_bits = out.maxvel2_bits;
+            g.steps = out.steps; g.status = out.status; g.cm_init = out.cm_init; g.active = out.active; g.diverged = out.diverged;
+            g.rebuild_now = out.rebuild_now; g.rebuilds = out.rebuilds; g.col_tiled = out.col_tiled;
+        }
+    }
+}
+
+}  // namespace vxh

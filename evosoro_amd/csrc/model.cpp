@@ -317,4 +317,103 @@ RobotModel build_robot(const VxaModel& vxa)
     return r;
 }
 
+// ------------------------------------------------------------------------------------------------ tiling (kernels_tiled.hpp)
+namespace {
+
+// cut `vox` (voxel indices) into `parts` groups of equal size (+-1) along lattice axis `axis` (0 = x); ties keep voxel order
+std::vector<std::vector<int>> cut_along(const std::vector<int>& vox, const std::vector<int>& coord3, int axis, int parts)
+{
+    std::vector<int> sorted = vox;
+    std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) { return coord3[3 * a + axis] < coord3[3 * b + axis]; });
+    std::vector<std::vector<int>> out(parts);
+    const size_t n = sorted.size();
+    for (int p = 0; p < parts; ++p) {
+        const size_t lo = n * (size_t)p / parts, hi = n * (size_t)(p + 1) / parts;
+        out[p].assign(sorted.begin() + lo, sorted.begin() + hi);
+    }
+    return out;
+}
+
+}  // namespace
+
+TilePlan plan_tiles(const RobotModel& M, int k_request)
+{
+    TilePlan P;
+    const int n = M.nvox;
+    if (n == 0) return P;
+    const int nx = M.vxa.nx, ny = M.vxa.ny;
+    std::vector<int> coord3((size_t)n * 3);
+    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+    for (int v = 0; v < n; ++v) {
+        const int i = M.struct_index[v];
+        const int iz = i / (nx * ny), iy = (i - iz * nx * ny) / nx, ix = i - iz * nx * ny - iy * nx;
+        const int c[3] = {ix, iy, iz};
+        for (int a = 0; a < 3; ++a) { coord3[3 * (size_t)v + a] = c[a]; lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+    }
+    const double ext[3] = {double(hi[0] - lo[0] + 1), double(hi[1] - lo[1] + 1), double(hi[2] - lo[2] + 1)};
+    const double fill = n / (ext[0] * ext[1] * ext[2]);
+    // the grid: among k' in [0.8 k, k] and the factorisations k' = a b c (a <= ext x, ...), the one whose typical tile lists
+    // the fewest bonds (3 per voxel inside + 2 per boundary face voxel)
+    int kmax = std::max(1, std::min(k_request, n));
+    double best = 1e300;
+    for (int k = kmax; k >= std::max(1, (kmax * 4 + 4) / 5); --k)
+        for (int a = 1; a <= k; ++a) {
+            if (k % a || a > ext[0]) continue;
+            for (int b = 1; b <= k / a; ++b) {
+                if ((k / a) % b || b > ext[1]) continue;
+                const int c = k / a / b;
+                if (c > ext[2]) continue;
+                const double sx = ext[0] / a, sy = ext[1] / b, sz = ext[2] / c;
+                const double faces = (a > 1 ? 2 : 0) * sy * sz + (b > 1 ? 2 : 0) * sx * sz + (c > 1 ? 2 : 0) * sx * sy;
+                const double bonds = 3.0 * n / k + faces * fill;
+                if (bonds < best - 1e-9) { best = bonds; P.k = k; P.kx = a; P.ky = b; P.kz = c; }
+            }
+        }
+    if (P.k == 0) { P.k = P.kx = P.ky = P.kz = 1; }
+    P.tile_of.assign(n, 0);
+    std::vector<int> all(n);
+    for (int v = 0; v < n; ++v) all[v] = v;
+    int t = 0;
+    for (auto& gx : cut_along(all, coord3, 0, P.kx))
+        for (auto& gy : cut_along(gx, coord3, 1, P.ky))
+            for (auto& gz : cut_along(gy, coord3, 2, P.kz)) {
+                for (int v : gz) P.tile_of[v] = t;
+                ++t;
+            }
+    P.tiles.assign(P.k, TilePlan::Tile());
+    for (int v = 0; v < n; ++v) P.tiles[P.tile_of[v]].own.push_back(v);       // ascending
+    std::vector<int> local(n, -1);
+    for (int ti = 0; ti < P.k; ++ti) {
+        TilePlan::Tile& T = P.tiles[ti];
+        for (int v : T.own)
+            for (int d = 0; d < 6; ++d) {
+                const int o = M.nbr[(size_t)v * 6 + d];
+                if (o >= 0 && P.tile_of[o] != ti) T.halo.push_back(o);
+            }
+        std::sort(T.halo.begin(), T.halo.end());
+        T.halo.erase(std::unique(T.halo.begin(), T.halo.end()), T.halo.end());
+        for (size_t i = 0; i < T.own.size(); ++i) local[T.own[i]] = (int)i;
+        for (size_t i = 0; i < T.halo.size(); ++i) local[T.halo[i]] = (int)(T.own.size() + i);
+        for (int a = 0; a < 3; ++a) {
+            // bonds of axis a with an owned end, by negative-end voxel: the owned voxels' +a bonds and the halo voxels' +a bonds
+            // that end in an owned voxel
+            std::vector<int> v1s;
+            for (int v : T.own) if (M.nbr[(size_t)v * 6 + 2 * a] >= 0) v1s.push_back(v);
+            for (int v : T.halo) { const int o = M.nbr[(size_t)v * 6 + 2 * a]; if (o >= 0 && P.tile_of[o] == ti) v1s.push_back(v); }
+            std::sort(v1s.begin(), v1s.end());
+            for (int v1 : v1s) {
+                const int v2 = M.nbr[(size_t)v1 * 6 + 2 * a];
+                T.bond_v1.push_back(v1); T.bond_axis.push_back(a);
+                T.bond_entry.push_back((int)((unsigned)local[v1] | ((unsigned)local[v2] << 10) | ((unsigned)a << 20)));
+            }
+        }
+        for (int v : T.own) local[v] = -1;
+        for (int v : T.halo) local[v] = -1;
+        P.max_own = std::max(P.max_own, (int)T.own.size());
+        P.max_local = std::max(P.max_local, (int)(T.own.size() + T.halo.size()));
+        P.max_bonds = std::max(P.max_bonds, (int)T.bond_v1.size());
+    }
+    return P;
+}
+
 }  // namespace vxh

@@ -72,6 +72,25 @@ struct RobotModel {
 
 RobotModel build_robot(const VxaModel& vxa);   // throws std::runtime_error
 
+// A robot cut into tiles for the multi-workgroup kernel (kernels_tiled.hpp): a kx x ky x kz grid of boxes over the lattice,
+// cut positions chosen so that the tiles hold equal numbers of voxels.  Every voxel is OWNED by exactly one tile; a tile's
+// halo = the far ends of bonds that leave it; its bond list = every bond with at least one owned end, so a bond that crosses
+// a boundary is listed by both tiles.  Local index = position in `own` followed by `halo` (both ascending voxel index).
+struct TilePlan {
+    int k = 0, kx = 1, ky = 1, kz = 1;
+    std::vector<int> tile_of;               // [nvox]
+    struct Tile {
+        std::vector<int> own, halo;         // voxel indices
+        std::vector<int> bond_v1;           // negative-end voxel of every listed bond (sorted by axis, then voxel)
+        std::vector<int> bond_axis;
+        std::vector<int> bond_entry;        // local negative end | local positive end << 10 | axis << 20
+    };
+    std::vector<Tile> tiles;
+    int max_own = 0, max_local = 0, max_bonds = 0;
+};
+// k_request tiles or somewhat fewer (a k without a good factorisation into a grid is replaced by a smaller one with one)
+TilePlan plan_tiles(const RobotModel& model, int k_request);
+
 // number of TimeStep calls until StopConditionMet, replaying CurTime += dt in double precision
 long long plan_steps(const VxaModel& vxa, double dt);
 

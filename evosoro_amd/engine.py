@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_num_robots", "vxh_robot_dims",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_counters", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version"]
@@ -61,6 +61,12 @@ class VxhModelInfo(ctypes.Structure):
                 ("alg_bytes_per_step", ctypes.c_double)]
 
 
+class VxhTilingInfo(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int), ("kx", ctypes.c_int), ("ky", ctypes.c_int), ("kz", ctypes.c_int),
+                ("max_own", ctypes.c_int), ("max_local", ctypes.c_int), ("max_bonds", ctypes.c_int),
+                ("total_bonds", ctypes.c_int)]
+
+
 class VxhError(RuntimeError):
     def __init__(self, status, message):
         RuntimeError.__init__(self, "libvxhip status %d: %s" % (status, message))
@@ -92,6 +98,8 @@ def load_library():
     P, I, D, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_longlong
     lib.vxh_inspect_vxa_buffer.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, ctypes.POINTER(VxhModelInfo),
                                            ctypes.c_char_p, ctypes.c_size_t]
+    lib.vxh_plan_tiles_buffer.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, I, ctypes.POINTER(VxhTilingInfo),
+                                          ctypes.POINTER(I), I, ctypes.c_char_p, ctypes.c_size_t]
     lib.vxh_create.argtypes = [ctypes.POINTER(P), I, I]
     lib.vxh_destroy.argtypes = [P]
     lib.vxh_destroy.restype = None
@@ -132,6 +140,23 @@ def inspect_vxa(text_or_path, variant=VOXCAD):
     if rc != 0:
         raise VxhError(rc, "%s (%s)" % (lib.vxh_strerror(rc).decode(), err.value.decode()))
     return info
+
+
+def plan_tiles(text_or_path, k_request, variant=VOXCAD):
+    """Host-only: how the engine would cut the robot into tiles; returns (VxhTilingInfo, owner tile of every voxel)."""
+    lib = load_library()
+    if os.path.exists(text_or_path):
+        with open(text_or_path, "rb") as handle:
+            raw = handle.read()
+    else:
+        raw = text_or_path.encode("latin-1") if isinstance(text_or_path, str) else text_or_path
+    nvox = inspect_vxa(raw, variant).nvox
+    info, err = VxhTilingInfo(), ctypes.create_string_buffer(512)
+    owner = (ctypes.c_int * max(nvox, 1))()
+    rc = lib.vxh_plan_tiles_buffer(raw, len(raw), variant, k_request, ctypes.byref(info), owner, nvox, err, len(err))
+    if rc != 0:
+        raise VxhError(rc, "%s (%s)" % (lib.vxh_strerror(rc).decode(), err.value.decode()))
+    return info, np.array(owner[:nvox], dtype=np.int64)
 
 
 class Engine(object):

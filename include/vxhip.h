@@ -46,7 +46,8 @@ enum vxh_variant { VXH_VOXCAD = 0, VXH_VOXCAD_LAND_WATER = 1 };
 /* per-robot outcome; the reference has no such codes: a diverged or empty robot makes its process spin
  * forever and evosoro times it out (evaluation.py:107-119). */
 enum vxh_robot_status { VXH_ROBOT_PENDING = 0, VXH_ROBOT_FINISHED = 1, VXH_ROBOT_DIVERGED = 2, VXH_ROBOT_EMPTY = 3,
-                        VXH_ROBOT_COL_OVERFLOW = 4 };
+                        VXH_ROBOT_COL_OVERFLOW = 4,
+                        VXH_ROBOT_SYNC_TIMEOUT = 5 /* device side only: vxh_run / vxh_step fail with VXH_ERR_HIP instead */ };
 
 typedef struct vxh_result {
     int status;            /* vxh_robot_status */
@@ -98,6 +99,19 @@ typedef struct vxh_model_info {
 } vxh_model_info;
 int  vxh_inspect_vxa_buffer(const char* xml, size_t len, int variant, vxh_model_info* out, char* errbuf, size_t errcap);
 
+/* Host-only view of how the engine would cut a robot into tiles for its multi-workgroup kernel (evosoro_amd/csrc/kernels_tiled.hpp;
+ * the loop being tiled: CVX_Sim::Integrate, VX/VX_Sim.cpp:1763-1933): the grid, the largest tile, and the owner tile of every voxel
+ * (tile_of_out, `capacity` entries, may be NULL).  k_request tiles or somewhat fewer. */
+typedef struct vxh_tiling_info {
+    int k, kx, ky, kz;       /* tiles = kx * ky * kz boxes */
+    int max_own;             /* most voxels owned by a tile */
+    int max_local;           /* ... owned + mirrored (halo) */
+    int max_bonds;           /* most bonds evaluated by a tile (bonds crossing a tile boundary count on both sides) */
+    int total_bonds;         /* sum over tiles */
+} vxh_tiling_info;
+int  vxh_plan_tiles_buffer(const char* xml, size_t len, int variant, int k_request, vxh_tiling_info* out, int* tile_of_out, int capacity,
+                           char* errbuf, size_t errcap);
+
 int  vxh_create(vxh_engine** out, int variant, int device_id);
 void vxh_destroy(vxh_engine* e);
 
@@ -120,6 +134,15 @@ int  vxh_fitness_file_name(const vxh_engine* e, int robot, char* buf, size_t cap
 /* per voxel 14 doubles: pos3, quat(w,x,y,z), scale, vel3, angvel3; capacity in voxels */
 int  vxh_get_state(const vxh_engine* e, int robot, double* out14n, int capacity);
 int  vxh_get_counters(const vxh_engine* e, vxh_counters* out);
+/* Options (all have working defaults):
+ *   "tiled"             0 = never, 1 (default) = robots of more than 1024 voxels and populations smaller than 3/4 of the CUs are
+ *                       stepped by the multi-workgroup kernel, 2 = every robot it supports; "tiles_per_robot" > 0 requests a tile count.
+ *                       Both belong to the uploaded batch: set them before the first vxh_run / vxh_step (VXH_ERR_STATE afterwards,
+ *                       until vxh_reset).  The tiles of a robot wait for each other on the device: the engine must own its GPU
+ *                       (with another process on the same GPU set "tiled" to 0).
+ *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 256)
+ *   "fused"             0 = robots the tiled kernel does not take go through the streaming kernels (cross-checks)
+ *   "graph_steps"       streaming kernels: step rounds per captured hipGraph (0 = plain launches) */
 int  vxh_set_option(vxh_engine* e, const char* key, double value);
 
 const char* vxh_strerror(int status);

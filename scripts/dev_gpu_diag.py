@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer diagnostics for the GPU box (not collected by pytest, not part of the product): per-step error of the HIP
 engine against the CPU oracle on the golden robots, timings of synthetic batches, per-phase cycle shares (library
-built by `make -C evosoro_amd/csrc prof`), whole-generation wall clock.  Lives under tests/ because it uses oracle/."""
+built by `make -C evosoro_amd/csrc prof`), whole-generation wall clock.  Uses oracle/ as the checker, like the tests do."""
 import os
 import sys
 import time
@@ -325,3 +325,44 @@ if __name__ == "__main__" and "crosscheck" in sys.argv[1:]:
     diff = np.array([np.abs(a[:, :3] - b[:, :3]).max() / 0.01 for a, b in zip(states[1], states[0])])
     print("fused vs streaming after 400 steps, position difference in voxels: median %.2e, 90%% %.2e, 99%% %.2e, max %.2e" % (
         np.median(diff), np.percentile(diff, 90), np.percentile(diff, 99), diff.max()))
+
+
+if __name__ == "__main__" and "tilecfgs" in sys.argv[1:]:
+    # the multi-workgroup kernel against the round-1 paths on the populations that cannot fill the chip one robot per CU
+    for opts in ({"tiled": 0}, {"tiled": 1}):
+        timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.01, Env(), opts, full=True)                     # configs[4]
+        timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), opts)                                  # configs[1]
+        timing_cfg(engine.VOXCAD, 64, (10, 10, 10), 0.03, Env(), opts)                               # configs[2] at 8 GPUs: 64 per GPU
+        timing_cfg(engine.VOXCAD, 16, (10, 10, 10), 0.03, Env(), opts)
+    for k in (27, 64, 125, 216):
+        timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.01, Env(), {"tiled": 2, "tiles_per_robot": k}, full=True)
+    for k in (1, 2, 4, 8):
+        timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), {"tiled": 2, "tiles_per_robot": k})
+
+
+if __name__ == "__main__" and "tilephases" in sys.argv[1:]:
+    # per-phase cycle shares of the tiled kernel (library built by `make -C evosoro_amd/csrc prof`)
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    engine._lib = None
+    print("20^3, 125 tiles", flush=True)
+    timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.01, Env(), {"tiled": 2, "tiles_per_robot": 125}, full=True, phases=True)
+    print("64 x 6^3, 4 tiles each", flush=True)
+    timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), {"tiled": 2, "tiles_per_robot": 4}, phases=True)
+    print("64 x 6^3, 1 tile each", flush=True)
+    timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), {"tiled": 2, "tiles_per_robot": 1}, phases=True)
+
+
+if __name__ == "__main__" and "tilelong" in sys.argv[1:]:
+    if "prof" in sys.argv[1:]:
+        engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+        engine._lib = None
+    timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.08, Env(), {"tiled": 2, "tiles_per_robot": 125}, full=True, phases="prof" in sys.argv[1:])
+    timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.08, Env(), {"tiled": 2, "tiles_per_robot": 64}, full=True, phases="prof" in sys.argv[1:])
+
+
+if __name__ == "__main__" and "tilefence" in sys.argv[1:]:
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    engine._lib = None
+    for dbg in (0, 4):
+        print("dbg", dbg, flush=True)
+        timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.08, Env(), {"tiled": 2, "tiles_per_robot": 125, "dbg": dbg}, full=True)

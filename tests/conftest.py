@@ -23,3 +23,24 @@ def manifest():
     import json
     with open(os.path.join(GOLDEN, "manifest.json")) as handle:
         return json.load(handle)
+
+
+# Every GPU test runs once per kernel path: "auto" (the engine's own choice: small test batches go to the multi-workgroup
+# kernel with one bond per lane), "resident" (tiled = 0: one workgroup per robot / streaming kernels, the round-1 paths) and
+# "tiles3" (every robot cut into about three tiles whatever its size).  A test that sets the options itself overrides this.
+KERNEL_PATHS = {"auto": "", "resident": "tiled=0", "tiles3": "tiled=2,tiles_per_robot=3"}
+
+
+def pytest_generate_tests(metafunc):
+    if "kernel_path" in metafunc.fixturenames:
+        on_gpu = metafunc.definition.get_closest_marker("gpu") is not None
+        metafunc.parametrize("kernel_path", sorted(KERNEL_PATHS) if on_gpu else ["auto"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def kernel_path(request, monkeypatch):
+    if KERNEL_PATHS[request.param]:
+        monkeypatch.setenv("VXH_ENGINE_OPTIONS", KERNEL_PATHS[request.param])
+    else:
+        monkeypatch.delenv("VXH_ENGINE_OPTIONS", raising=False)
+    yield request.param

@@ -139,6 +139,7 @@ def test_streaming_path_matches_fused_path(eng_mod, golden_dir):
     states = {}
     for fused in (1, 0):
         with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 0)
             eng.set_option("fused", fused)
             for n in names:
                 eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))

@@ -1,0 +1,82 @@
+"""GPU tests (-m gpu) of the multi-workgroup kernel (evosoro_amd/csrc/kernels_tiled.hpp): a robot's trajectory must not
+depend on whether, or into how many tiles, it was cut -- the tiled kernel evaluates every bond and voxel with the resident
+kernel's arithmetic and sums in its order -- and must match the CPU oracle like every other path.  (The parity tests of
+tests/test_gpu_parity.py also run on this kernel: see `kernel_path` in conftest.py.)"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LAND = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "stiff5", "grow5", "devo4"]
+
+
+def _states(eng_mod, paths, options, checkpoints, variant=0):
+    out = []
+    with eng_mod.Engine(variant, 0) as eng:
+        for key, val in options.items():
+            eng.set_option(key, val)
+        for p in paths:
+            eng.add_vxa_file(p)
+        done = 0
+        for upto in checkpoints:
+            eng.step(upto - done)
+            done = upto
+            out.append([eng.state(i) for i in range(len(paths))])
+    return out
+
+
+def test_tiling_does_not_change_the_trajectory(golden_dir):
+    from evosoro_amd import engine as eng_mod
+    paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in LAND]
+    checkpoints = (1, 7, 300, 900)            # 900 steps: past InitCmTime for most robots, launches of 256 steps chained
+    ref = _states(eng_mod, paths, {"tiled": 0}, checkpoints)
+    bitwise = {}
+    for k in (1, 2, 5):
+        got = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": k}, checkpoints)
+        for c in range(len(checkpoints)):
+            for i, name in enumerate(LAND):
+                err = np.abs(got[c][i][:, :8] - ref[c][i][:, :8]).max()
+                assert err < 1e-12, (k, checkpoints[c], name, err)
+                assert np.abs(got[c][i][:, 8:] - ref[c][i][:, 8:]).max() < 1e-9, (k, checkpoints[c], name)
+        bitwise[k] = all(np.array_equal(got[-1][i], ref[-1][i]) for i in range(len(LAND)))
+    print("tiled == resident bit for bit after 900 steps, by tile count:", bitwise)
+    # different tile counts among themselves: the same bits (same code, same order, only the partition differs)
+    a = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": 2}, (900,))
+    b = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": 6}, (900,))
+    for i, name in enumerate(LAND):
+        assert np.array_equal(a[0][i], b[0][i]), name
+
+
+def test_tiled_whole_runs_match_the_reference_xml(golden_dir):
+    from evosoro_amd import engine as eng_mod
+    from oracle import vxoracle as vo
+    names = ["probe6", "rand6_col", "soft5_init0"]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 2)
+        eng.set_option("tiles_per_robot", 4)
+        for n in names:
+            eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))
+        eng.run()
+        for i, n in enumerate(names):
+            trace = vo.read_trace(os.path.join(golden_dir, "expected", n + ".final.bin"))
+            want = vo.read_result_xml(os.path.join(golden_dir, "expected", n + ".xml"))
+            res = eng.result(i)
+            lat = vo.parse_vxa(os.path.join(golden_dir, "vxa", n + ".vxa"))["lattice_dim"]
+            assert res.status == eng_mod.ROBOT_FINISHED and res.steps == trace["total_steps"], n
+            assert np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / lat < 1e-9, n
+            assert np.abs(np.array(res.ini_cm) - trace["ini_cm"]).max() / lat < 1e-9, n
+            assert abs(res.norm_final_dist - want["NormFinalDist"]) <= 1e-5 * abs(want["NormFinalDist"]) + 2e-9, n
+
+
+def test_stepping_in_pieces_equals_one_run(golden_dir):
+    """launch boundaries (history, mode bits, pending MaxVoxVel, exchange buffers) must be invisible: 1 + 2 + 253 + 300 steps
+    in separate calls = 556 steps in one"""
+    from evosoro_amd import engine as eng_mod
+    paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in ("rand6_col", "probe6")]
+    opts = {"tiled": 2, "tiles_per_robot": 3, "steps_per_launch": 64}
+    pieces = _states(eng_mod, paths, opts, (1, 3, 256, 556))[-1]
+    whole = _states(eng_mod, paths, opts, (556,))[-1]
+    for a, b in zip(pieces, whole):
+        assert np.array_equal(a, b)
