@@ -222,12 +222,16 @@ void Engine::clear()
     if (dev_->B.prof) {
         unsigned long long h[16 * 8 + 256 * 8];
         HIP_OK(hipMemcpy(h, dev_->B.prof, sizeof(h), hipMemcpyDeviceToHost));
-        if (std::getenv("VXH_PROF_TILES"))      // wave 0 of each of the first tiles: cycles per phase
+        if (std::getenv("VXH_PROF_TILES")) {    // the first tiles at one step of the last launch: real-time counter (10 ns ticks) at the step's boundaries
+            unsigned long long t0 = ~0ull;
+            for (int t = 0; t < std::min(256, dev_->B.n_tiles); ++t) if (h[128 + t * 8]) t0 = std::min(t0, h[128 + t * 8]);
+            fprintf(stderr, "tile: top  halo-done  bond-done  voxel-done  C-passed | svc: barrier-resolved control-done | mv-published   (us after the first tile's top)\n");
             for (int t = 0; t < std::min(256, dev_->B.n_tiles); ++t) {
                 fprintf(stderr, "tile %3d:", t);
-                for (int k = 0; k < 8; ++k) fprintf(stderr, " %9llu", h[128 + t * 8 + k]);
+                for (int k : {0, 1, 2, 3, 4, 5, 6, 7}) fprintf(stderr, " %7.2f", 0.01 * (double)(long long)(h[128 + t * 8 + k] - t0));
                 fprintf(stderr, "\n");
             }
+        }
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
         static const char* tnames[8] = {"halo-wait", "bond", "svc:poll", "barB", "latch/rebuild", "voxel", "barC+mv", "svc:reduce+horizon"};
         const bool tiled = !dev_->tile_launches.empty();

@@ -634,13 +634,15 @@ __device__ __forceinline__ StepCtl step_control_begin(const DRobot& R, DRobotSta
     rs.active = 1;
     return c;
 }
-__device__ __forceinline__ void step_control_horizon(const DRobot& R, DRobotState& rs, StepCtl& c)
+// (dt_prev: the step length of the step before the one being decided -- rs.dt_prev, unless the caller has already let
+// step_control_begin of the NEXT step overwrite it)
+__device__ __forceinline__ void step_control_horizon(const DRobot& R, DRobotState& rs, StepCtl& c, double dt_prev)
 {
     if (c.go && (R.flags & RF_SELF_COL)) {                                       // UpdateCollisions :1729-1755
         // (lean sqrt / divide: bit-identical for the finite non-negative operands here, a third of the instructions -- this runs
         // on one thread while its workgroup waits)
         const double mv = vsqrt_nn(__longlong_as_double((long long)rs.maxvel2_bits));
-        rs.max_disp += fabs(vdiv(mv * rs.dt_prev, R.lat));
+        rs.max_disp += fabs(vdiv(mv * dt_prev, R.lat));
         rs.maxvel2_bits = 0ull;
         if (!(R.flags & RF_HORIZON_COL) || rs.max_disp > (R.col_horizon - 1.0) / 2) { c.rebuild = 1; rs.max_disp = 0.0; rs.rebuilds += 1; rs.col_tiled = 0; }
     }
@@ -649,7 +651,7 @@ __device__ __forceinline__ void step_control_horizon(const DRobot& R, DRobotStat
 __device__ __forceinline__ StepCtl step_control(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step)
 {
     StepCtl c = step_control_begin(R, rs, step_cap, begin_new_step);
-    step_control_horizon(R, rs, c);
+    step_control_horizon(R, rs, c, rs.dt_prev);
     return c;
 }
 

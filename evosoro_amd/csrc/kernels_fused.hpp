@@ -414,12 +414,13 @@ __device__ __forceinline__ void fused_control_begin(const DRobot& R, DRobotState
     K.act_sin = K.act_cos = 0;
     if (c.go) actuation_sincos(R, rs.cur_time, K.act_sin, K.act_cos);
 }
-__device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K)
+__device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K, double dt_prev)
 {
     StepCtl c; c.go = K.go; c.latch = c.eol = c.rebuild = 0;
-    step_control_horizon(R, rs, c);
+    step_control_horizon(R, rs, c, dt_prev);
     K.rebuild = c.rebuild;
 }
+__device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K) { fused_control_horizon(R, rs, K, rs.dt_prev); }
 
 template <int BLOCK, int NACC, bool MESH, bool TABG>
 __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const DRobot* __restrict__ robots,

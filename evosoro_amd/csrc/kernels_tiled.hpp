@@ -322,10 +322,14 @@ __device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DR
 #define VXH_TT_DECL unsigned long long tt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tt_last = __builtin_readcyclecounter();
 #define VXH_TT_MARK(k) { const unsigned long long tt_now = __builtin_readcyclecounter(); tt_acc[k] += tt_now - tt_last; tt_last = tt_now; }
 #define VXH_TT_FLUSH if (B.prof && (threadIdx.x & 63) == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&B.prof[(threadIdx.x >> 6) * 8 + k], tt_acc[k]); }
+// ... and, at step VXH_TS_STEP of a launch, the real-time counter (100 MHz, common to all CUs) at the boundaries of the step, per tile
+#define VXH_TS_STEP 100
+#define VXH_TS(k, who) if (B.prof && it == VXH_TS_STEP && (who) && ti < 256) B.prof[128 + ti * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define VXH_TT_DECL
 #define VXH_TT_MARK(k)
 #define VXH_TT_FLUSH
+#define VXH_TS(k, who)
 #endif
 
 
@@ -335,12 +339,12 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
 {
     constexpr int BLOCK = VXH_TILE_BLOCK, NT = VXH_TILE_THREADS;   // worker threads (one per owned voxel), all threads
     extern __shared__ __align__(16) double lds[];
-    __shared__ DRobotState rs, rs_bak;
+    __shared__ DRobotState rs, rs_bak, rs_bak2;
     __shared__ FusedCtl s_ctl[2];
-    __shared__ double s_wmax[BLOCK / 64];
+    __shared__ unsigned long long s_mvbits;
     __shared__ double s_box[12 + 6 * (NT / 64)];
-    __shared__ int s_div, s_divprev, s_abort, s_xhn, s_pool;
-    static_assert(2 * sizeof(DRobotState) + 2 * sizeof(FusedCtl) + sizeof(double) * (BLOCK / 64) + sizeof(double) * (12 + 6 * (NT / 64)) + 5 * sizeof(int) + 32 <= VXH_TILE_STATIC_LDS, "static LDS bound");
+    __shared__ int s_div, s_divprev, s_abort, s_xhn, s_pool, s_done;
+    static_assert(3 * sizeof(DRobotState) + 2 * sizeof(FusedCtl) + sizeof(double) + sizeof(double) * (12 + 6 * (NT / 64)) + 6 * sizeof(int) + 32 <= VXH_TILE_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
     const bool svc = tid >= BLOCK;            // the service wavefront: per-robot barrier, control block
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     const size_t mvbuf = (size_t)VXH_TILE_MV_STRIDE * B.n_tiles;
 
     if (svc) __builtin_amdgcn_s_setprio(3);   // its few instructions sit on the critical path of the whole robot; it shares a SIMD with a worker
-    if (tid == 0) { rs = B.rstate[r]; s_div = 0; s_divprev = 0; s_abort = 0; s_pool = 0; s_xhn = B.rstate[r].col_tiled ? B.tile_xhn[ti] : 0; }
+    if (tid == 0) { rs = B.rstate[r]; s_div = 0; s_divprev = 0; s_abort = 0; s_pool = 0; s_done = 0; s_mvbits = 0; s_xhn = B.rstate[r].col_tiled ? B.tile_xhn[ti] : 0; }
     bool codes_live = B.rstate[r].col_tiled != 0;      // contact rows built by this kernel (else: every partner from memory until the next broad-phase)
     for (int e = tid; e < VXH_TILE_XH; e += NT) xh[e] = B.tile_xh[(size_t)ti * VXH_TILE_XH + e];
     const DBondClass* bct;
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     // the service wavefront's part of a step: wait until every tile of the robot has published its max |v|^2 for this step (= has
     // finished the previous one), reduce, note a divergence, else take the collision-horizon decision of the step
     constexpr int MVC = VXH_TILE_MAX_TILES / 64;
-    auto robot_barrier = [&](const unsigned long long* mvq, unsigned tag, unsigned long long (&mg)[2 * MVC], bool go, FusedCtl& K) {
+    auto robot_barrier = [&](const unsigned long long* mvq, unsigned tag, unsigned long long (&mg)[2 * MVC], bool go, FusedCtl& K, double dt_prev) {
         const int lane = tid - BLOCK;
         int spins = 0;
 #ifdef VXH_PHASE_TIMING
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             s_divprev = neg ? 1 : 0;
             if (!neg) {
                 rs.maxvel2_bits = (unsigned long long)__double_as_longlong(mvmax);
-                if (go) fused_control_horizon(R, rs, K);
+                if (go) fused_control_horizon(R, rs, K, dt_prev);
             }
         }
         return neg;
@@ -506,6 +510,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         FusedCtl& K = s_ctl[it & 1];
         FusedCtl& Knext = s_ctl[(it + 1) & 1];
         VXH_TT_MARK(6)
+        VXH_TS(0, tid == 0)
         const unsigned ringn = ring == 2 ? 0 : ring + 1, ringp = ring == 0 ? 2 : ring - 1;
         const unsigned long long* const xq = B.xch + (size_t)ring * xbuf;      // poses at the start of this step
         unsigned long long* const xqn = B.xch + (size_t)ringn * xbuf;          // ... of the next one
@@ -564,13 +569,14 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         if (tid == 0) s_div = 0;
         __syncthreads();
         VXH_TT_MARK(0)
+        VXH_TS(1, tid == 0)
         const bool damp_on = K.damp_on != 0;
 
         // ---- 2. workers: bond phase, every bond with an owned end, all axes in one round.  Service wavefront, on steps that do
         // not speculate: the per-robot barrier
         bool div = false;
         if (svc) {
-            if (!speculate) { robot_barrier(mvq, tag, mg, go, K); VXH_TT_MARK(2) }
+            if (!speculate) { robot_barrier(mvq, tag, mg, go, K, rs.dt_prev); VXH_TT_MARK(2) }
         } else if (go && !s_abort) {
             for (int b = tid; b < nb; b += BLOCK) {
                 const int e = bent[b];
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         if (div) s_div = 1;
         __syncthreads();                       // (B)
         VXH_TT_MARK(3)
+        VXH_TS(2, tid == 0)
         const PoseFromXch pose{xq, nx, B.xslot, tag, &s_abort};
         if (!speculate) {
             if (s_abort) break;
@@ -664,18 +671,46 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 for (int k = 0; k < 8; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_own, nx, p8[k], tagn);
             }
             if (svc && attempt == 0) {
-                bool neg = false;
-                if (speculate) { neg = robot_barrier(mvq, tag, mg, go, K); VXH_TT_MARK(2) }
-                // next step's control, off the critical path (not when the robot turns out to have stopped a step ago)
-                if (ctl_thread && !neg && !s_abort) { rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
-                VXH_TT_MARK(7)
+                if (speculate) {
+                    // the next step's control first (it shares no field with the horizon update but dt_prev, handed over by
+                    // value): it is done by the time the per-robot barrier resolves.  If the barrier then reports that the robot
+                    // stopped a step ago, the control block goes back two snapshots instead of one.
+                    const double dt_prev = rs.dt_prev;
+                    if (ctl_thread) { rs_bak2 = rs_bak; rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
+                    VXH_TT_MARK(7)
+                    const bool neg = robot_barrier(mvq, tag, mg, go, K, dt_prev);
+                    VXH_TT_MARK(2)
+                    VXH_TS(5, ctl_thread)
+                    if (ctl_thread) {
+                        if (neg) rs_bak = rs_bak2;
+                        else {   // the snapshot of this step carries the horizon update as well
+                            rs_bak.maxvel2_bits = rs.maxvel2_bits; rs_bak.max_disp = rs.max_disp; rs_bak.rebuilds = rs.rebuilds;
+                            rs_bak.col_tiled = rs.col_tiled; rs_bak.rebuild_now = rs.rebuild_now;
+                        }
+                    }
+                } else {
+                    // next step's control, off the critical path
+                    if (ctl_thread && !s_abort) { rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
+                    VXH_TT_MARK(7)
+                }
+                VXH_TS(6, ctl_thread)
             }
             if (!svc) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { const double o2 = __shfl_xor(vel2, off); vel2 = o2 > vel2 ? o2 : vel2; }
-                if ((tid & 63) == 0) s_wmax[tid >> 6] = vel2;
+                // the tile's max |v|^2 goes out with the last worker wave to finish, not behind the workgroup barrier
+                vel2 = wave_max_nonneg(vel2);
+                if ((tid & 63) == 0) {
+                    atomicMax(&s_mvbits, (unsigned long long)__double_as_longlong(vel2));
+                    if (atomicAdd(&s_done, 1) == BLOCK / 64 - 1) {
+                        double mv = (R.flags & RF_SELF_COL) ? __longlong_as_double((long long)s_mvbits) : 0.0;   // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
+                        if (diverged_here) mv = -1.0;
+                        s_mvbits = 0; s_done = 0;
+                        st_gran2(B.tile_mv + (size_t)ringn * mvbuf + (size_t)ti * VXH_TILE_MV_STRIDE, 1, mv, tagn);
+                        VXH_TS(7, true)
+                    }
+                }
             }
             VXH_TT_MARK(5)
+            VXH_TS(3, tid == 0)
             __syncthreads();                   // (C) the voxel phase is complete and, on a speculating step, the per-robot barrier resolved
             if (s_abort || s_divprev) { stop = true; break; }
             if (speculate && attempt == 0 && K.rebuild) {
@@ -692,21 +727,12 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         }
         if (stop) break;
         // ---- 4. commit
+        VXH_TS(4, tid == 0)
         lm_bak = lm; am_bak = am;
         lm = lm_new; am = am_new;
         if (valid) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) ps[k * np + tid] = p8[k];
-        }
-        if (tid == 0) {
-            double mv = 0.0;
-            if (R.flags & RF_SELF_COL) {       // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
-#pragma unroll
-                for (int w = 0; w < BLOCK / 64; ++w) mv = s_wmax[w] > mv ? s_wmax[w] : mv;
-            }
-            if (diverged_here) mv = -1.0;
-            st_gran2(B.tile_mv + (size_t)ringn * mvbuf + (size_t)ti * VXH_TILE_MV_STRIDE, 1, mv, tile_tag(gen, ep, it + 2));
-            if (B.dbg & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         }
         ring = ringn;
         (void)ringp;
