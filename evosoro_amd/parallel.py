@@ -8,6 +8,7 @@ on its own GPU with no data-path communication, and ONE collective returns the f
 (<= 256 B per robot) to every rank.
 """
 import os
+import sys
 
 import numpy as np
 
@@ -53,18 +54,38 @@ def shard_round_robin(count, world_size):
     return [list(range(r, count, world_size)) for r in range(world_size)]
 
 
+def _dist():
+    """torch.distributed if importable and initialised with more than one rank, else None (single GPU: no torch needed)"""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return None
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+def rank_and_world():
+    dist = _dist()
+    return (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+
+
+def barrier():
+    dist = _dist()
+    if dist:
+        dist.barrier()
+
+
 def gather_records(local_records, local_indices, total, device=None):
     """All ranks receive the full [total, RECORD_LEN] table.  Single all_gather of a padded per-rank block.
 
     Without an initialised process group (single GPU) this is a plain scatter into the table.
     """
-    import torch
-    import torch.distributed as dist
     table = np.zeros((total, RECORD_LEN), dtype=np.float64)
     local_records = np.asarray(local_records, dtype=np.float64).reshape(-1, RECORD_LEN)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    dist = _dist()
+    if dist is None:
         table[list(local_indices)] = local_records
         return table
+    import torch
     world = dist.get_world_size()
     per_rank = (total + world - 1) // world + 1          # LPT shards may be uneven: allow slack, verified below
     counts = torch.zeros(world, dtype=torch.int64, device=device)
@@ -108,25 +129,30 @@ def run_shard(engine_module, paths, variant, device_index, options=None, write_x
     return records, counters
 
 
-def run_population(engine_module, paths, variant=0, costs=None, options=None, write_xml=True):
+def run_population(engine_module, paths, variant=0, costs=None, options=None, write_xml=True, device=None):
     """Evaluate every .vxa of a generation; with an initialised process group the files are sharded over ranks.
 
-    Returns the full record table (identical on every rank).
+    Returns the full record table (identical on every rank).  `device`: HIP device index of this process; by default the
+    launcher's LOCAL_RANK in a multi-GPU job, else torch's current device when torch is loaded and CUDA-initialised, else 0
+    (the single-GPU path needs no torch at all).
     """
-    import torch
-    import torch.distributed as dist
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if distributed:
+    dist = _dist()
+    if dist:
         world, rank = dist.get_world_size(), dist.get_rank()
         shards = shard_by_cost(costs, world) if costs is not None else shard_round_robin(len(paths), world)
         mine = shards[rank]
     else:
         mine = list(range(len(paths)))
-    device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    if distributed and device_index == 0 and torch.cuda.is_available() and torch.cuda.device_count() > 1:
-        # one process per GPU: a launcher (torch.distributed.run) exports LOCAL_RANK; honour it when the caller did not
-        # call torch.cuda.set_device itself, instead of piling every rank onto device 0
-        device_index = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
-    records, _ = run_shard(engine_module, [paths[i] for i in mine], variant, device_index, options, write_xml)
-    device = torch.device("cuda", device_index) if (distributed and dist.get_backend() == "nccl") else None
-    return gather_records(records, mine, len(paths), device)
+    torch = sys.modules.get("torch")
+    cuda_ready = torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized()
+    if device is None:
+        if dist and "LOCAL_RANK" in os.environ and not (cuda_ready and torch.cuda.current_device() != 0):
+            # one process per GPU: a launcher (torch.distributed.run) exports LOCAL_RANK; honour it unless the caller has
+            # selected a device itself, instead of piling every rank onto device 0
+            n_dev = torch.cuda.device_count() if (torch is not None and torch.cuda.is_available()) else 0
+            device = int(os.environ["LOCAL_RANK"]) % n_dev if n_dev > 0 else 0
+        else:
+            device = torch.cuda.current_device() if cuda_ready else 0
+    records, _ = run_shard(engine_module, [paths[i] for i in mine], variant, device, options, write_xml)
+    gather_device = torch.device("cuda", device) if (dist and dist.get_backend() == "nccl") else None
+    return gather_records(records, mine, len(paths), gather_device)

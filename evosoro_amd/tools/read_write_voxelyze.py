@@ -162,11 +162,13 @@ def _vxc_header_lines(env, size_xyz):
     return text + "".join(_IND + line + "\n" for line in tail)
 
 
-def write_voxelyze_file(sim, env, individual, run_directory, run_name):
+def write_voxelyze_file(sim, env, individual, run_directory, run_name, write=True):
     """Serialise one individual to `<run_directory>/voxelyzeFiles/<run_name>--id_%05i.vxa`.
 
     Returns the md5 hex digest of the concatenated per-voxel output strings, which evaluate_all uses as
-    its evaluation-cache key (reference :362,390,404-407).
+    its evaluation-cache key (reference :362,390,404-407).  `write=False` (ranks other than 0 of a multi-GPU
+    job, which share the run directory) does everything but touch the file: the environment attributes driven by
+    the genotype are set and the global `random` stream advances exactly as on the writing rank.
     """
     mapping = individual.genotype.to_phenotype_mapping
     size = individual.genotype.orig_size_xyz
@@ -237,6 +239,7 @@ def write_voxelyze_file(sim, env, individual, run_directory, run_name):
     out.append("</Structure>\n" + _IND + "</VXC>\n" + _IND + "</VXA>")
 
     path = run_directory + "/voxelyzeFiles/" + run_name + "--id_%05i.vxa" % individual.id
-    with open(path, "w") as handle:
-        handle.write("".join(out))
+    if write:
+        with open(path, "w") as handle:
+            handle.write("".join(out))
     return hashlib.md5("".join(md5_text).encode()).hexdigest()

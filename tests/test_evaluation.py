@@ -1,6 +1,9 @@
 """evaluate_all: the bookkeeping contract of evosoro/tools/evaluation.py, exercised on CPU with the oracle-backed
 stub engine (tests/stub_engine.py); fitness values must equal the reference's golden result XMLs."""
+import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 
@@ -67,3 +70,31 @@ def test_evaluate_all_contract(tmp_path, golden_dir):
                  save_lineages=True)
     assert b.fitness == want and pop2.total_evaluations == 0  # served from the md5 cache, nothing simulated
     assert any("Launched 0 voxelyze calls" in l for l in log.lines)
+
+
+def test_evaluate_all_on_two_ranks(tmp_path):
+    """a 2-rank job (gloo) on one shared run directory: both ranks must end both generations with the same fitness values,
+    caches and counters, nobody may report a robot as unfinished, and the files are rank 0's business alone"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = str(tmp_path / "run")
+    for d in ("voxelyzeFiles", "fitnessFiles", "tempFiles", "bestSoFar/fitOnly", "ancestors", "Gen_0000", "Gen_0001"):
+        os.makedirs(os.path.join(run, d))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=repo)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(repo, "tests", "dist_worker_eval.py"), run]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert proc.returncode == 0, proc.stdout.decode()[-3000:]
+    r0, r1 = (json.load(open(os.path.join(run, "rank%d.json" % k))) for k in (0, 1))
+    assert r0 == r1                                           # identical populations, caches, counters on both ranks
+    assert r0["warnings"] == []                               # nobody took a robot another rank simulated for unfinished
+    fit = r0["fitness"]
+    assert all(f > -10e6 for f in fit[:5]) and fit[5] == -10e6                       # five evaluated, the invalid one at its worst value
+    assert fit[6] == fit[0] and r0["md5"][6] == r0["md5"][0]                          # generation 2: clone served from the md5 cache
+    assert r0["total"] == 6 and r0["ids"] == [0, 1, 2, 3, 4, 11] and len(r0["cache"]) == 6
+    assert all(float("%.6g" % f) == f for f in fit[:5])                               # six significant digits, as the XML would carry
+    # housekeeping done once: generation 0 moved to Gen_0000 (save_vxa_every = 1), generation 1 removed, no result files left
+    assert sorted(f.split("--id_")[1] for f in os.listdir(os.path.join(run, "Gen_0000"))) == ["%05d.vxa" % i for i in range(5)]
+    # (the clone of generation 2 and the invalid robot of generation 1 were never simulated: their files stay, as in the reference)
+    assert sorted(os.listdir(os.path.join(run, "voxelyzeFiles"))) == ["D--id_00005.vxa", "D--id_00010.vxa"]
+    assert os.listdir(os.path.join(run, "fitnessFiles")) == []
+    assert len(os.listdir(os.path.join(run, "bestSoFar/fitOnly"))) >= 1

@@ -676,3 +676,68 @@ def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
                 err = _pos_err(eng.state(i), o.state(), models[i]["lattice_dim"])
                 assert err <= tol, (i, upto, err, tol, paths[i])
     assert sum(1 for sp in spreads if sp < 1e-10) >= 0.75 * count
+
+
+def test_evaluate_all_with_the_real_engine(eng_mod, golden_dir, manifest, tmp_path):
+    """BASELINE configs[0] end to end through the recommended route: evaluate_all -> run_population ->
+    libvxhip, NOT the stub engine of the CPU suite.  The basic.py-style 6x6x6 locomotor (0.5 s) and a second generation with
+    another golden robot; objective values must equal what the reference's read_voxlyze_results parsed out of the reference
+    binary's result XML (tests/golden/manifest.json), six digits; md5 keys, cache and file housekeeping as evaluation.py:18-219."""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env, ObjectiveDict
+    from evosoro_amd.tools.evaluation import evaluate_all
+
+    class Log(object):
+        lines = []
+
+        def message(self, text):
+            self.lines.append(str(text))
+
+    class Pop(list):
+        pass
+
+    def make_pop(inds, gen):
+        pop = Pop(inds)
+        pop.objective_dict = ObjectiveDict()
+        pop.objective_dict.add_objective(name="fitness", maximize=True, tag="<NormFinalDist>")
+        pop.objective_dict.add_objective(name="age", maximize=False, tag=None)
+        pop.objective_dict.add_objective(name="y", maximize=True, tag="<finalDistY>")
+        pop.objective_dict.add_objective(name="touch", maximize=True, tag="<NumTouchingFloor>")
+        pop.gen, pop.pop_size, pop.total_evaluations, pop.best_fit_so_far = gen, len(inds), 0, -1e9
+        pop.already_evaluated, pop.all_evaluated_individuals_ids = {}, []
+        for ind in pop:
+            ind.fitness, ind.age, ind.y, ind.touch = -10e6, 0, -10e6, -10e6
+        return pop
+
+    run = str(tmp_path / "run")
+    for d in ("voxelyzeFiles", "fitnessFiles", "tempFiles", "bestSoFar/fitOnly", "ancestors", "Gen_0000", "Gen_0001"):
+        os.makedirs(os.path.join(run, d))
+    env, log = Env(), Log()
+    probe = workloads.make_individual(0, workloads.probe_material())
+    clone = workloads.make_individual(7, workloads.probe_material())
+    pop = make_pop([probe, clone], 0)
+    # the clone differs in id only: with zero actuation variance the reference evaluates both (the cache is filled after the
+    # generation) and both get the same value
+    evaluate_all(Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1), env, pop, log, save_vxa_every=1,
+                 run_directory=run, run_name="E")
+    want = manifest["probe6"]
+    assert probe.md5 == clone.md5 == want["md5"]
+    for ind in (probe, clone):
+        assert (ind.fitness, ind.y, ind.touch) == (want["read_results"]["0"], want["read_results"]["2"], want["read_results"]["3"])
+    assert pop.total_evaluations == 2 and pop.all_evaluated_individuals_ids == [0, 7] and pop.best_fit_so_far == probe.fitness
+    assert os.listdir(os.path.join(run, "fitnessFiles")) == [] and os.listdir(os.path.join(run, "voxelyzeFiles")) == []
+    assert len(os.listdir(os.path.join(run, "Gen_0000"))) == 2 and len(os.listdir(os.path.join(run, "bestSoFar/fitOnly"))) == 1
+
+    other = workloads.random_robot(2, (6, 6, 6), 7)           # = golden case rand6_col
+    again = workloads.make_individual(9, workloads.probe_material())
+    pop2 = make_pop([other, again], 1)
+    pop2.already_evaluated, pop2.best_fit_so_far = pop.already_evaluated, pop.best_fit_so_far
+    evaluate_all(Sim(dt_frac=0.9, simulation_time=0.25, fitness_eval_init_time=0.1), env, pop2, log, save_vxa_every=0,
+                 run_directory=run, run_name="E", save_lineages=True)
+    want2 = manifest["rand6_col"]
+    assert other.md5 == want2["md5"]
+    assert (other.fitness, other.y, other.touch) == (want2["read_results"]["0"], want2["read_results"]["2"], want2["read_results"]["3"])
+    assert again.fitness == probe.fitness and pop2.total_evaluations == 1     # served from the md5 cache
+    assert pop2.best_fit_so_far == other.fitness and len(os.listdir(os.path.join(run, "bestSoFar/fitOnly"))) == 2
+    assert os.listdir(os.path.join(run, "ancestors")) == ["E--id_00002.vxa"]
+    assert not any("WARNING" in l for l in log.lines)
