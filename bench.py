@@ -4,17 +4,28 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload = BASELINE.json configs[2], "population 512 of 10x10x10 robots": it fits one MI355X, so a single GPU
-steps the whole population of 512; with N GPUs every rank steps its own 512 robots (weak scaling, seeds
-offset by rank, no data-path collective).  A "step" is one Voxelyze TimeStep of every robot of the batch.
-Robots: material per voxel uniform on {0..4} with P(empty)=0.3, largest connected component, evosoro's default
-materials/environment, self-collision ON, DtFrac 0.9.  After the timed region the
-fitness records of all ranks are gathered with one RCCL all_gather (the path's only collective).
+Workload of the headline `value` = BASELINE.json configs[2], "population 512 of 10x10x10 robots": it fits one MI355X, so
+a single GPU steps the whole population of 512; with N GPUs every rank steps its own 512 robots (WEAK scaling, seeds
+offset by rank, no data-path collective).  A "step" is one Voxelyze TimeStep of every robot of the batch.  Robots:
+material per voxel uniform on {0..4} with P(empty)=0.3, largest connected component, evosoro's default
+materials/environment, self-collision ON, DtFrac 0.9.  Before anything is timed every robot is
+advanced past InitCmTime (untimed), so that whatever window --steps selects, it samples the steady-state instruction mix:
+actuation on, bonds in both the small- and the large-angle branch (`config.large_angle_bonds` = their share at the end
+of the timed window).  After the timed region the fitness records of all ranks are gathered with one RCCL all_gather
+(the path's only collective).
 
-The printed JSON line carries `roofline` (HBM: algorithmic bytes (224*Nvox + 144*Nbond) per voxel-step of
-SURVEY.md 8(d) over the HIP-event time of the dominant kernel) and `cpu_baseline` (the reference C++
-voxelyze, oracle/_ref/voxelyze_ref built from the reference sources, timed on this box's host cores on a
-bounded sample of the same robots; rank 0, N=1 only).
+With N > 1 the same line carries `strong`: BASELINE configs[2] as stated -- ONE population of 512, partitioned over the
+N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak run.
+
+The JSON line also carries
+  roofline      HBM: algorithmic bytes (224*Nvox + 144*Nbond per voxel-step) of the dominant kernel over its
+                HIP-event time, in GB/s against the 8 TB/s peak; `traffic` = what the PMC counters saw for the same kernel on
+                this workload (newest profiles/r*_hbm_traffic.json), also in GB/s -- rates, comparable whatever the launch length
+  other_configs the other BASELINE configs at their stated sizes (64 x 6^3 walkers, 64 x 8^3 swimmers, one 20^3 lattice),
+                N = 1 only: value, us per step, algorithmic roofline fraction, kernel
+  cpu_baseline  the reference C++ voxelyze (oracle/_ref/voxelyze_ref, built from the reference sources) on this box's host
+                cores: `nproc` concurrent processes on 2 x nproc robots of the bench population (evaluation.py:89 launches
+                one process per robot and lets the OS schedule them), plus the single-process figure; rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -29,76 +40,94 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+INIT_CM_TIME = 0.05            # FitnessEvaluationInitTime of the bench robots
 
 
-def make_population(tmp, count, first_seed, shape, sim_time, init_time, selfcol=True):
+def make_population(tmp, count, first_seed, shape, sim_time, init_time, selfcol=True, env=None, variant_phase=False):
     from evosoro_amd import workloads
     from evosoro_amd.base import Sim, Env
     from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
     for d in ("voxelyzeFiles", "fitnessFiles", "tempFiles"):
         os.makedirs(os.path.join(tmp, d), exist_ok=True)
     sim = Sim(self_collisions_enabled=selfcol, dt_frac=0.9, simulation_time=sim_time, fitness_eval_init_time=init_time)
-    env = Env()
+    env = env or Env()
     paths = []
     for i in range(count):
-        ind = workloads.random_robot(first_seed + i, shape, first_seed + i)
+        ind = workloads.random_robot(first_seed + i, shape, first_seed + i, phase_offset=variant_phase)
         write_voxelyze_file(sim, env, ind, tmp, "bench")
         paths.append(os.path.join(tmp, "voxelyzeFiles", "bench--id_%05i.vxa" % ind.id))
     return paths
 
 
-def cpu_baseline(shape, sim_time=0.25):
-    """Reference voxelyze (oracle/_ref) on the host cores: 4 robots per core (at most 128) of the bench workload,
-    0.25 s of simulated time each (about 3900 steps), launched concurrently like evaluation.py:89 does; sized for
-    roughly 10-30 s of CPU work."""
+def run_reference(ref, paths, tmp, concurrency):
+    """the reference binary on every file, `concurrency` processes at a time; wall seconds"""
+    t0 = time.time()
+    running, queue = [], list(paths)
+    while queue or running:
+        while queue and len(running) < concurrency:
+            running.append(subprocess.Popen(["timeout", "900", ref, "-f", queue.pop(0)], cwd=tmp,
+                                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        running = [p for p in running if p.poll() is None]
+        time.sleep(0.002)
+    return time.time() - t0
+
+
+def cpu_baseline(shape):
+    """Reference voxelyze (oracle/_ref) on the host cores.  Sample: 2 x nproc robots of the bench population (at most 512),
+    0.12 s of simulated time each (about 1900 steps), nproc processes at a time, like evaluation.py:89 -- sized for roughly
+    10-30 s of wall clock; then ONE robot alone for the single-core figure."""
     from evosoro_amd import engine
     ref = os.path.join(REPO, "oracle", "_ref", "voxelyze_ref")
-    cores = os.cpu_count() or 1
-    budget_robots = min(128, 4 * cores)
+    nproc = os.cpu_count() or 1
+    sim_time = 0.12
     tmp = tempfile.mkdtemp(prefix="vxbench_cpu_")
     try:
-        paths = make_population(tmp, budget_robots, 0, shape, sim_time, 0.05)
-        work = 0.0
-        with engine.Engine(engine.VOXCAD, 0) as eng:      # only to get voxel counts and planned step counts
-            for p in paths:
-                eng.add_vxa_file(p)
-            for i in range(len(paths)):
-                d = eng.dims(i)
-                work += d["nvox"] * d["planned_steps"]
+        paths = make_population(tmp, min(512, 2 * nproc), 0, shape, sim_time, 0.05)
+
+        def work_of(files):
+            total = 0.0
+            for p in files:
+                d = engine.inspect_vxa(p)
+                total += d.nvox * d.planned_steps
+            return total
         if os.path.exists(ref):
-            kind, used = "reference", min(cores, len(paths))
-            t0 = time.time()
-            running, queue = [], list(paths)
-            while queue or running:
-                while queue and len(running) < used:
-                    running.append(subprocess.Popen(["timeout", "600", ref, "-f", queue.pop(0)], cwd=tmp,
-                                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
-                running = [p for p in running if p.poll() is None]
-                time.sleep(0.005)
-            wall = time.time() - t0
-            done = len([f for f in os.listdir(os.path.join(tmp, "fitnessFiles")) if f.endswith(".xml")])
-            if done != len(paths):
-                raise RuntimeError("reference finished %d of %d robots" % (done, len(paths)))
-        else:
-            from oracle import vxoracle
-            kind, used = "port", 1
-            t0 = time.time()
-            for p in paths:
-                sim = vxoracle.OracleSim.from_vxa(p)
-                sim.step(-1)
-            wall = time.time() - t0
-        return {"value": work / wall, "unit": "voxel-timesteps/s", "cores": used, "kind": kind,
-                "sample": "%d random %dx%dx%d robots of the bench population, %.2f s simulated each (%.3g voxel-steps), "
-                          "%d concurrent processes, %.1f s wall" % (len(paths), shape[0], shape[1], shape[2], sim_time, work, used, wall)}
+            # all hardware threads busy, and one process per physical core (two threads of a core share its FP units): the better counts
+            walls = {}
+            for used in sorted(set([nproc, max(1, nproc // 2)]), reverse=True):
+                for f in os.listdir(os.path.join(tmp, "fitnessFiles")):
+                    os.remove(os.path.join(tmp, "fitnessFiles", f))
+                walls[used] = run_reference(ref, paths, tmp, used)
+                done = len([f for f in os.listdir(os.path.join(tmp, "fitnessFiles")) if f.endswith(".xml")])
+                if done != len(paths):
+                    raise RuntimeError("reference finished %d of %d robots" % (done, len(paths)))
+            used = min(walls, key=walls.get)
+            wall = walls[used]
+            one = run_reference(ref, paths[:1], tmp, 1)
+            return {"value": work_of(paths) / wall, "unit": "voxel-timesteps/s", "cores": used, "kind": "reference",
+                    "nproc": nproc, "single_core_value": work_of(paths[:1]) / one,
+                    "sample": "%d random %dx%dx%d robots of the bench population, %.2f s simulated each (%.3g voxel-steps), one process per "
+                              "robot (evaluation.py:89), g++ -O3 build of the reference sources, host with %d hardware threads: %s; "
+                              "value = the faster; single_core_value: one robot alone, %.1f s"
+                              % (len(paths), shape[0], shape[1], shape[2], sim_time, work_of(paths), nproc,
+                                 ", ".join("%d at a time %.1f s" % (u, w) for u, w in sorted(walls.items())), one)}
+        from oracle import vxoracle
+        t0 = time.time()
+        for p in paths[:4]:
+            sim = vxoracle.OracleSim.from_vxa(p)
+            sim.step(-1)
+        wall = time.time() - t0
+        return {"value": work_of(paths[:4]) / wall, "unit": "voxel-timesteps/s", "cores": 1, "kind": "port", "nproc": nproc,
+                "single_core_value": work_of(paths[:4]) / wall,
+                "sample": "4 robots of the bench population through the C restatement (oracle/), one core, %.1f s" % wall}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
 def measured_traffic(robots_per_gpu, lattice):
-    """HBM bytes the dominant kernel really moved, from the newest rocprofv3 counter summary under profiles/
-    (scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes over this same command; FETCH_SIZE is
-    doubled, as the 8-byte-per-lane calibration kernels of the same passes show it counts half the bytes).  PMC
-    counters cannot be read from inside this process, so the figure is only reported for the profiled workload."""
+    """HBM GB/s the dominant kernel really moved, from the newest rocprofv3 counter summary under profiles/
+    (scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes over this same command; FETCH_SIZE scaled by
+    the calibration kernels of the same passes).  PMC counters cannot be read from inside this process, so the figure is
+    only reported for the profiled workload; it is a RATE (bytes of a launch over that launch's duration in the profile)."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")))
     if not files or robots_per_gpu != 512 or lattice != 10:
@@ -110,10 +139,65 @@ def measured_traffic(robots_per_gpu, lattice):
     fetch_scale = t["calib_true_bytes"] / (t["calib_fetch_raw"] * 1024.0) if t.get("calib_fetch_raw") else 2.0
     write_scale = t["calib_true_bytes"] / (t["calib_write_raw"] * 1024.0) if t.get("calib_write_raw") else 1.0
     nbytes = t["fetch_raw_per_launch"] * 1024.0 * fetch_scale + t["write_raw_per_launch"] * 1024.0 * write_scale
-    return {"traffic": nbytes / t["avg_launch_ns"],      # bytes / ns = GB/s, per launch like `achieved`
-            "traffic_bytes_per_launch": nbytes,
+    return {"traffic": nbytes / t["avg_launch_ns"],
             "traffic_source": os.path.relpath(files[-1], REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "command; FETCH x%.2f, WRITE x%.2f from the calibration kernels)" % (fetch_scale, write_scale)}
+
+
+def kernel_name(block):
+    return "k_tile_steps" if block == 1 else (("k_robot_steps<%d,...>" % block) if block else "k_bonds+k_voxels")
+
+
+def timed_steps(eng, steps, barrier=None):
+    """EXACTLY `steps` time steps of every robot, bracketed the way the driver asks: barrier + device sync on both sides"""
+    import torch
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(steps)                      # (returns after the engine's own stream synchronisation)
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0
+
+
+def side_config(engine, name, variant, count, shape, env, device, steps, full=False, phase=False, init_time=0.02):
+    """one of the other BASELINE configs at its stated size: pre-advanced past InitCmTime, then `steps` timed steps"""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    tmp = tempfile.mkdtemp(prefix="vxbench_side_")
+    try:
+        os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+        # (long enough for the robot with the largest time step: nothing is run to its stop condition here)
+        sim = Sim(dt_frac=0.9, simulation_time=init_time + (steps + 4000) * 7.2e-4, fitness_eval_init_time=init_time)
+        with engine.Engine(variant, device) as eng:
+            for i in range(count):
+                if full:
+                    ind = workloads.make_individual(i, workloads.full_material(shape[0], 1 + i))
+                else:
+                    ind = workloads.random_robot(i, shape, i, phase_offset=phase)
+                write_voxelyze_file(sim, env, ind, tmp, "s")
+                eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "s--id_%05i.vxa" % i))
+            dims = [eng.dims(i) for i in range(count)]
+            nvox = sum(d["nvox"] for d in dims)
+            nbond = sum(d["nbond"] for d in dims)
+            pre = int(max(init_time / d["dt"] for d in dims)) + 32
+            eng.step(pre)
+            c0 = eng.counters()
+            elapsed = timed_steps(eng, steps)
+            c1 = eng.counters()
+            assert abs((c1.voxel_steps - c0.voxel_steps) - float(nvox) * steps) < 0.5, name
+            alg = (224.0 * nvox + 144.0 * nbond) * steps
+            large, total = eng.bond_modes()
+            return {"workload": name, "value": nvox * steps / elapsed, "unit": "voxel-timesteps/s",
+                    "us_per_step": elapsed / steps * 1e6, "steps": steps, "voxels": nvox, "bonds": nbond,
+                    "kernel": kernel_name(c1.dominant_block),
+                    "roofline_frac": alg / c1.dominant_seconds / 1e9 / HBM_PEAK_GBS if c1.dominant_seconds > 0 else None,
+                    "large_angle_bonds": large / max(1, total)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -124,12 +208,14 @@ def main():
     ap.add_argument("--robots-per-gpu", type=int, default=512)
     ap.add_argument("--lattice", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from evosoro_amd import engine, parallel
+    from evosoro_amd.base import Env
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -137,51 +223,81 @@ def main():
     distributed = world > 1 or os.environ.get("VXH_FORCE_DIST") == "1"   # (the latter: 1-rank RCCL smoke test)
     if args.gpus != world and distributed:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    # VXH_BENCH_SHARE_GPU=1: every rank on device 0 and gloo instead of RCCL -- only to walk the N > 1 code path on a 1-GPU box
+    share_gpu = os.environ.get("VXH_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    barrier = dist.barrier if distributed else None
 
     shape = (args.lattice,) * 3
     n_local = args.robots_per_gpu
-    tmp = tempfile.mkdtemp(prefix="vxbench_r%d_" % rank)
-    try:
-        # long enough that no robot reaches its stop condition inside warmup + timed steps
-        sim_time = max(0.5, (args.steps + args.warmup + 64) * 7.2e-4)
-        paths = make_population(tmp, n_local, rank * n_local, shape, sim_time, 0.05)
+
+    def run_population(paths):
+        """pre-advance past InitCmTime + warmup (untimed), then the timed steps; returns everything the line needs"""
         eng = engine.Engine(engine.VOXCAD, local_rank)
         for p in paths:
             eng.add_vxa_file(p)
-        nvox = sum(eng.dims(i)["nvox"] for i in range(n_local))
-        nbond = sum(eng.dims(i)["nbond"] for i in range(n_local))
-        eng.step(max(args.warmup, 1))                       # upload + warmup (untimed)
+        n = len(paths)
+        dims = [eng.dims(i) for i in range(n)]
+        nvox, nbond = sum(d["nvox"] for d in dims), sum(d["nbond"] for d in dims)
+        pre = (int(max(INIT_CM_TIME / d["dt"] for d in dims)) + 32) if n else 0
+        if n:
+            eng.step(pre + max(args.warmup, 1))             # upload, past InitCmTime, warmup: all untimed
         c0 = eng.counters()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.step(args.steps)                                # EXACTLY K time steps of every robot
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_steps(eng, args.steps, barrier)
         c1 = eng.counters()
         local_vs = c1.voxel_steps - c0.voxel_steps
         assert abs(local_vs - float(nvox) * args.steps) < 0.5, "a robot stopped inside the timed region"
-        stats = torch.tensor([elapsed, local_vs, c1.kernel_seconds - c0.kernel_seconds], dtype=torch.float64, device="cuda")
-        if distributed:
-            tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-            elapsed_max, total_vs = float(tmax[0]), float(tsum[1])
-        else:
-            elapsed_max, total_vs = elapsed, local_vs
+        return eng, elapsed, local_vs, nvox, nbond, c0, c1, pre
+
+    def reduce_stats(elapsed, local_vs):
+        if not distributed:
+            return elapsed, local_vs
+        stats = torch.tensor([elapsed, local_vs], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        return float(tmax[0]), float(tsum[1])
+
+    tmp = tempfile.mkdtemp(prefix="vxbench_r%d_" % rank)
+    try:
+        # long enough that no robot reaches its stop condition inside pre-advance + warmup + timed steps
+        # (sized for the largest time step a robot can have, ten times the usual one: nothing is run to its stop condition)
+        sim_time = max(0.5, INIT_CM_TIME + (args.steps + args.warmup + 1100) * 7.2e-4)
+        paths = make_population(tmp, n_local, rank * n_local, shape, sim_time, INIT_CM_TIME)
+        eng, elapsed, local_vs, nvox, nbond, c0, c1, pre = run_population(paths)
+        elapsed_max, total_vs = reduce_stats(elapsed, local_vs)
+        large, total_b = eng.bond_modes()
         # the path's collective: fitness records of every rank to every rank (untimed region, reported separately)
         tg = time.perf_counter()
         records = np.stack([parallel.result_to_record(eng.result(i)) for i in range(n_local)])
         table = parallel.gather_records(records, list(range(rank * n_local, (rank + 1) * n_local)), world * n_local,
-                                        torch.device("cuda", local_rank) if distributed else None)
+                                        torch.device("cuda", local_rank) if (distributed and not share_gpu) else None)
         gather_ms = (time.perf_counter() - tg) * 1e3
         assert table.shape[0] == world * n_local and (table[:, 2] > 0).all()
+        eng.close()
+
+        strong = None
+        if world > 1:
+            # BASELINE configs[2] as stated: ONE population of 512, partitioned over the ranks by cost (LPT on voxels x steps)
+            shared = [make_population(os.path.join(tmp, "strong"), n_local, 0, shape, sim_time, INIT_CM_TIME) if rank == 0 else None]
+            dist.broadcast_object_list(shared, src=0)        # (one node: rank 0's files are visible to every rank)
+            all_paths = shared[0]
+            costs = [engine.inspect_vxa(p).nvox for p in all_paths]          # (every robot takes the same number of steps here)
+            mine = parallel.shard_by_cost(costs, world)[rank]
+            seng, s_elapsed, s_vs, s_nvox, _, _, sc1, _ = run_population([all_paths[i] for i in mine])
+            s_elapsed_max, s_total_vs = reduce_stats(s_elapsed, s_vs)
+            strong = {"scaling": "strong", "workload": "ONE population of %d random %dx%dx%d robots sharded %d-way by cost (%d on this rank)"
+                                 % (n_local, shape[0], shape[1], shape[2], world, len(mine)),
+                      "value": s_total_vs / s_elapsed_max, "unit": "voxel-timesteps/s", "ms_per_step": s_elapsed_max / args.steps * 1e3,
+                      "kernel": kernel_name(sc1.dominant_block)}
+            seng.close()
 
         if rank == 0:
             dom_seconds = c1.dominant_seconds
@@ -195,24 +311,40 @@ def main():
                                        "pop-512 of 10x10x10), self-collision on, DtFrac 0.9, evosoro default materials"
                                        % (n_local, shape[0], shape[1], shape[2]),
                            "robots_per_gpu": n_local, "voxels_per_gpu": nvox, "bonds_per_gpu": nbond,
+                           "pre_advanced_steps": pre + max(args.warmup, 1),
+                           "large_angle_bonds": large / max(1, total_b),
                            "parallelism": "population sharded %d-way, no data-path collective" % world},
                 "roofline": {"bound": "hbm", "achieved": roof_bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": roof_bw / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": ("k_robot_steps<%d,...>" % c1.dominant_block) if c1.dominant_block else "k_bonds+k_voxels",
+                             "kernel": kernel_name(c1.dominant_block),
                              "launches": int(c1.dominant_launches),
                              "avg_launch_ms": dom_seconds / max(1, c1.dominant_launches) * 1e3,
-                             "alg_bytes_per_launch": c1.dominant_alg_bytes / max(1, c1.dominant_launches),
+                             "alg_bytes_per_voxel_step": c1.dominant_alg_bytes / max(1.0, c1.dominant_voxel_steps),
                              "note": "achieved = (224*Nvox + 144*Nbond) bytes per voxel-step x steps / HIP-event time of "
-                                     "the dominant size class on its stream; other size classes run concurrently"},
+                                     "the dominant kernel on its stream; achieved and traffic are both rates (GB/s)"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,
             }
             out["roofline"].update(measured_traffic(n_local, args.lattice))
+            if strong:
+                out["strong"] = strong
+            if world == 1 and not args.no_other_configs:
+                env_w = Env()
+                env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+                env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+                out["other_configs"] = [
+                    side_config(engine, "configs[1]: batch of 64 random 6x6x6 robots", engine.VOXCAD, 64, (6, 6, 6), Env(), local_rank, 1024),
+                    side_config(engine, "configs[3]: 64 random 8x8x8 swimmers (_voxcad_land_water, fluid drag)", engine.VOXCAD_LAND_WATER,
+                                64, (8, 8, 8), env_w, local_rank, 1024, phase=True, init_time=0.005),
+                    side_config(engine, "configs[4]: one full 20x20x20 lattice, self-collision on", engine.VOXCAD, 1, (20, 20, 20), Env(),
+                                local_rank, 2048, full=True, init_time=0.005),
+                ]
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(shape)
             print(json.dumps(out))
-        eng.close()
     finally:
+        if distributed:
+            dist.barrier()
         shutil.rmtree(tmp, ignore_errors=True)
         if distributed:
             dist.destroy_process_group()

@@ -212,6 +212,13 @@ int vxh_get_counters(const vxh_engine* e, vxh_counters* out)
     return VXH_OK;
 }
 
+int vxh_count_bond_modes(const vxh_engine* ce, long long* large_angle_out, long long* total_out)
+{
+    vxh_engine* e = const_cast<vxh_engine*>(ce);
+    if (!e || !e->impl) return VXH_ERR_ARG;
+    return guarded(e, [&] { long long l = 0, t = 0; e->impl->bond_modes(&l, &t); if (large_angle_out) *large_angle_out = l; if (total_out) *total_out = t; });
+}
+
 int vxh_set_option(vxh_engine* e, const char* key, double value)
 {
     if (!key) return VXH_ERR_ARG;

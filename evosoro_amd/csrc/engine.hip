@@ -1004,6 +1004,23 @@ void Engine::download()
     state_downloaded_ = true;
 }
 
+void Engine::bond_modes(long long* large_angle, long long* total)
+{
+    if (!prepared_) throw std::logic_error("bond modes requested before vxh_run/vxh_step");
+    HIP_OK(hipSetDevice(device_id_));
+    const int nv = dev_->B.nv;
+    std::vector<unsigned char> flags((size_t)3 * nv);
+    HIP_OK(hipMemcpy(flags.data(), dev_->B.small_angle, flags.size(), hipMemcpyDeviceToHost));
+    long long l = 0, t = 0;
+    for (size_t r = 0; r < robots_.size(); ++r) {
+        const RobotModel& M = robots_[r];
+        for (int v = 0; v < M.nvox; ++v)
+            for (int a = 0; a < 3; ++a)
+                if (M.bond_class[(size_t)v * 3 + a] >= 0) { ++t; if (!(flags[(size_t)a * nv + dev_->vox_begin[r] + v] & 1)) ++l; }
+    }
+    *large_angle = l; *total = t;
+}
+
 void Engine::result(int robot, vxh_result* out)
 {
     if (!prepared_) throw std::logic_error("results requested before vxh_run/vxh_step");

@@ -31,6 +31,7 @@ public:
     void result(int robot, vxh_result* out);
     void state14(int robot, double* out, int capacity);
     void counters(vxh_counters* out) const { *out = counters_; }
+    void bond_modes(long long* large_angle, long long* total);   // SmallAngle flags of every bond, downloaded
     void set_option(const std::string& key, double value);
     int variant() const { return variant_; }
 

@@ -18,7 +18,7 @@ ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW =
 
 EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
-           "vxh_fitness_file_name", "vxh_get_state", "vxh_get_counters", "vxh_set_option", "vxh_strerror",
+           "vxh_fitness_file_name", "vxh_get_state", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version"]
 
 
@@ -117,6 +117,7 @@ def load_library():
     lib.vxh_fitness_file_name.argtypes = [P, I, ctypes.c_char_p, ctypes.c_size_t]
     lib.vxh_get_state.argtypes = [P, I, P, I]
     lib.vxh_get_counters.argtypes = [P, ctypes.POINTER(VxhCounters)]
+    lib.vxh_count_bond_modes.argtypes = [P, ctypes.POINTER(LL), ctypes.POINTER(LL)]
     lib.vxh_set_option.argtypes = [P, ctypes.c_char_p, D]
     lib.vxh_strerror.argtypes = [I]
     lib.vxh_strerror.restype = ctypes.c_char_p
@@ -255,6 +256,12 @@ class Engine(object):
         out = VxhCounters()
         self._check(self._lib.vxh_get_counters(self._h, ctypes.byref(out)))
         return out
+
+    def bond_modes(self):
+        """(bonds in the large-angle branch, bonds) of the whole batch right now"""
+        large, total = ctypes.c_longlong(), ctypes.c_longlong()
+        self._check(self._lib.vxh_count_bond_modes(self._h, ctypes.byref(large), ctypes.byref(total)))
+        return large.value, total.value
 
     def set_option(self, key, value):
         self._check(self._lib.vxh_set_option(self._h, key.encode(), float(value)))

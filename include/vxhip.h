@@ -134,6 +134,10 @@ int  vxh_fitness_file_name(const vxh_engine* e, int robot, char* buf, size_t cap
 /* per voxel 14 doubles: pos3, quat(w,x,y,z), scale, vel3, angvel3; capacity in voxels */
 int  vxh_get_state(const vxh_engine* e, int robot, double* out14n, int capacity);
 int  vxh_get_counters(const vxh_engine* e, vxh_counters* out);
+/* how many internal bonds of the batch are currently in the large-angle branch of CVXS_BondInternal::CalcLinForce
+ * (VX/VXS_BondInternal.cpp:72-126, the SmallAngle flag): the two branches differ 2.5x in arithmetic, so a throughput figure
+ * should say which mix it was measured on */
+int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long long* total_out);
 /* Options (all have working defaults):
  *   "tiled"             0 = never, 1 (default) = robots of more than 1024 voxels and populations smaller than 3/4 of the CUs are
  *                       stepped by the multi-workgroup kernel, 2 = every robot it supports; "tiles_per_robot" > 0 requests a tile count.
