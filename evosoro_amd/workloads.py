@@ -91,6 +91,14 @@ def random_robot(ident, shape, seed, p_empty=0.3, phase_offset=False):
     return make_individual(ident, mat, extra)
 
 
+def swimmer(ident, shape, seed, p_empty=0.3):
+    """Random robot with a per-voxel <PhaseOffset> layer, as the _voxcad_land_water examples evolve them (BASELINE configs[3]).
+    Phases are rounded to 3 decimals: Python 2 (the reference) and Python 3 print such numbers alike, so the .vxa text of the
+    golden cases is the same whichever interpreter wrote it."""
+    phase = np.round(np.random.RandomState(seed + 100003).uniform(-1.0, 1.0, size=shape), 3)
+    return make_individual(ident, random_material(shape, seed, p_empty), OrderedDict([("<PhaseOffset>", phase)]))
+
+
 def probe_material():
     """The 6x6x6 plumbing robot of SURVEY.md Appendix C: RandomState(1).randint(0,5), floor layer all muscle."""
     mat = np.random.RandomState(1).randint(0, 5, size=(6, 6, 6)).astype(np.int64)

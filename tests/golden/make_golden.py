@@ -120,6 +120,24 @@ def cases():
     out["lw_land10"] = dict(variant="lw", early=False, sim=Sim(dt_frac=0.9, simulation_time=0.1, fitness_eval_init_time=0.02),
                             env=Env(), ind=workloads.make_individual(31, workloads.full_material(10, 62),
                                                                      OrderedDict([("<PhaseOffset>", phase10)])))
+    # ---- BASELINE configs[1] and [3] at their stated sizes: four robots of each batch (the GPU tests step the whole batches and
+    # compare these four with the reference), the whole 0.5 s evaluation; final state and result XML only
+    for k in (0, 21, 42, 63):
+        out["cfg1_%02d" % k] = dict(variant="land", early=False,
+                                    sim=Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1),
+                                    env=Env(), ind=workloads.random_robot(100 + k, (6, 6, 6), k))
+        out["cfg3_%02d" % k] = dict(variant="lw", early=False,
+                                    sim=Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.05),
+                                    env=env_w, ind=workloads.swimmer(200 + k, (8, 8, 8), k))
+    # ---- the other stop rules (VX_Sim.cpp:1398-1423): type 1 = a number of time steps, type 3 = a number of actuation periods
+    soft4 = workloads.random_material((5, 5, 4), 71, 0.2)
+    soft4[soft4 == 2] = 1
+    out["stop1_5"] = dict(variant="land", sim=Sim(dt_frac=0.9, stop_condition=1, simulation_time=700, fitness_eval_init_time=0.05),
+                          env=Env(), ind=workloads.make_individual(40, soft4))
+    out["stop3_5"] = dict(variant="land", sim=Sim(dt_frac=0.9, stop_condition=3, simulation_time=1.5, fitness_eval_init_time=0.05),
+                          env=Env(), ind=workloads.make_individual(41, soft4))
+    out["lw_stop3_5"] = dict(variant="lw", sim=Sim(dt_frac=0.9, stop_condition=3, simulation_time=1.5, fitness_eval_init_time=0.05),
+                             env=Env(), ind=workloads.make_individual(42, soft4))
     return out
 
 

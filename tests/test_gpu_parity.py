@@ -23,7 +23,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "stiff5", "grow5", "devo4"]
+CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "stiff5", "grow5", "devo4",
+         "stop1_5", "stop3_5"]                # (the last two: StopConditionType 1 and 3, VX_Sim.cpp:1398-1423)
 FLOOR_VOX = 1e-9
 
 
@@ -34,8 +35,13 @@ def eng_mod():
 
 
 def _perturbed(model):
+    """the same robot with ONE input changed by an ulp or two: gravity -- or, for a robot in a fluid, where gravity is off, the
+    drag coefficient"""
     twin = dict(model)
-    twin["grav_acc"] = model["grav_acc"] * (1 + 4e-16)
+    if model.get("fluid_env"):
+        twin["aggregate_drag_coef"] = model["aggregate_drag_coef"] * (1 + 4e-16)
+    else:
+        twin["grav_acc"] = model["grav_acc"] * (1 + 4e-16)
     return twin
 
 
@@ -225,7 +231,7 @@ def test_full_size_batch_properties(eng_mod, tmp_path):
         assert results[i].steps == o.info().steps
 
 
-LW_CASES = ["lw_land6", "lw_swim6", "lw_hexapus", "lw_quadruped_land", "lw_stiff5"]
+LW_CASES = ["lw_land6", "lw_swim6", "lw_hexapus", "lw_quadruped_land", "lw_stiff5", "lw_stop3_5"]
 
 
 def test_land_water_variant(eng_mod, golden_dir):
@@ -741,3 +747,70 @@ def test_evaluate_all_with_the_real_engine(eng_mod, golden_dir, manifest, tmp_pa
     assert pop2.best_fit_so_far == other.fitness and len(os.listdir(os.path.join(run, "bestSoFar/fitOnly"))) == 2
     assert os.listdir(os.path.join(run, "ancestors")) == ["E--id_00002.vxa"]
     assert not any("WARNING" in l for l in log.lines)
+
+
+def _full_batch_vs_reference(eng_mod, golden_dir, tmp_path, variant, prefix, make_ind, sim, env, tags):
+    """64 robots stepped through their whole evaluation in one batch; robots 0, 21, 42 and 63 of the batch are golden cases whose final
+    state and result XML come from the reference binary"""
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    golden = {0: "%s_00" % prefix, 21: "%s_21" % prefix, 42: "%s_42" % prefix, 63: "%s_63" % prefix}
+    paths = []
+    for i in range(64):
+        if i in golden:
+            paths.append(os.path.join(golden_dir, "vxa", golden[i] + ".vxa"))
+        else:
+            ind = make_ind(i)
+            write_voxelyze_file(sim, env, ind, str(tmp_path), "full")
+            paths.append(str(tmp_path / "voxelyzeFiles" / ("full--id_%05i.vxa" % ind.id)))
+    with eng_mod.Engine(variant, 0) as eng:
+        eng.add_vxa_files(paths)
+        eng.run()
+        statuses = [eng.result(i).status for i in range(64)]
+        assert statuses == [eng_mod.ROBOT_FINISHED] * 64
+        steps = {eng.result(i).steps for i in range(64)}
+        assert all(np.isfinite(eng.state(i)).all() for i in range(0, 64, 7))
+        worst = 0.0
+        for i, name in golden.items():
+            model = vo.parse_vxa(paths[i], variant)
+            lat = model["lattice_dim"]
+            planned = eng.dims(i)["planned_steps"]
+            tol = max(FLOOR_VOX, 20 * _spread(model, (planned // 4, planned // 2, planned))[0])
+            trace = vo.read_trace(os.path.join(golden_dir, "expected", name + ".final.bin"))
+            want = vo.read_result_xml(os.path.join(golden_dir, "expected", name + ".xml"))
+            res = eng.result(i)
+            assert res.steps == trace["total_steps"] == planned, name
+            err = _pos_err(eng.state(i), trace["records"][-1]["state"], lat)
+            worst = max(worst, err / tol)
+            assert err <= tol, (name, err, tol)
+            assert np.abs(np.array(res.cur_cm) - trace["cur_cm"]).max() / lat <= tol, name
+            assert np.abs(np.array(res.ini_cm) - trace["ini_cm"]).max() / lat <= tol, name
+            for tag, field in tags:
+                val = getattr(res, field)
+                assert abs(val - want[tag]) <= 2 * tol + 1e-5 * abs(want[tag]), (name, tag, val, want[tag])
+        print("%s: 64 robots, step counts %s, worst error / bar over the four golden robots %.3g" % (prefix, sorted(steps)[:3], worst))
+
+
+def test_configs1_whole_batch_full_duration_vs_reference(eng_mod, golden_dir, tmp_path):
+    """BASELINE configs[1] at its stated size and duration: 64 random 6x6x6 walkers, 0.5 s (7806 steps each)"""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    _full_batch_vs_reference(eng_mod, golden_dir, tmp_path, eng_mod.VOXCAD, "cfg1", lambda i: workloads.random_robot(100 + i, (6, 6, 6), i),
+                             Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1), Env(),
+                             [("NormFinalDist", "norm_final_dist"), ("finalDistY", "final_dist_y"), ("AnteriorDist", "anterior_dist"),
+                              ("PosteriorY", "posterior_y")])
+
+
+def test_configs3_whole_batch_full_duration_vs_reference(eng_mod, golden_dir, tmp_path):
+    """BASELINE configs[3] at its stated size and duration: 64 random 8x8x8 swimmers of _voxcad_land_water in a fluid (per-facet drag,
+    gravity and floor off), 0.5 s each"""
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    _full_batch_vs_reference(eng_mod, golden_dir, tmp_path, eng_mod.VOXCAD_LAND_WATER, "cfg3", lambda i: workloads.swimmer(200 + i, (8, 8, 8), i),
+                             Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.05), env_w,
+                             [("normAbsoluteDisplacement", "norm_abs_disp"), ("normDistX", "norm_dist_x"), ("normDistY", "norm_dist_y"),
+                              ("normDistZ", "norm_dist_z")])

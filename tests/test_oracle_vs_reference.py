@@ -13,10 +13,11 @@ import pytest
 
 from oracle import vxoracle as vo
 
-LAND_CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "stiff5", "grow5", "devo4"]
+LAND_CASES = ["probe6", "rand6_nocol", "rand6_col", "soft5_init0", "phase4", "stiff5", "grow5", "devo4",
+              "stop1_5", "stop3_5"]           # (the last two: StopConditionType 1 = time steps, 3 = actuation periods)
 SHIPPED = ["example_1", "example_phaseoffset"]
 # _voxcad_land_water: generated (land + fluid swimmer with facet drag) and two sample files shipped with the reference
-LW_CASES = ["lw_land6", "lw_swim6", "lw_stiff5"]
+LW_CASES = ["lw_land6", "lw_swim6", "lw_stiff5", "lw_stop3_5"]
 LW_SHIPPED = ["lw_hexapus", "lw_quadruped_land"]
 LW_TAGS = [("normAbsoluteDisplacement", "norm_abs_disp"), ("normDistX", "norm_dist_x"), ("normDistY", "norm_dist_y"),
            ("normDistZ", "norm_dist_z"), ("VoxelNumber", "nvox")]
@@ -30,7 +31,7 @@ RESULT_TAGS = [("NormFinalDist", "norm_final_dist"), ("NormRegimeDist", "norm_re
 
 
 def _sim(golden_dir, name):
-    return vo.OracleSim.from_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"), variant=1 if name.startswith("lw_") else 0)
+    return vo.OracleSim.from_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"), variant=1 if name.startswith(("lw_", "cfg3_")) else 0)
 
 
 @pytest.mark.parametrize("name", LAND_CASES + SHIPPED + LW_CASES + LW_SHIPPED)
@@ -51,7 +52,8 @@ def test_early_trace_bit_exact(golden_dir, name):
 
 
 # BASELINE configs[2] size: two robots of the bench population, whole 0.5 s evaluation (7806 steps, ~700 voxels, collisions)
-BIG_CASES = ["bench10_0", "bench10_1"]
+# ... and BASELINE configs[1]: four robots of the batch of 64 random 6x6x6 walkers, whole 0.5 s evaluation
+BIG_CASES = ["bench10_0", "bench10_1", "cfg1_00", "cfg1_21", "cfg1_42", "cfg1_63"]
 
 
 @pytest.mark.parametrize("name", LAND_CASES + BIG_CASES)
@@ -72,7 +74,8 @@ def test_full_run_final_state_and_result(golden_dir, name):
 
 
 # BASELINE configs[2] size in _voxcad_land_water: a ~700-voxel swimmer and a full 10x10x10 lattice on land (final state + XML)
-LW_BIG_CASES = ["lw_swim10", "lw_land10"]
+# ... and BASELINE configs[3]: four swimmers of the batch of 64 random 8x8x8 ones, whole 0.5 s evaluation
+LW_BIG_CASES = ["lw_swim10", "lw_land10", "cfg3_00", "cfg3_21", "cfg3_42", "cfg3_63"]
 
 
 @pytest.mark.parametrize("name", LW_CASES + LW_BIG_CASES)
