@@ -189,7 +189,9 @@ int vxh_write_result_xml(const vxh_engine* ce, int robot, const char* path_or_nu
     const vxh::RobotModel& m = e->impl->robot(robot);
     std::string path = path_or_null ? path_or_null : m.vxa.fitness_file_name;
     if (path.empty()) { e->last_error = "no FitnessFileName in the .vxa and no path given"; return VXH_ERR_IO; }
-    const std::string text = vxh::result_xml(m, res);
+    std::string text;
+    rc = guarded(e, [&] { text = vxh::result_xml(m, res, e->impl->trace_of(robot)); });
+    if (rc != VXH_OK) return rc;
     std::FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) { e->last_error = "cannot write " + path; return VXH_ERR_IO; }
     const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
@@ -210,6 +212,13 @@ int vxh_get_counters(const vxh_engine* e, vxh_counters* out)
     if (!e || !e->impl || !out) return VXH_ERR_ARG;
     e->impl->counters(out);
     return VXH_OK;
+}
+
+int vxh_get_cm_trace(const vxh_engine* ce, int robot, double* out4n, int capacity, int* count_out)
+{
+    vxh_engine* e = const_cast<vxh_engine*>(ce);
+    if (bad_robot(e, robot) || capacity < 0 || (capacity > 0 && !out4n)) return VXH_ERR_ARG;
+    return guarded(e, [&] { const int n = e->impl->cm_trace(robot, out4n, capacity); if (count_out) *count_out = n; });
 }
 
 int vxh_count_bond_modes(const vxh_engine* ce, long long* large_angle_out, long long* total_out)

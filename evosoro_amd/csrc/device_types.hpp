@@ -37,6 +37,8 @@ struct DRobot {               // constant per robot
     double init_cm_time, stop_value, afterlife, temp_period_d;
     double min_temp_fact, growth_amplitude, col_horizon, filter_dist2, drag_coef;
     double midlife_freeze_time;
+    double trace_dt;              // <TimeBetweenTraces>, 0 = no centre-of-mass trace
+    int trace_begin, trace_cap;   // this robot's entries of DBatch::trace
     float temp_amplitude, temp_period;
 };
 
@@ -47,7 +49,9 @@ struct DRobotState {          // mutable per robot
     double act_sin, act_cos;      // streaming path: sincos of the actuation phase of the current step (actuation_sincos)
     unsigned long long maxvel2_bits;
     int steps, status, cm_init, active, diverged, col_overflow, rebuild_now, rebuilds;
-    int col_tiled, pad0;          // the contact rows were built by the tiled kernel (DBatch::col_code / tile_xh are valid for them)
+    int col_tiled, ntrace;        // the contact rows were built by the tiled kernel (DBatch::col_code / tile_xh are valid for them) ; points
+                                  // of the centre-of-mass trace recorded so far (SS.CMTrace, VX_Sim.cpp:1537-1547)
+    double last_trace_time;
 };
 
 // Tiled path (kernels_tiled.hpp): a robot cut into `ntiles` tiles, one workgroup each.  A tile OWNS n_own voxels (it
@@ -185,6 +189,7 @@ struct DBatch {
                                       // LDS (owned voxel: its index; mirrored partner: np + entry of tile_xh), -1 = fetch from memory
     int* tile_xh;                     // [total tiles][VXH_TILE_XH] contact partners owned by other tiles that the tile mirrors (global slots)
     int* tile_xhn;                    // [total tiles] their number
+    double* trace;                    // centre-of-mass traces: 4 doubles (time, x, y, z) per entry, robots one after the other (DRobot::trace_begin)
     unsigned long long* prof;         // developer builds (-DVXH_PHASE_TIMING): per-wave phase cycle sums, else null
     // constants from Vec3D.h evaluated by the host libm (thresholds of the small-angle logic)
     double small_angle_w, smallish_angle_w, slthresh_acos2sqrt;

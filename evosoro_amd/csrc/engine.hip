@@ -57,6 +57,8 @@ struct Engine::Device {
     DBatch B{};
     std::vector<DRobot> h_robot;
     std::vector<int> vox_begin;           // per robot, global slot of voxel 0
+    std::vector<int> trace_begin, trace_cap;   // per robot, entries of DBatch::trace
+    int total_trace = 0;
     std::vector<int> surf_begin;
     int total_surf = 0;
     long long max_planned = 0;
@@ -300,6 +302,19 @@ void Engine::prepare()
     if ((long long)nv * 36 >= (1LL << 32))
         throw std::invalid_argument("batch too large for one engine (" + std::to_string(nv) + " voxel slots; limit 119 million): split the population");
     D.total_surf = ns;
+    // centre-of-mass traces (<TimeBetweenTraces>): one entry at most every trace_dt of simulated time after InitCmTime
+    D.trace_begin.assign(nr, 0); D.trace_cap.assign(nr, 0); D.total_trace = 0;
+    for (int r = 0; r < nr; ++r) {
+        const RobotModel& M = robots_[r];
+        D.trace_begin[r] = D.total_trace;
+        if (variant_ == 0 && M.vxa.time_between_traces > 0 && M.nvox > 0) {
+            const double span = std::max(0.0, (double)M.planned_steps * M.dt - M.vxa.init_cm_time);
+            const double n = span / M.vxa.time_between_traces + 8;
+            if (!(n < 4e6)) throw std::invalid_argument("TimeBetweenTraces asks for more than 4 million trace points");
+            D.trace_cap[r] = (int)n;
+            D.total_trace += D.trace_cap[r];
+        }
+    }
 
     std::vector<int> wave_robot(nv / 64, -1), nbr((size_t)6 * nv, -1), surf(std::max(ns, 1), 0), surf_ord(nv, -1);
     std::vector<unsigned long long> excl;
@@ -465,6 +480,7 @@ void Engine::prepare()
         { double fd = X.collision_horizon * 1.5 * X.lattice_dim; R.filter_dist2 = fd * fd; }
         R.drag_coef = X.aggregate_drag_coef;
         R.midlife_freeze_time = X.midlife_freeze_time;
+        R.trace_dt = D.trace_cap[r] > 0 ? X.time_between_traces : 0.0; R.trace_begin = D.trace_begin[r]; R.trace_cap = D.trace_cap[r];
         R.temp_amplitude = (float)X.temp_amplitude; R.temp_period = (float)X.temp_period;
         DRobotState& S = rstate[r];
         std::memset(&S, 0, sizeof(S));
@@ -525,6 +541,7 @@ void Engine::prepare()
     B.mesh_pos = D.alloc_zero<double>(any_fluid ? (size_t)3 * std::max(total_mv, 1) : 1);
     B.fdrag = D.alloc_zero<double>(any_fluid ? (size_t)3 * std::max(total_facet, 1) : 1);
     D.any_fluid = any_fluid;
+    B.trace = D.alloc_zero<double>((size_t)std::max(D.total_trace, 1) * 4);
     B.col_rows = std::max(ns, 1);
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
@@ -950,6 +967,7 @@ void Engine::download_control()
         const DRobotState& S = rstate[r];
         H.cur_time = S.cur_time; H.steps = S.steps; H.status = S.status; H.cm_init = S.cm_init; H.rebuilds = S.rebuilds;
         H.eol_post_y = S.eol_post_y;
+        H.cm_trace.assign((size_t)4 * std::min(S.ntrace, D.trace_cap[r]), 0.0);      // (filled by download())
         for (int k = 0; k < 3; ++k) H.ini_cm[k] = S.ini_cm[k];
         if (S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
         if (S.status == 5)
@@ -984,6 +1002,12 @@ void Engine::download()
             H.scale[v] = plane(4 * b + 3)[base + v];
         }
     }
+    if (D.total_trace > 0) {
+        std::vector<double> tr((size_t)D.total_trace * 4);
+        HIP_OK(hipMemcpy(tr.data(), B.trace, sizeof(double) * tr.size(), hipMemcpyDeviceToHost));
+        for (int r = 0; r < nr; ++r)
+            for (size_t k = 0; k < host_[r].cm_trace.size(); ++k) host_[r].cm_trace[k] = tr[(size_t)D.trace_begin[r] * 4 + k];
+    }
     // land_water robots: directional strains of the last step (RobotVolumeEnd)
     bool any_mesh = false;
     for (int r = 0; r < nr; ++r) any_mesh = any_mesh || robots_[r].nmv > 0;
@@ -1002,6 +1026,21 @@ void Engine::download()
         for (int r = 0; r < nr; ++r) host_[r].strain.clear();
     }
     state_downloaded_ = true;
+}
+
+const std::vector<double>& Engine::trace_of(int robot)
+{
+    if (!prepared_) throw std::logic_error("trace requested before vxh_run/vxh_step");
+    if (!state_downloaded_) download();
+    return host_[robot].cm_trace;
+}
+
+int Engine::cm_trace(int robot, double* out4n, int capacity)
+{
+    const std::vector<double>& t = trace_of(robot);
+    const int n = (int)(t.size() / 4);
+    for (int k = 0; k < std::min(n, capacity) * 4; ++k) out4n[k] = t[k];
+    return n;
 }
 
 void Engine::bond_modes(long long* large_angle, long long* total)

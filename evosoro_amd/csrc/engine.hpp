@@ -14,6 +14,7 @@ struct HostState {                      // final/current state of one robot, dow
     std::vector<double> strain;                                // land_water: [6*n] StrainPosDirsCur xyz, StrainNegDirsCur xyz of the last step
     double cur_time = 0, ini_cm[3] = {0, 0, 0}, eol_post_y = 0;
     int steps = 0, status = 0, cm_init = 0, rebuilds = 0;
+    std::vector<double> cm_trace;                              // [4*k] (time, x, y, z): SS.CMTraceTime / SS.CMTrace
 };
 
 class Engine {
@@ -29,8 +30,10 @@ public:
     void reset();
     void clear();
     void result(int robot, vxh_result* out);
+    const std::vector<double>& trace_of(int robot);            // (downloads the state if needed)
     void state14(int robot, double* out, int capacity);
     void counters(vxh_counters* out) const { *out = counters_; }
+    int cm_trace(int robot, double* out4n, int capacity);      // returns the number of points recorded
     void bond_modes(long long* large_angle, long long* total);   // SmallAngle flags of every bond, downloaded
     void set_option(const std::string& key, double value);
     int variant() const { return variant_; }
@@ -60,6 +63,7 @@ private:
 
 // results.cpp: the numbers of CVX_SimGA::WriteResultFile from a final state, and the XML text
 void compute_result(const RobotModel& model, const HostState& st, vxh_result* out);
-std::string result_xml(const RobotModel& model, const vxh_result& res);
+std::string result_xml(const RobotModel& model, const vxh_result& res, const std::vector<double>& cm_trace);
+const std::vector<double>& empty_trace();
 
 }  // namespace vxh

@@ -604,18 +604,26 @@ __device__ __forceinline__ void actuation_sincos(const DRobot& R, double t, doub
 __device__ __forceinline__ double actuation_prenatal_c(const DRobot& R, double t) { return (t >= 0.5 * R.init_cm_time) ? 1.0 : 2 * t / R.init_cm_time; }
 
 // ------------------------------------------------------------------------------------- per-robot step control
-struct StepCtl { int go, latch, eol, rebuild; };
+struct StepCtl { int go, latch, eol, rebuild, trace, trace_index; };
 
 // Executed by ONE thread per robot before every step (and once after the last): completes the previous step's
 // accounting, evaluates the stop condition and decides what this step needs.  Two parts: step_control_begin needs
 // nothing of the previous step's voxel phase; step_control_horizon consumes its MaxVoxVel.
 __device__ __forceinline__ StepCtl step_control_begin(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step)
 {
-    StepCtl c; c.go = c.latch = c.eol = c.rebuild = 0;
+    StepCtl c; c.go = c.latch = c.eol = c.rebuild = c.trace = c.trace_index = 0;
     if (rs.status != 0) return c;
     if (rs.active) {                         // finish the step the previous round computed
         if (rs.diverged) rs.status = 2;
-        else { rs.cur_time += R.dt; rs.steps += 1; rs.dt_prev = R.dt; }
+        else {
+            rs.cur_time += R.dt; rs.steps += 1; rs.dt_prev = R.dt;
+            // UpdateStats of that step (VX_Sim.cpp:1537-1547): a point of the centre-of-mass trace is due; the pass that latches
+            // IniCM computes it from the poses the step left (also when the robot stops now: c.go stays 0, c.trace is set)
+            if (R.trace_dt > 0 && rs.cur_time > R.init_cm_time && (rs.ntrace == 0 || rs.last_trace_time + R.trace_dt <= rs.cur_time)) {
+                if (rs.ntrace < R.trace_cap) { c.trace = 1; c.trace_index = rs.ntrace; }
+                rs.ntrace += 1; rs.last_trace_time = rs.cur_time;
+            }
+        }
         rs.active = 0;
     }
     if (rs.status != 0) return c;
@@ -665,7 +673,8 @@ struct PoseFromState {     // streaming path: the state planes, buffer `cur`
 // IniCM latch (= SS.CurCM of the previous step: mass-weighted SEQUENTIAL sum in voxel order, GetCM VX_Sim.cpp:2415-2430)
 // and EndOfLifetimePosteriorY (getPosteriorY :2640-2656).  Whole workgroup; `sh` holds 5*CH doubles of LDS scratch.
 template <class Pose>
-__device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobotState& rs, const Pose& pose, bool latch, bool eol, double* sh, int CH)
+__device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobotState& rs, const Pose& pose, bool latch, bool eol, double* sh, int CH,
+                                         bool trace = false, int trace_index = 0)
 {
     // The sums keep the reference's order (one thread adds voxel after voxel), but only the additions are serial: the products
     // x * m are formed by the staging threads (the same single rounding), and the y / lat of getPosteriorY is taken once, of the
@@ -695,6 +704,11 @@ __device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobo
     if (tid == 0) {
         if (latch) { const double inv = 1.0 / sm; rs.ini_cm[0] = inv * sx; rs.ini_cm[1] = inv * sy; rs.ini_cm[2] = inv * sz; rs.cm_init = 1; }
         if (eol) { const double q = miny / R.lat; rs.eol_post_y = q < 100000.0 ? q : 100000.0; }
+        if (trace) {                         // SS.CMTraceTime / SS.CMTrace: (CurTime, GetCM()) of the step just finished
+            const double inv = 1.0 / sm;
+            double* e = B.trace + (size_t)(R.trace_begin + trace_index) * 4;
+            e[0] = rs.cur_time; e[1] = inv * sx; e[2] = inv * sy; e[3] = inv * sz;
+        }
     }
 }
 
@@ -773,15 +787,14 @@ __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap
     const DRobot& R = B.robot[r];
     DRobotState& rs = B.rstate[r];
     __shared__ double sh[5 * 256];
-    __shared__ int s_go, s_latch, s_eol;
+    __shared__ int s_go, s_latch, s_eol, s_trace, s_tidx;
     if (threadIdx.x == 0) {
         StepCtl c = step_control(R, rs, step_cap, begin_new_step);
-        s_go = c.go; s_latch = c.latch; s_eol = c.eol;
+        s_go = c.go; s_latch = c.latch; s_eol = c.eol; s_trace = c.trace; s_tidx = c.trace_index;
         if (c.go) actuation_sincos(R, rs.cur_time, rs.act_sin, rs.act_cos);
     }
     __syncthreads();
-    if (!s_go) return;
-    if (s_latch || s_eol) latch_cm(B, R, rs, PoseFromState{B, rs.steps & 1}, s_latch != 0, s_eol != 0, sh, 256);
+    if (s_latch || s_eol || s_trace) latch_cm(B, R, rs, PoseFromState{B, rs.steps & 1}, s_latch != 0, s_eol != 0, sh, 256, s_trace != 0, s_tidx);
 }
 
 template <int A>

@@ -64,7 +64,7 @@ __device__ __forceinline__ void st_plane(double* base, unsigned plane, unsigned 
 // IniCM latch + EndOfLifetimePosteriorY from the pose tile (see latch_cm in kernels.hpp for the reference lines)
 template <int BLOCK>
 __device__ __forceinline__ void fused_latch_cm(const DRobot& R, DRobotState& rs, const double* ps, double* sh, bool valid,
-                                               const DVoxClass& C, bool latch, bool eol)
+                                               const DVoxClass& C, bool latch, bool eol, bool trace, double* trace_entry)
 {
     const int tid = threadIdx.x;
     if (valid) sh[tid] = (C.mat == 5) ? -C.mass : C.mass;      // sign marks the material excluded from PosteriorY
@@ -78,6 +78,7 @@ __device__ __forceinline__ void fused_latch_cm(const DRobot& R, DRobotState& rs,
         }
         if (latch) { const double inv = 1.0 / sm; rs.ini_cm[0] = inv * sx; rs.ini_cm[1] = inv * sy; rs.ini_cm[2] = inv * sz; rs.cm_init = 1; }
         if (eol) rs.eol_post_y = miny;
+        if (trace) { const double inv = 1.0 / sm; trace_entry[0] = rs.cur_time; trace_entry[1] = inv * sx; trace_entry[2] = inv * sy; trace_entry[3] = inv * sz; }   // SS.CMTrace (VX_Sim.cpp:1537-1547)
     }
     __syncthreads();
 }
@@ -403,12 +404,12 @@ __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, co
     if (has) fused_accumulate<BLOCK, A == 0 && NACC == 2>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
 }
 
-struct FusedCtl { double time, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild, damp_on, pad; };
+struct FusedCtl { double time, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild, damp_on, trace, trace_index, pad; };
 
 __device__ __forceinline__ void fused_control_begin(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step, FusedCtl& K)
 {
     const StepCtl c = step_control_begin(R, rs, step_cap, begin_new_step);
-    K.go = c.go; K.latch = c.latch; K.eol = c.eol; K.rebuild = 0;
+    K.go = c.go; K.latch = c.latch; K.eol = c.eol; K.rebuild = 0; K.trace = c.trace; K.trace_index = c.trace_index;
     K.time = rs.cur_time; K.damp_on = rs.dt_prev != 0;
     K.prenatal_c = actuation_prenatal_c(R, rs.cur_time);
     K.act_sin = K.act_cos = 0;
@@ -416,7 +417,7 @@ __device__ __forceinline__ void fused_control_begin(const DRobot& R, DRobotState
 }
 __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K, double dt_prev)
 {
-    StepCtl c; c.go = K.go; c.latch = c.eol = c.rebuild = 0;
+    StepCtl c; c.go = K.go; c.latch = c.eol = c.rebuild = c.trace = c.trace_index = 0;
     step_control_horizon(R, rs, c, dt_prev);
     K.rebuild = c.rebuild;
 }
@@ -517,13 +518,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     for (int it = 0;; ++it) {
         const FusedCtl& K = s_ctl[it & 1];
         FusedCtl& Knext = s_ctl[(it + 1) & 1];
-        if (!K.go) break;
+        if (!K.go && !K.trace) break;
         // opaque per-step copies: keeps the compiler from hoisting every address of the step out of the loop (dozens of
         // loop-invariant 64-bit pointers, which it then spills)
         int vv = v, rowv = row;
         asm volatile("" : "+v"(vv), "+v"(rowv));
         bool scratch_used = false;            // latch / broad-phase borrow the accumulator tile
-        if (K.latch || K.eol) { fused_latch_cm<BLOCK>(R, rs, ps, acc, valid, C, K.latch != 0, K.eol != 0); scratch_used = true; }
+        if (K.latch || K.eol || K.trace) {
+            fused_latch_cm<BLOCK>(R, rs, ps, acc, valid, C, K.latch != 0, K.eol != 0, K.trace != 0, B.trace + (size_t)(R.trace_begin + K.trace_index) * 4);
+            scratch_used = true;
+        }
+        if (!K.go) break;                      // (the robot has stopped; the last step's trace point, if one was due, is in)
         if (K.rebuild) { fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct); scratch_used = true; }
         if (scratch_used) { acc[tid] = 0.0; __syncthreads(); }
         // the partner count only changes when the broad-phase ran; no global load sits at the head of the step's queue

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         const bool go = K.go != 0;
         // does this step's voxel phase run ahead of the per-robot barrier?  Not when a whole-robot pass is known to come (latch),
         // not at the end of the launch (the control block written back needs the reduced max |v|^2)
-        const bool speculate = can_speculate && go && !K.latch && !K.eol;
+        const bool speculate = can_speculate && go && !K.latch && !K.eol && !K.trace;
         int spins = 0;
         // the service wavefront requests the robot's max-|v|^2 words at once (tiles lane, lane + 64, ...)
         unsigned long long mg[2 * MVC];
@@ -614,12 +614,13 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         if (!speculate) {
             if (s_abort) break;
             if (s_divprev) break;              // (undone below)
-            if (!go) break;
-            // ---- whole-robot passes (rare): IniCM latch by the robot's first tile (the others only note that it happened), broad-phase
-            if (K.latch || K.eol) {
-                if (ti == T.tile0) latch_cm(B, R, rs, pose, K.latch != 0, K.eol != 0, sc, VXH_TILE_CH);
+            // ---- whole-robot passes (rare): IniCM latch / a point of the CoM trace by the robot's first tile (the others only note that
+            // it happened), broad-phase
+            if (K.latch || K.eol || K.trace) {
+                if (ti == T.tile0) latch_cm(B, R, rs, pose, K.latch != 0, K.eol != 0, sc, VXH_TILE_CH, K.trace != 0, K.trace_index);
                 else if (tid == 0) { if (K.latch) rs.cm_init = 1; if (K.eol) rs.eol_post_y = 1.0; }
             }
+            if (!go) break;
             if (K.rebuild) {
                 ccnt = tile_rebuild(B, R, rs, ti, pose, ps, np, my_ord, xh, &s_xhn, s_box, sc, hkey, hval);
                 codes_live = true;
@@ -784,7 +785,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             g.ini_cm[0] = out.ini_cm[0]; g.ini_cm[1] = out.ini_cm[1]; g.ini_cm[2] = out.ini_cm[2];
             g.eol_post_y = out.eol_post_y; g.act_sin = out.act_sin; g.act_cos = out.act_cos; g.maxvel2_bits = out.maxvel2_bits;
             g.steps = out.steps; g.status = out.status; g.cm_init = out.cm_init; g.active = out.active; g.diverged = out.diverged;
-            g.rebuild_now = out.rebuild_now; g.rebuilds = out.rebuilds; g.col_tiled = out.col_tiled;
+            g.rebuild_now = out.rebuild_now; g.rebuilds = out.rebuilds; g.col_tiled = out.col_tiled; g.ntrace = out.ntrace; g.last_trace_time = out.last_trace_time;
         }
     }
 }

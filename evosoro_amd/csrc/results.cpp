@@ -131,7 +131,9 @@ void tag(std::string& out, const char* name, double value)
 }
 }  // namespace
 
-std::string result_xml(const RobotModel& M, const vxh_result& r)
+const std::vector<double>& empty_trace() { static const std::vector<double> none; return none; }
+
+std::string result_xml(const RobotModel& M, const vxh_result& r, const std::vector<double>& cm_trace)
 {
     std::string out = "<?xml version=\"1.0\" ?>\n<Voxelyze_Sim_Result Version=\"1.0\">\n    <Fitness>\n";
     if (M.vxa.variant == 0) {
@@ -166,7 +168,22 @@ std::string result_xml(const RobotModel& M, const vxh_result& r)
         tag(out, "ShapeComplexityStart", -1);
         tag(out, "ShapeComplexityEnd", -1);
     }
-    out += "    </Fitness>\n</Voxelyze_Sim_Result>\n";
+    out += "    </Fitness>\n";
+    if (M.vxa.variant == 0 && M.vxa.time_between_traces > 0 && M.vxa.save_traces) {     // VX_SimGA.cpp:170-184
+        out += "    <CMTrace>\n";
+        static const char* names[4] = {"Time", "TraceX", "TraceY", "TraceZ"};
+        for (size_t i = 0; i + 3 < cm_trace.size(); i += 4) {
+            out += "        <TraceStep>\n";
+            for (int k = 0; k < 4; ++k) {
+                char buf[64];
+                std::snprintf(buf, sizeof(buf), "%g", cm_trace[i + k]);
+                out += "            <"; out += names[k]; out += ">"; out += buf; out += "</"; out += names[k]; out += ">\n";
+            }
+            out += "        </TraceStep>\n";
+        }
+        out += "    </CMTrace>\n";
+    }
+    out += "</Voxelyze_Sim_Result>\n";
     return out;
 }
 

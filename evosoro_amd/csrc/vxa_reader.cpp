@@ -258,6 +258,10 @@ VxaModel read_vxa(const char* data, size_t len, int variant)
     m.growth_amplitude = num(env, "GrowthAmplitude", 0);
     m.min_growth_time = num(env, "MinGrowthTime", 0);
     m.sticky_floor = flag(env, "StickyFloor", false);
+    if (variant == 0) {                   // (the land_water simulator has no traces: the tags are unknown to it)
+        m.time_between_traces = num(env, "TimeBetweenTraces", 0);
+        m.save_traces = flag(env, "SaveTraces", false);
+    }
     m.fluid_env = flag(env, "FluidEnvironment", false);
     m.aggregate_drag_coef = num(env, "AggregateDragCoefficient", 0);
     if (variant == 0) {

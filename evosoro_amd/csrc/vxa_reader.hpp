@@ -44,6 +44,8 @@ struct VxaModel {
     double grav_acc = -9.81, temp_amplitude = 0, temp_base = 25, temp_period = 0.1;
     double growth_amplitude = 0, min_growth_time = 0;
     bool sticky_floor = false;
+    double time_between_traces = 0;       // <TimeBetweenTraces> (VX_Environment.cpp:215), _voxcad: a point of the CoM trace at most this often
+    bool save_traces = false;             // <SaveTraces> (:214): the trace is printed into the result file
     bool fluid_env = false;
     double aggregate_drag_coef = 0;
     // VXC

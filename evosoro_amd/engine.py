@@ -18,7 +18,7 @@ ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW =
 
 EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
-           "vxh_fitness_file_name", "vxh_get_state", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
+           "vxh_fitness_file_name", "vxh_get_state", "vxh_get_cm_trace", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version"]
 
 
@@ -117,6 +117,7 @@ def load_library():
     lib.vxh_fitness_file_name.argtypes = [P, I, ctypes.c_char_p, ctypes.c_size_t]
     lib.vxh_get_state.argtypes = [P, I, P, I]
     lib.vxh_get_counters.argtypes = [P, ctypes.POINTER(VxhCounters)]
+    lib.vxh_get_cm_trace.argtypes = [P, I, P, I, ctypes.POINTER(I)]
     lib.vxh_count_bond_modes.argtypes = [P, ctypes.POINTER(LL), ctypes.POINTER(LL)]
     lib.vxh_set_option.argtypes = [P, ctypes.c_char_p, D]
     lib.vxh_strerror.argtypes = [I]
@@ -256,6 +257,14 @@ class Engine(object):
         out = VxhCounters()
         self._check(self._lib.vxh_get_counters(self._h, ctypes.byref(out)))
         return out
+
+    def cm_trace(self, robot):
+        """[n, 4] (time, x, y, z): the centre-of-mass trace of a robot with <TimeBetweenTraces> > 0"""
+        count = ctypes.c_int()
+        self._check(self._lib.vxh_get_cm_trace(self._h, robot, None, 0, ctypes.byref(count)))
+        out = np.zeros((max(count.value, 1), 4), dtype=np.float64)
+        self._check(self._lib.vxh_get_cm_trace(self._h, robot, out.ctypes.data, count.value, ctypes.byref(count)))
+        return out[:count.value]
 
     def bond_modes(self):
         """(bonds in the large-angle branch, bonds) of the whole batch right now"""

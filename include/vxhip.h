@@ -133,6 +133,10 @@ int  vxh_write_result_xml(const vxh_engine* e, int robot, const char* path_or_nu
 int  vxh_fitness_file_name(const vxh_engine* e, int robot, char* buf, size_t cap);
 /* per voxel 14 doubles: pos3, quat(w,x,y,z), scale, vel3, angvel3; capacity in voxels */
 int  vxh_get_state(const vxh_engine* e, int robot, double* out14n, int capacity);
+/* the centre-of-mass trace of a _voxcad robot whose .vxa sets <TimeBetweenTraces> > 0 (SS.CMTraceTime / SS.CMTrace, VX/VX_Sim.cpp:1537-1547;
+ * recorded on the device at the end of the step in which it falls due): per point 4 doubles (time, x, y, z); count_out = points
+ * recorded (may exceed capacity).  With <SaveTraces> the result XML carries the same points as <CMTrace> (VX/VX_SimGA.cpp:170-184). */
+int  vxh_get_cm_trace(const vxh_engine* e, int robot, double* out4n, int capacity, int* count_out);
 int  vxh_get_counters(const vxh_engine* e, vxh_counters* out);
 /* how many internal bonds of the batch are currently in the large-angle branch of CVXS_BondInternal::CalcLinForce
  * (VX/VXS_BondInternal.cpp:72-126, the SmallAngle flag): the two branches differ 2.5x in arithmetic, so a throughput figure

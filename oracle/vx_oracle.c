@@ -146,6 +146,8 @@ struct vxo_sim {
     double max_vox_vel; v3 cur_cm, ini_cm; double end_of_life_posterior_y;
     /* LW fluid drag mesh (LW/VX_MeshUtil.cpp:110-276) */
     int nmv, nmf; struct mvert* mv; struct mfacet* mf;
+    /* SS.CMTraceTime / SS.CMTrace (VX_Sim.cpp:1537-1547) */
+    int ntrace, captrace; double* trace;
 };
 
 static double bond_E(double E1, double E2) { return (E1 * E2 / (E1 + E2)) * 2; }    /* VX/VX_Bond.cpp:87 */
@@ -701,6 +703,13 @@ static int time_step(vxo_sim* s)
     s->steps++;
     /* UpdateStats: CoM and (collisions only) max velocity */
     s->cur_cm = get_cm(s);
+    if (s->m.variant == 0 && s->m.time_between_traces > 0 && s->cur_time > s->m.init_cm_time) {     /* VX_Sim.cpp:1537-1547 */
+        if (s->ntrace == 0 || s->trace[4 * (s->ntrace - 1)] + s->m.time_between_traces <= s->cur_time) {
+            if (s->ntrace == s->captrace) { s->captrace = s->captrace ? 2 * s->captrace : 64; s->trace = (double*)realloc(s->trace, sizeof(double) * 4 * s->captrace); }
+            double* e = s->trace + 4 * s->ntrace++;
+            e[0] = s->cur_time; e[1] = s->cur_cm.x; e[2] = s->cur_cm.y; e[3] = s->cur_cm.z;
+        }
+    }
     {
         double mv2 = 0;
         for (int i = 0; i < s->nvox; i++) { double t = vlen2(s->vox[i].vel); if (t > mv2) mv2 = t; }
@@ -866,7 +875,7 @@ void vxo_destroy(vxo_sim* s)
 {
     if (!s) return;
     for (int i = 0; i < s->nvox; i++) { free(s->vox[i].col); free(s->vox[i].near); }
-    free(s->vox); free(s->bond); free(s->surf); free(s->col); free(s->mv); free(s->mf); free(s);
+    free(s->vox); free(s->bond); free(s->surf); free(s->col); free(s->mv); free(s->mf); free(s->trace); free(s);
 }
 
 /* the loop of voxelyzeMain/main.cpp:89-111; a diverged robot would spin forever there, we stop and flag it */
@@ -907,6 +916,12 @@ void vxo_get_state(const vxo_sim* s, double* o)
 void vxo_get_bond_table(const vxo_sim* s, int* v1, int* v2, int* axis)
 {
     for (int i = 0; i < s->nbond; i++) { v1[i] = s->bond[i].v1; v2[i] = s->bond[i].v2; axis[i] = s->bond[i].axis; }
+}
+
+int vxo_get_cm_trace(const vxo_sim* s, double* out4n, int capacity)
+{
+    for (int i = 0; i < s->ntrace && i < capacity; i++) memcpy(out4n + 4 * i, s->trace + 4 * i, 4 * sizeof(double));
+    return s->ntrace;
 }
 
 double vxo_alg_bytes_per_step(const vxo_sim* s) { return 224.0 * s->nvox + 144.0 * s->nbond; }

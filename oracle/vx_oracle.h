@@ -54,6 +54,8 @@ typedef struct vxo_model {
     int sticky_floor;
     /* land_water only */
     int fluid_env; double aggregate_drag_coef;
+    /* _voxcad only: centre-of-mass trace (<TimeBetweenTraces>, VX_Environment.cpp:215; recorded in UpdateStats, VX_Sim.cpp:1537-1547) */
+    double time_between_traces;
 } vxo_model;
 
 typedef struct vxo_info {
@@ -84,6 +86,7 @@ void     vxo_get_info(const vxo_sim* s, vxo_info* out);
 void     vxo_get_state(const vxo_sim* s, double* out14n); /* per voxel: pos3, quat wxyz, scale, vel3, angvel3 */
 void     vxo_get_bond_table(const vxo_sim* s, int* vox1, int* vox2, int* axis);
 void     vxo_get_result(const vxo_sim* s, vxo_result* out);
+int      vxo_get_cm_trace(const vxo_sim* s, double* out4n, int capacity); /* (time, x, y, z) per entry; returns the number recorded */
 double   vxo_alg_bytes_per_step(const vxo_sim* s); /* 224*nvox + 144*nbond, SURVEY.md 8(d) */
 
 #ifdef __cplusplus

@@ -43,6 +43,7 @@ class VxoModel(ctypes.Structure):
         ("temp_period", ctypes.c_double), ("vary_temp_enabled", ctypes.c_int),
         ("growth_amplitude", ctypes.c_double), ("min_growth_time", ctypes.c_double), ("sticky_floor", ctypes.c_int),
         ("fluid_env", ctypes.c_int), ("aggregate_drag_coef", ctypes.c_double),
+        ("time_between_traces", ctypes.c_double),
     ]
 
 
@@ -93,6 +94,8 @@ def lib():
         _lib.vxo_get_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_bond_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_result.argtypes = [ctypes.c_void_p, ctypes.POINTER(VxoResult)]
+        _lib.vxo_get_cm_trace.restype = ctypes.c_int
+        _lib.vxo_get_cm_trace.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
         _lib.vxo_alg_bytes_per_step.restype = ctypes.c_double
         _lib.vxo_alg_bytes_per_step.argtypes = [ctypes.c_void_p]
     return _lib
@@ -202,6 +205,8 @@ def parse_vxa(path_or_text, variant=0):
     d["sticky_floor"] = _flag(env, "StickyFloor", 0)
     d["fluid_env"] = _flag(env, "FluidEnvironment", 0)
     d["aggregate_drag_coef"] = _num(env, "AggregateDragCoefficient", 0.0)
+    d["time_between_traces"] = _num(env, "TimeBetweenTraces", 0.0)       # VX_Environment.cpp:214-215
+    d["save_traces"] = _flag(env, "SaveTraces", 0)
 
     # VXC
     lattice = _find(vxc, "Lattice")
@@ -316,6 +321,13 @@ class OracleSim(object):
         out = VxoResult()
         lib().vxo_get_result(self._h, ctypes.byref(out))
         return out
+
+    def cm_trace(self):
+        """[n, 4] (time, x, y, z): SS.CMTraceTime / SS.CMTrace"""
+        n = lib().vxo_get_cm_trace(self._h, None, 0)
+        out = np.zeros((max(n, 1), 4), dtype=np.float64)
+        lib().vxo_get_cm_trace(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n)
+        return out[:n]
 
     def alg_bytes_per_step(self):
         return lib().vxo_alg_bytes_per_step(self._h)

@@ -136,6 +136,13 @@ def cases():
                           env=Env(), ind=workloads.make_individual(40, soft4))
     out["stop3_5"] = dict(variant="land", sim=Sim(dt_frac=0.9, stop_condition=3, simulation_time=1.5, fitness_eval_init_time=0.05),
                           env=Env(), ind=workloads.make_individual(41, soft4))
+    # ---- centre-of-mass trace in the result file (VX_Sim.cpp:1537-1547, VX_SimGA.cpp:170-184): <TimeBetweenTraces> + <SaveTraces>
+    env_t = Env(frequency=5.0, temp_amp=35, time_between_traces=0.02)
+    env_t.add_param("growth_amplitude", 0.3, "<GrowthAmplitude>")
+    env_t.add_param("save_traces", 1, "<SaveTraces>")
+    out["trace4"] = dict(variant="land", sim=Sim(dt_frac=0.8, simulation_time=0.3, fitness_eval_init_time=0.05),
+                         env=env_t, ind=workloads.make_individual(43, workloads.random_material((4, 4, 4), 5, 0.1),
+                                                                  OrderedDict([("<PhaseOffset>", phase)])))
     out["lw_stop3_5"] = dict(variant="lw", sim=Sim(dt_frac=0.9, stop_condition=3, simulation_time=1.5, fitness_eval_init_time=0.05),
                              env=Env(), ind=workloads.make_individual(42, soft4))
     return out
@@ -146,6 +153,10 @@ class _Pop(object):
 
 
 def main():
+    # `make_golden.py --only name,name`: (re)generate just these generated cases and keep everything else as it is
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     work = os.path.join("/tmp", "vx_golden_work")
     shutil.rmtree(work, ignore_errors=True)
     for sub in ("ref", "ours"):
@@ -153,16 +164,22 @@ def main():
             os.makedirs(os.path.join(work, sub, RUN_DIR, d))
     vxa_dir = os.path.join(HERE, "vxa")
     exp_dir = os.path.join(HERE, "expected")
-    shutil.rmtree(vxa_dir, ignore_errors=True)
-    shutil.rmtree(exp_dir, ignore_errors=True)
-    os.makedirs(vxa_dir)
-    os.makedirs(exp_dir)
     manifest = OrderedDict()
+    if only is None:
+        shutil.rmtree(vxa_dir, ignore_errors=True)
+        shutil.rmtree(exp_dir, ignore_errors=True)
+        os.makedirs(vxa_dir)
+        os.makedirs(exp_dir)
+    else:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f, object_pairs_hook=OrderedDict)
     probe = {"land": os.path.join(REPO, "oracle/_ref/vxprobe"), "lw": os.path.join(REPO, "oracle/_ref/vxprobe_lw")}
     refbin = {"land": os.path.join(REPO, "oracle/_ref/voxelyze_ref"),
               "lw": os.path.join(REPO, "oracle/_ref/voxelyze_lw_ref")}
 
     for name, case in cases().items():
+        if only is not None and name not in only:
+            continue
         ind = case["ind"]
         fname = RUN_NAME + "--id_%05i.vxa" % ind.id
         # reference writer (py3: file complete, then TypeError at the md5 update)
@@ -216,6 +233,10 @@ def main():
                           "nvox": int((ind.genotype.to_phenotype_mapping["material"]["state"] > 0).sum())}
         print(name, manifest[name])
 
+    if only is not None:
+        with open(os.path.join(HERE, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1)
+        return
     # input files the reference ships next to its simulator (data, not code); expected values from the reference
     shipped = [("land", "evosoro/_voxcad/voxelyzeMain/Example_withPhaseOffset.vxa", "example_phaseoffset"),
                ("land", "evosoro/_voxcad/voxelyzeMain/Example_1.vxa", "example_1"),

@@ -814,3 +814,47 @@ def test_configs3_whole_batch_full_duration_vs_reference(eng_mod, golden_dir, tm
                              Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.05), env_w,
                              [("normAbsoluteDisplacement", "norm_abs_disp"), ("normDistX", "norm_dist_x"), ("normDistY", "norm_dist_y"),
                               ("normDistZ", "norm_dist_z")])
+
+
+def test_cm_trace_in_the_result_file(eng_mod, golden_dir, tmp_path):
+    """<TimeBetweenTraces> + <SaveTraces> (VX_Sim.cpp:1537-1547, VX_SimGA.cpp:170-184): the trace points are recorded on the device at the
+    end of the step in which they fall due; times equal the reference's, centres of mass within the parity bar; the result XML carries
+    them like the reference's; a robot without the tags in the same batch has none"""
+    import re
+    from oracle import vxoracle as vo
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("steps_per_launch", 100)          # launch boundaries inside the run, also right at trace steps
+        eng.add_vxa_file(os.path.join(golden_dir, "vxa", "trace4.vxa"))
+        eng.add_vxa_file(os.path.join(golden_dir, "vxa", "phase4.vxa"))
+        eng.run()
+        got = eng.cm_trace(0)
+        assert eng.cm_trace(1).shape == (0, 4)
+        sim = vo.OracleSim.from_vxa(os.path.join(golden_dir, "vxa", "trace4.vxa"))
+        sim.step(-1)
+        want = sim.cm_trace()
+        assert got.shape == want.shape == (13, 4)
+        assert np.array_equal(got[:, 0], want[:, 0])                         # the times: CurTime is a sum of identical dt's, bitwise
+        model = vo.parse_vxa(os.path.join(golden_dir, "vxa", "trace4.vxa"))
+        tol = max(FLOOR_VOX, 20 * _spread(model, (1000, 2000, eng.dims(0)["planned_steps"]))[0])
+        assert np.abs(got[:, 1:] - want[:, 1:]).max() / model["lattice_dim"] <= tol
+        out = str(tmp_path / "trace.xml")
+        eng.write_result_xml(0, out)
+        text, ref = open(out).read(), open(os.path.join(golden_dir, "expected", "trace4.xml")).read()
+        assert text.count("<TraceStep>") == ref.count("<TraceStep>") == 13
+        for tag in ("Time", "TraceX", "TraceY", "TraceZ"):
+            a = [float(v) for v in re.findall(r"<%s>(.*?)</%s>" % (tag, tag), text)]
+            b = [float(v) for v in re.findall(r"<%s>(.*?)</%s>" % (tag, tag), ref)]
+            assert np.allclose(a, b, rtol=2e-6, atol=2 * tol * model["lattice_dim"])
+        # same structure as the reference file: <Fitness> block, then <CMTrace>
+        assert re.sub(r">[^<>\n]+<", "><", text) == re.sub(r">[^<>\n]+<", "><", ref)
+        eng.write_result_xml(1, out)
+        assert "<CMTrace>" not in open(out).read()
+    # the streaming kernels record the same trace (k_step_begin, also in the call that only finishes the last step)
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 0)
+        eng.set_option("fused", 0)
+        eng.add_vxa_file(os.path.join(golden_dir, "vxa", "trace4.vxa"))
+        eng.run()
+        streamed = eng.cm_trace(0)
+        assert streamed.shape == (13, 4) and np.array_equal(streamed[:, 0], want[:, 0])
+        assert np.abs(streamed[:, 1:] - want[:, 1:]).max() / model["lattice_dim"] <= tol

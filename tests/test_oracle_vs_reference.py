@@ -120,3 +120,20 @@ def test_empty_and_single_voxel():
     assert (info.nvox, info.nbond) == (1, 0)
     sim.step(-1)
     assert sim.info().status == 1 and np.isfinite(sim.state()).all()
+
+
+def test_cm_trace_equals_the_reference_xml(golden_dir):
+    """<TimeBetweenTraces> + <SaveTraces>: the points of SS.CMTrace (VX_Sim.cpp:1537-1547) as the reference binary printed them"""
+    import re
+    sim = _sim(golden_dir, "trace4")
+    sim.step(-1)
+    trace = sim.cm_trace()
+    xml = open(os.path.join(golden_dir, "expected", "trace4.xml")).read()
+    want = [re.findall(r"<%s>(.*?)</%s>" % (tag, tag), xml) for tag in ("Time", "TraceX", "TraceY", "TraceZ")]
+    assert len(trace) == len(want[0]) == 13
+    for k in range(4):
+        assert ["%g" % v for v in trace[:, k]] == want[k]
+    # without the tag: no trace
+    plain = _sim(golden_dir, "phase4")
+    plain.step(-1)
+    assert len(plain.cm_trace()) == 0
