@@ -145,6 +145,15 @@ int vxh_add_vxa_files(vxh_engine* e, const char* const* paths, int n, int* first
     return rc;
 }
 
+int vxh_add_robots(vxh_engine* e, const char* template_vxa, size_t template_len, const vxh_robot_arrays* robots, int n,
+                   int round_like_text, int* first_index_out)
+{
+    if (!e || !e->impl || !template_vxa || n < 0 || (n > 0 && !robots)) return VXH_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (robots[i].n_layers < 0 || (robots[i].n_layers > 0 && (!robots[i].layer_tags || !robots[i].layers))) return VXH_ERR_ARG;
+    return guarded(e, [&] { int idx = e->impl->add_arrays(template_vxa, template_len, robots, n, round_like_text != 0); if (first_index_out) *first_index_out = idx; });
+}
+
 int vxh_num_robots(const vxh_engine* e) { return (e && e->impl) ? e->impl->num_robots() : VXH_ERR_ARG; }
 
 int vxh_robot_dims(const vxh_engine* e, int robot, int* nvox, int* nbond, double* dt, long long* planned_steps)

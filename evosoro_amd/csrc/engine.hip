@@ -217,6 +217,80 @@ int Engine::add_vxa_files(const std::vector<std::string>& paths)
     return first;
 }
 
+// A generation handed over as arrays (vxh_add_robots): one parsed template + per-robot lattice and layers.  The VxaModel of a robot
+// is exactly what read_vxa builds from the file the writer would have produced: material digits as they are, layer values taken by
+// occupied-voxel counter in file order (VX_Object.cpp:1879-1900), optionally through the writer's decimal text.
+int Engine::add_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* in, int n, bool round_like_text)
+{
+    VxaModel base = read_vxa(template_vxa, len, variant_);
+    if (!base.unsupported.empty()) {
+        std::string msg = "unsupported .vxa feature(s):";
+        for (const auto& u : base.unsupported) msg += " [" + u + "]";
+        throw std::invalid_argument(msg + " in the template");
+    }
+    struct LayerSlot { const char* tag; bool VxaModel::*has; std::vector<double> VxaModel::*values; bool land_only; };
+    static const LayerSlot slots[] = {
+        {"PhaseOffset", &VxaModel::has_phase_offset, &VxaModel::phase_offset, false},
+        {"TempAmpDamp", &VxaModel::has_temp_amp_damp, &VxaModel::temp_amp_damp, false},
+        {"Stiffness", &VxaModel::has_stiffness, &VxaModel::stiffness, false},
+        {"FinalPhaseOffset", &VxaModel::has_final_phase_offset, &VxaModel::final_phase_offset, true},
+        {"FinalTempAmpDamp", &VxaModel::has_final_temp_amp_damp, &VxaModel::final_temp_amp_damp, true},
+        {"InitialVoxelSize", &VxaModel::has_initial_voxel_size, &VxaModel::initial_voxel_size, true},
+        {"FinalVoxelSize", &VxaModel::has_final_voxel_size, &VxaModel::final_voxel_size, true},
+        {"GrowthTime", &VxaModel::has_growth_time, &VxaModel::growth_time, true},
+        {"StartGrowthTime", &VxaModel::has_start_growth_time, &VxaModel::start_growth_time, true},
+    };
+    for (const auto& sl : slots) { base.*(sl.has) = false; (base.*(sl.values)).clear(); }
+    base.structure.clear();
+    std::vector<RobotModel> built(n);
+    std::vector<std::exception_ptr> errors(n);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            try {
+                const vxh_robot_arrays& A = in[i];
+                if (A.nx < 1 || A.ny < 1 || A.nz < 1 || (long long)A.nx * A.ny * A.nz > (1LL << 26) || !A.material) throw std::invalid_argument("bad lattice");
+                VxaModel m = base;
+                m.nx = A.nx; m.ny = A.ny; m.nz = A.nz;
+                const size_t cells = (size_t)A.nx * A.ny * A.nz;
+                m.structure.assign(A.material, A.material + cells);
+                for (size_t k = 0; k < cells; ++k)
+                    if (m.structure[k] >= m.palette.size()) throw std::invalid_argument("material index outside the palette");
+                if (A.fitness_file_name) m.fitness_file_name = A.fitness_file_name;
+                for (int l = 0; l < A.n_layers; ++l) {
+                    const LayerSlot* slot = nullptr;
+                    for (const auto& sl : slots) if (std::strcmp(sl.tag, A.layer_tags[l]) == 0) slot = &sl;
+                    if (!slot) throw std::invalid_argument(std::string("unsupported per-voxel layer <") + A.layer_tags[l] + ">");
+                    if (slot->land_only && variant_ != 0) throw std::invalid_argument(std::string("unsupported <") + A.layer_tags[l] + "> development layer (land_water)");
+                    std::vector<double>& out = m.*(slot->values);
+                    m.*(slot->has) = true;
+                    out.clear();
+                    for (size_t k = 0; k < cells; ++k) {
+                        if (m.structure[k] == 0) continue;
+                        double v = A.layers[l][k];
+                        if (round_like_text) { char buf[48]; std::snprintf(buf, sizeof(buf), "%.12g", v); v = std::atof(buf); }
+                        out.push_back(v);
+                    }
+                }
+                built[i] = build_robot(m);
+            } catch (...) {
+                errors[i] = std::current_exception();
+            }
+        }
+    };
+    const int nthreads = std::max(1, std::min({n, (int)std::thread::hardware_concurrency(), 32}));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    for (int i = 0; i < n; ++i) if (errors[i]) std::rethrow_exception(errors[i]);
+    const int first = (int)robots_.size();
+    for (int i = 0; i < n; ++i) robots_.push_back(std::move(built[i]));
+    prepared_ = false;
+    state_downloaded_ = control_downloaded_ = false;
+    return first;
+}
+
 void Engine::clear()
 {
     HIP_OK(hipSetDevice(device_id_));

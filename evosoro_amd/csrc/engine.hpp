@@ -23,6 +23,7 @@ public:
     ~Engine();
     int add_vxa(const char* data, size_t len);              // returns robot index; throws
     int add_vxa_files(const std::vector<std::string>& paths);   // parse + build on all host cores, append in order; returns first index
+    int add_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text);   // returns first index
     int num_robots() const { return (int)robots_.size(); }
     const RobotModel& robot(int i) const { return robots_[i]; }
     void run();                                // to completion

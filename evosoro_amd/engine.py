@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_num_robots", "vxh_robot_dims",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_cm_trace", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version"]
@@ -67,6 +67,13 @@ class VxhTilingInfo(ctypes.Structure):
                 ("total_bonds", ctypes.c_int)]
 
 
+class VxhRobotArrays(ctypes.Structure):
+    _fields_ = [("nx", ctypes.c_int), ("ny", ctypes.c_int), ("nz", ctypes.c_int),
+                ("material", ctypes.POINTER(ctypes.c_ubyte)), ("n_layers", ctypes.c_int),
+                ("layer_tags", ctypes.POINTER(ctypes.c_char_p)), ("layers", ctypes.POINTER(ctypes.POINTER(ctypes.c_double))),
+                ("fitness_file_name", ctypes.c_char_p)]
+
+
 class VxhError(RuntimeError):
     def __init__(self, status, message):
         RuntimeError.__init__(self, "libvxhip status %d: %s" % (status, message))
@@ -106,6 +113,7 @@ def load_library():
     lib.vxh_add_vxa_file.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(I)]
     lib.vxh_add_vxa_buffer.argtypes = [P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(I)]
     lib.vxh_add_vxa_files.argtypes = [P, ctypes.POINTER(ctypes.c_char_p), I, ctypes.POINTER(I)]
+    lib.vxh_add_robots.argtypes = [P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(VxhRobotArrays), I, I, ctypes.POINTER(I)]
     lib.vxh_num_robots.argtypes = [P]
     lib.vxh_robot_dims.argtypes = [P, I, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(D), ctypes.POINTER(LL)]
     lib.vxh_run.argtypes = [P]
@@ -205,6 +213,29 @@ class Engine(object):
         arr = (ctypes.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
         idx = ctypes.c_int(-1)
         self._check(self._lib.vxh_add_vxa_files(self._h, arr, len(paths), ctypes.byref(idx)))
+        return idx.value
+
+    def add_robots(self, template_text, robots, round_like_text=True):
+        """A generation from arrays (vxh_add_robots).  `robots`: sequence of (material, layers, fitness_file_name) with material an
+        integer array [x, y, z] as the genotype holds it, layers an ordered mapping tag -> float array [x, y, z] (tags with or without
+        angle brackets), fitness_file_name a str or None.  Returns the first robot index."""
+        raw = template_text.encode("latin-1") if isinstance(template_text, str) else template_text
+        n = len(robots)
+        descs = (VxhRobotArrays * max(n, 1))()
+        keep = []                                         # buffers must outlive the call
+        for i, (material, layers, name) in enumerate(robots):
+            mat = np.ascontiguousarray(np.asarray(material).transpose(2, 1, 0), dtype=np.uint8)     # -> z slowest, x fastest
+            tags = (ctypes.c_char_p * max(len(layers), 1))(*[t.strip("<>").encode() for t in layers])
+            arrs = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).transpose(2, 1, 0)) for a in layers.values()]
+            ptrs = (ctypes.POINTER(ctypes.c_double) * max(len(arrs), 1))(*[a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for a in arrs])
+            keep += [mat, tags, arrs, ptrs]
+            d = descs[i]
+            d.nx, d.ny, d.nz = (int(v) for v in np.asarray(material).shape)
+            d.material = mat.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))
+            d.n_layers, d.layer_tags, d.layers = len(arrs), tags, ptrs
+            d.fitness_file_name = None if name is None else os.fsencode(name)
+        idx = ctypes.c_int(-1)
+        self._check(self._lib.vxh_add_robots(self._h, raw, len(raw), descs, n, 1 if round_like_text else 0, ctypes.byref(idx)))
         return idx.value
 
     def add_vxa_text(self, text):

@@ -106,15 +106,18 @@ def gather_records(local_records, local_indices, total, device=None):
     return table
 
 
-def run_shard(engine_module, paths, variant, device_index, options=None, write_xml=True):
-    """Step the given .vxa files as one batch on one GPU; returns (records [n, RECORD_LEN], counters)."""
+def run_shard(engine_module, paths, variant, device_index, options=None, write_xml=True, loader=None):
+    """Step the given .vxa files as one batch on one GPU; returns (records [n, RECORD_LEN], counters).  `loader(eng)`, when given,
+    adds the robots instead (the in-memory hand-off); `paths` then only says how many there are."""
     records = np.zeros((len(paths), RECORD_LEN), dtype=np.float64)
     if not paths:
         return records, None
     with engine_module.Engine(variant, device_index) as eng:
         for key, val in (options or {}).items():
             eng.set_option(key, val)
-        if hasattr(eng, "add_vxa_files"):
+        if loader is not None:
+            loader(eng)
+        elif hasattr(eng, "add_vxa_files"):
             eng.add_vxa_files(list(paths))       # parsed and built on all host cores
         else:
             for path in paths:
@@ -129,12 +132,12 @@ def run_shard(engine_module, paths, variant, device_index, options=None, write_x
     return records, counters
 
 
-def run_population(engine_module, paths, variant=0, costs=None, options=None, write_xml=True, device=None):
+def run_population(engine_module, paths, variant=0, costs=None, options=None, write_xml=True, device=None, make_loader=None):
     """Evaluate every .vxa of a generation; with an initialised process group the files are sharded over ranks.
 
     Returns the full record table (identical on every rank).  `device`: HIP device index of this process; by default the
     launcher's LOCAL_RANK in a multi-GPU job, else torch's current device when torch is loaded and CUDA-initialised, else 0
-    (the single-GPU path needs no torch at all).
+    (the single-GPU path needs no torch at all).  `make_loader(indices)` -> loader(eng): the in-memory hand-off of this rank's robots.
     """
     dist = _dist()
     if dist:
@@ -153,6 +156,7 @@ def run_population(engine_module, paths, variant=0, costs=None, options=None, wr
             device = int(os.environ["LOCAL_RANK"]) % n_dev if n_dev > 0 else 0
         else:
             device = torch.cuda.current_device() if cuda_ready else 0
-    records, _ = run_shard(engine_module, [paths[i] for i in mine], variant, device, options, write_xml)
+    records, _ = run_shard(engine_module, [paths[i] for i in mine], variant, device, options, write_xml,
+                           make_loader(mine) if make_loader else None)
     gather_device = torch.device("cuda", device) if (dist and dist.get_backend() == "nccl") else None
     return gather_records(records, mine, len(paths), gather_device)

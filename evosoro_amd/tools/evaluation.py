@@ -27,7 +27,9 @@ import time
 
 import numpy as np
 
-from evosoro_amd.tools.read_write_voxelyze import read_voxlyze_results, write_voxelyze_file
+import random
+
+from evosoro_amd.tools.read_write_voxelyze import phenotype_arrays, read_voxlyze_results, write_voxelyze_file
 
 
 def _vxa_path(run_directory, run_name, ident):
@@ -72,7 +74,11 @@ def _values_from_record(pop, record, parallel):
 
 
 def evaluate_all(sim, env, pop, print_log, save_vxa_every, run_directory, run_name, max_eval_time=60,
-                 time_to_try_again=10, save_lineages=False, variant=0, engine_module=None, engine_options=None):
+                 time_to_try_again=10, save_lineages=False, variant=0, engine_module=None, engine_options=None, in_memory=None):
+    """in_memory: hand the generation to the engine as arrays (vxh_add_robots) instead of through .vxa files; the files are then
+    only written for the individuals the bookkeeping keeps (champions, lineages, saved generations).  Default (None): whenever that is
+    exact -- no actuation variance (the file would carry per-robot random CTEs), no genotype output driving the environment -- and the
+    engine offers it.  The robots are bit-identical to those the file route builds (tests/test_gpu_parity.py)."""
     start_time = time.time()
     if engine_module is None:
         from evosoro_amd import engine as engine_module   # fails loudly when libvxhip.so / a GPU is missing
@@ -85,9 +91,32 @@ def evaluate_all(sim, env, pop, print_log, save_vxa_every, run_directory, run_na
     distributed = world > 1
     owner = rank == 0
 
+    arrays = {}
+    if in_memory is None or in_memory:
+        possible = env.actuation_variance == 0 and hasattr(engine_module.Engine, "add_robots")
+        if possible:
+            for ind in pop:
+                arrays[ind.id] = phenotype_arrays(ind)
+            possible = all(a is not None for a in arrays.values())
+        if in_memory and not possible:
+            raise ValueError("in_memory=True, but this population needs its .vxa files (actuation variance, environment driven by the genotype)")
+        in_memory = possible
+    template = None
+
+    def ensure_file(ind):
+        """the individual's .vxa, written now if the in-memory route skipped it (without touching the global random stream again)"""
+        if in_memory and not os.path.exists(_vxa_path(run_directory, run_name, ind.id)):
+            state = random.getstate()
+            write_voxelyze_file(sim, env, ind, run_directory, run_name)
+            random.setstate(state)
+
     pending = []
     for ind in pop:
-        ind.md5 = write_voxelyze_file(sim, env, ind, run_directory, run_name, write=owner)
+        if in_memory:
+            ind.md5, text = write_voxelyze_file(sim, env, ind, run_directory, run_name, write=False, want_text=True)
+            template = template or text
+        else:
+            ind.md5 = write_voxelyze_file(sim, env, ind, run_directory, run_name, write=owner)
         if not ind.phenotype.is_valid():
             for _, goal in pop.objective_dict.items():
                 if goal["name"] != "age":
@@ -98,6 +127,7 @@ def evaluate_all(sim, env, pop, print_log, save_vxa_every, run_directory, run_na
                 if goal["tag"] is not None:
                     setattr(ind, goal["name"], pop.already_evaluated[ind.md5][obj_rank])
             if owner and save_vxa_every > 0 and pop.gen % save_vxa_every == 0:
+                ensure_file(ind)
                 shutil.copy(_vxa_path(run_directory, run_name, ind.id),
                             run_directory + "/Gen_%04i/" % pop.gen + run_name +
                             "--Gen_%04i--fit_%.08f--id_%05i.vxa" % (pop.gen, ind.fitness, ind.id))
@@ -111,12 +141,18 @@ def evaluate_all(sim, env, pop, print_log, save_vxa_every, run_directory, run_na
     if pending:
         if owner:
             os.makedirs(run_directory + "/fitnessFiles", exist_ok=True)
-        if distributed:
+        if distributed and not in_memory:
             parallel.barrier()                 # the files of the generation are complete before any rank opens them
         paths = [_vxa_path(run_directory, run_name, ind.id) for ind in pending]
+
+        def make_loader(indices):
+            def loader(eng):
+                eng.add_robots(template, [(arrays[pending[i].id][0], arrays[pending[i].id][1],
+                                           run_directory + "/fitnessFiles/softbotsOutput--id_%05i.xml" % pending[i].id) for i in indices])
+            return loader
         table = parallel.run_population(engine_module, paths, variant=variant,
                                         costs=[_estimated_cost(ind) for ind in pending], options=engine_options,
-                                        write_xml=not distributed)
+                                        write_xml=not distributed, make_loader=make_loader if in_memory else None)
     num_finished = 0
     for k, ind in enumerate(pending):
         status = int(table[k, 0])
@@ -149,18 +185,21 @@ def evaluate_all(sim, env, pop, print_log, save_vxa_every, run_directory, run_na
         if champion:
             pop.best_fit_so_far = ind.fitness
         if owner:
+            keep = save_vxa_every > 0 and pop.gen % save_vxa_every == 0
+            if champion or save_lineages or keep:
+                ensure_file(ind)
             if champion:
                 shutil.copy(vxa, run_directory + "/bestSoFar/fitOnly/" + stamped)
             if save_lineages:
                 shutil.copy(vxa, run_directory + "/ancestors/")
-            if save_vxa_every > 0 and pop.gen % save_vxa_every == 0:
+            if keep:
                 shutil.move(vxa, run_directory + "/Gen_%04i/" % pop.gen + stamped)
-            else:
+            elif os.path.exists(vxa):
                 os.remove(vxa)
     if owner:
         # robots that did not finish leave their .vxa behind in the reference too (it times out and moves on); nothing else to do
         pass
-    if distributed and pending:
+    if distributed and pending and not in_memory:
         parallel.barrier()                     # rank 0 has finished with the files before any rank starts the next generation
 
     if num_finished < len(pending):

@@ -162,13 +162,14 @@ def _vxc_header_lines(env, size_xyz):
     return text + "".join(_IND + line + "\n" for line in tail)
 
 
-def write_voxelyze_file(sim, env, individual, run_directory, run_name, write=True):
+def write_voxelyze_file(sim, env, individual, run_directory, run_name, write=True, want_text=False):
     """Serialise one individual to `<run_directory>/voxelyzeFiles/<run_name>--id_%05i.vxa`.
 
     Returns the md5 hex digest of the concatenated per-voxel output strings, which evaluate_all uses as
     its evaluation-cache key (reference :362,390,404-407).  `write=False` (ranks other than 0 of a multi-GPU
     job, which share the run directory) does everything but touch the file: the environment attributes driven by
-    the genotype are set and the global `random` stream advances exactly as on the writing rank.
+    the genotype are set and the global `random` stream advances exactly as on the writing rank.  `want_text=True` returns
+    (md5, text of the file).
     """
     mapping = individual.genotype.to_phenotype_mapping
     size = individual.genotype.orig_size_xyz
@@ -242,4 +243,31 @@ def write_voxelyze_file(sim, env, individual, run_directory, run_name, write=Tru
     if write:
         with open(path, "w") as handle:
             handle.write("".join(out))
-    return hashlib.md5("".join(md5_text).encode()).hexdigest()
+    digest = hashlib.md5("".join(md5_text).encode()).hexdigest()
+    if want_text:
+        return digest, "".join(out)
+    return digest
+
+
+def phenotype_arrays(individual):
+    """What the .vxa would carry about the individual's body, as arrays (the in-memory hand-off, evosoro_amd.engine.Engine.add_robots):
+    (material [x, y, z] ints, OrderedDict tag -> float array [x, y, z]) -- or None when an output of the genotype drives an
+    environment attribute (then every individual has its own <Environment> and only the file says which)."""
+    from collections import OrderedDict
+    mapping = individual.genotype.to_phenotype_mapping
+    size = individual.genotype.orig_size_xyz
+    material, layers = None, OrderedDict()
+    for _, details in mapping.items():
+        if details["env_kws"] is not None or details["params"] is not None:
+            return None
+        state = np.asarray(details["state"])
+        if details["tag"] == "<Data>":
+            material = state.astype(np.int64)           # int(x) truncates towards zero, like astype
+            if material.size and (material.min() < 0 or material.max() > 9):
+                return None
+        else:
+            values = state.astype(np.int64).astype(np.float64) if details["output_type"] is int else state.astype(np.float64)
+            layers[details["tag"]] = values
+    if material is None:
+        material = np.full(size, 3, dtype=np.int64)     # morphology not evolved: a full box of material 3 (reference :361-370)
+    return material, layers

@@ -120,6 +120,24 @@ int  vxh_add_vxa_buffer(vxh_engine* e, const char* xml, size_t len, int* robot_i
 /* A whole generation at once (the files evaluate_all wrote, evosoro/tools/evaluation.py:62,89): read, parsed and built on
  * all host cores, appended in the order given; on error nothing is appended and the first failing file is reported. */
 int  vxh_add_vxa_files(vxh_engine* e, const char* const* paths, int n, int* first_index_out);
+/* In-memory hand-off of a generation (replaces, for the robots of one generation, evaluation.py:59-62 + read_write_voxelyze.py:345-399:
+ * per-voxel state arrays -> text -> file -> parser): the <Simulator>, <Environment> and <Palette> of the generation come from ONE
+ * .vxa text (`template_vxa`: the file of any individual of the generation; its <Structure> data are ignored), every robot's lattice
+ * and per-voxel layers from arrays in the order the writer prints them (z slowest, then y, x fastest).  Layer tags as in the file:
+ * "PhaseOffset", "TempAmpDamp", "Stiffness", "FinalPhaseOffset", "FinalTempAmpDamp", "InitialVoxelSize", "FinalVoxelSize",
+ * "GrowthTime", "StartGrowthTime".  round_like_text != 0: every layer value goes through the decimal text the Python-2 writer would
+ * have printed ("%.12g") and back, so the robot is bit-identical to the one the file route builds.  Robots are built on all host
+ * cores and appended in order; on error nothing is appended. */
+typedef struct vxh_robot_arrays {
+    int nx, ny, nz;
+    const unsigned char* material;         /* [nz*ny*nx] palette indices 0..n, 0 = empty: the digits of <Data> */
+    int n_layers;
+    const char* const* layer_tags;         /* [n_layers] */
+    const double* const* layers;           /* [n_layers] pointers to [nz*ny*nx] doubles */
+    const char* fitness_file_name;         /* <FitnessFileName> of this robot, or NULL */
+} vxh_robot_arrays;
+int  vxh_add_robots(vxh_engine* e, const char* template_vxa, size_t template_len, const vxh_robot_arrays* robots, int n,
+                    int round_like_text, int* first_index_out);
 int  vxh_num_robots(const vxh_engine* e);
 int  vxh_robot_dims(const vxh_engine* e, int robot, int* nvox, int* nbond, double* dt, long long* planned_steps);
 

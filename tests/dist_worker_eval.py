@@ -17,7 +17,7 @@ from test_evaluation import Log, make_pop  # noqa: E402
 
 
 def main():
-    run = sys.argv[1]
+    run, in_memory = sys.argv[1], sys.argv[2] == "memory"
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     sim = Sim(dt_frac=0.9, simulation_time=0.06, fitness_eval_init_time=0.02)
@@ -26,14 +26,14 @@ def main():
     inds.append(workloads.make_individual(5, np.zeros((4, 4, 4), dtype=int)))        # invalid phenotype
     pop = make_pop(inds)
     log = Log()
-    evaluate_all(sim, env, pop, log, save_vxa_every=1, run_directory=run, run_name="D", engine_module=stub_engine)
+    evaluate_all(sim, env, pop, log, save_vxa_every=1, run_directory=run, run_name="D", engine_module=stub_engine, in_memory=in_memory)
     # second generation: two clones of evaluated robots (md5 cache) and a new one
     inds2 = [workloads.random_robot(10, (4, 4, 4), 50, 0.2), workloads.random_robot(11, (4, 4, 4), 99, 0.2)]
     pop2 = make_pop(inds2)
     pop2.gen = 1
     pop2.already_evaluated, pop2.best_fit_so_far = pop.already_evaluated, pop.best_fit_so_far
     pop2.total_evaluations, pop2.all_evaluated_individuals_ids = pop.total_evaluations, pop.all_evaluated_individuals_ids
-    evaluate_all(sim, env, pop2, log, save_vxa_every=0, run_directory=run, run_name="D", engine_module=stub_engine)
+    evaluate_all(sim, env, pop2, log, save_vxa_every=0, run_directory=run, run_name="D", engine_module=stub_engine, in_memory=in_memory)
     out = {"fitness": [ind.fitness for ind in list(pop) + list(pop2)], "md5": [ind.md5 for ind in list(pop) + list(pop2)],
            "best": pop2.best_fit_so_far, "total": pop2.total_evaluations, "ids": pop2.all_evaluated_individuals_ids,
            "cache": sorted(pop2.already_evaluated), "warnings": [l for l in log.lines if "WARNING" in l]}

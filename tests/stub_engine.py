@@ -45,6 +45,33 @@ class Engine(object):
         self.sims.append(vo.OracleSim(self.models[-1]))
         return len(self.sims) - 1
 
+    def add_robots(self, template_text, robots, round_like_text=True):
+        """the in-memory hand-off (evosoro_amd.engine.Engine.add_robots) on the oracle's data model: simulator / environment / palette
+        from the template, lattice and layers from the arrays, values through the writer's decimal text"""
+        import tempfile
+        import numpy as np
+        with tempfile.NamedTemporaryFile("w", suffix=".vxa", delete=False) as f:
+            f.write(template_text)
+        base = vo.parse_vxa(f.name, self.variant)
+        os.remove(f.name)
+        keys = dict([("PhaseOffset", "phase_offset"), ("TempAmpDamp", "temp_amp_damp"), ("Stiffness", "stiffness")] + list(vo.DEV_LAYERS))
+        first = len(self.sims)
+        for material, layers, name in robots:
+            model = dict(base)
+            cells = np.ascontiguousarray(np.asarray(material).transpose(2, 1, 0)).reshape(-1).astype(np.uint8)
+            model["nx"], model["ny"], model["nz"] = (int(v) for v in np.asarray(material).shape)
+            model["structure"], model["nvox"] = cells, int((cells > 0).sum())
+            for key in keys.values():
+                model[key] = None
+            for tag, arr in layers.items():
+                flat = np.asarray(arr, dtype=np.float64).transpose(2, 1, 0).reshape(-1)[cells > 0]
+                model[keys[tag.strip("<>")]] = np.array([float("%.12g" % v) for v in flat]) if round_like_text else flat.copy()
+            if name is not None:
+                model["fitness_file_name"] = name
+            self.models.append(model)
+            self.sims.append(vo.OracleSim(model))
+        return first
+
     def run(self):
         for sim in self.sims:
             sim.step(-1)

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import stub_engine
 from evosoro_amd import workloads
@@ -41,7 +42,8 @@ def make_pop(inds):
     return pop
 
 
-def test_evaluate_all_contract(tmp_path, golden_dir):
+@pytest.mark.parametrize("in_memory", [False, True])
+def test_evaluate_all_contract(tmp_path, golden_dir, in_memory):
     run = str(tmp_path / "run")
     for d in ("voxelyzeFiles", "fitnessFiles", "tempFiles", "bestSoFar/fitOnly", "ancestors", "Gen_0000"):
         os.makedirs(os.path.join(run, d))
@@ -52,7 +54,7 @@ def test_evaluate_all_contract(tmp_path, golden_dir):
     invalid = workloads.make_individual(12, np.zeros((6, 6, 6), dtype=int))
     pop = make_pop([a, invalid])
     log = Log()
-    evaluate_all(sim, env, pop, log, save_vxa_every=1, run_directory=run, run_name="T", engine_module=stub_engine)
+    evaluate_all(sim, env, pop, log, save_vxa_every=1, run_directory=run, run_name="T", engine_module=stub_engine, in_memory=in_memory)
     want = vo.read_result_xml(os.path.join(golden_dir, "expected", "rand6_col.xml"))["NormFinalDist"]
     assert a.fitness == want                                  # 6-digit value parsed from the XML, like the reference
     assert a.num_voxels == 151 and a.md5 in pop.already_evaluated
@@ -67,12 +69,13 @@ def test_evaluate_all_contract(tmp_path, golden_dir):
     pop2 = make_pop([b])
     pop2.already_evaluated, pop2.best_fit_so_far = pop.already_evaluated, pop.best_fit_so_far
     evaluate_all(sim, env, pop2, log, save_vxa_every=0, run_directory=run, run_name="T", engine_module=stub_engine,
-                 save_lineages=True)
+                 save_lineages=True, in_memory=in_memory)
     assert b.fitness == want and pop2.total_evaluations == 0  # served from the md5 cache, nothing simulated
     assert any("Launched 0 voxelyze calls" in l for l in log.lines)
 
 
-def test_evaluate_all_on_two_ranks(tmp_path):
+@pytest.mark.parametrize("route", ["files", "memory"])
+def test_evaluate_all_on_two_ranks(tmp_path, route):
     """a 2-rank job (gloo) on one shared run directory: both ranks must end both generations with the same fitness values,
     caches and counters, nobody may report a robot as unfinished, and the files are rank 0's business alone"""
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -81,7 +84,7 @@ def test_evaluate_all_on_two_ranks(tmp_path):
         os.makedirs(os.path.join(run, d))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=repo)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", os.path.join(repo, "tests", "dist_worker_eval.py"), run]
+           "--master-port", "29617" if route == "files" else "29619", os.path.join(repo, "tests", "dist_worker_eval.py"), run, route]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert proc.returncode == 0, proc.stdout.decode()[-3000:]
     r0, r1 = (json.load(open(os.path.join(run, "rank%d.json" % k))) for k in (0, 1))
@@ -95,6 +98,7 @@ def test_evaluate_all_on_two_ranks(tmp_path):
     # housekeeping done once: generation 0 moved to Gen_0000 (save_vxa_every = 1), generation 1 removed, no result files left
     assert sorted(f.split("--id_")[1] for f in os.listdir(os.path.join(run, "Gen_0000"))) == ["%05d.vxa" % i for i in range(5)]
     # (the clone of generation 2 and the invalid robot of generation 1 were never simulated: their files stay, as in the reference)
-    assert sorted(os.listdir(os.path.join(run, "voxelyzeFiles"))) == ["D--id_00005.vxa", "D--id_00010.vxa"]
+    # (in memory: a .vxa only exists for the individuals the bookkeeping keeps)
+    assert sorted(os.listdir(os.path.join(run, "voxelyzeFiles"))) == (["D--id_00005.vxa", "D--id_00010.vxa"] if route == "files" else [])
     assert os.listdir(os.path.join(run, "fitnessFiles")) == []
     assert len(os.listdir(os.path.join(run, "bestSoFar/fitOnly"))) >= 1

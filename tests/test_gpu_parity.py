@@ -684,7 +684,48 @@ def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
     assert sum(1 for sp in spreads if sp < 1e-10) >= 0.75 * count
 
 
-def test_evaluate_all_with_the_real_engine(eng_mod, golden_dir, manifest, tmp_path):
+def test_in_memory_hand_off_builds_the_same_robots(eng_mod, tmp_path):
+    """vxh_add_robots (arrays + one template) against the file route: same counts, same time step, and the same trajectory bit for
+    bit -- including per-voxel layers whose values the .vxa text carries with 12 significant digits only"""
+    from collections import OrderedDict
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import phenotype_arrays, write_voxelyze_file
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim, env = Sim(dt_frac=0.9, simulation_time=0.3, fitness_eval_init_time=0.02), Env()
+    rs = np.random.RandomState(5)
+    inds = [workloads.random_robot(i, (6, 6, 6), 30 + i, phase_offset=True) for i in range(6)]        # unrounded random phases
+    inds.append(workloads.make_individual(6, workloads.random_material((5, 5, 5), 77),
+                                          OrderedDict([("<Stiffness>", 10 ** rs.uniform(6.0, 8.0, size=(5, 5, 5))),
+                                                       ("<PhaseOffset>", rs.uniform(-1, 1, size=(5, 5, 5)))])))
+    inds.append(workloads.make_individual(7, workloads.random_material((7, 4, 5), 78)))                 # no layer at all, not a cube
+    texts = []
+    for ind in inds:
+        texts.append(write_voxelyze_file(sim, env, ind, str(tmp_path), "m", want_text=True)[1])
+    paths = [str(tmp_path / "voxelyzeFiles" / ("m--id_%05i.vxa" % ind.id)) for ind in inds]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as by_file, eng_mod.Engine(eng_mod.VOXCAD, 0) as by_array:
+        by_file.add_vxa_files(paths)
+        first = by_array.add_robots(texts[3], [phenotype_arrays(ind) + ("fitnessFiles/softbotsOutput--id_%05i.xml" % ind.id,) for ind in inds])
+        assert first == 0 and by_array.num_robots() == len(inds)
+        for i in range(len(inds)):
+            assert by_file.dims(i) == by_array.dims(i), i
+            assert by_array.fitness_file_name(i) == "fitnessFiles/softbotsOutput--id_%05i.xml" % inds[i].id
+        by_file.step(400)
+        by_array.step(400)
+        for i in range(len(inds)):
+            assert np.array_equal(by_file.state(i), by_array.state(i)), i
+    # refusals: a layer the engine does not model, a material outside the palette
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as bad:
+        with pytest.raises(eng_mod.VxhError) as err:
+            bad.add_robots(texts[0], [(np.ones((2, 2, 2), dtype=int), OrderedDict([("<VestigialLimbs>", np.zeros((2, 2, 2)))]), None)])
+        assert err.value.status == -7
+        with pytest.raises(eng_mod.VxhError):
+            bad.add_robots(texts[0], [(np.full((2, 2, 2), 9), OrderedDict(), None)])
+        assert bad.num_robots() == 0
+
+
+@pytest.mark.parametrize("in_memory", [False, True])
+def test_evaluate_all_with_the_real_engine(eng_mod, golden_dir, manifest, tmp_path, in_memory):
     """BASELINE configs[0] end to end through the recommended route: evaluate_all -> run_population ->
     libvxhip, NOT the stub engine of the CPU suite.  The basic.py-style 6x6x6 locomotor (0.5 s) and a second generation with
     another golden robot; objective values must equal what the reference's read_voxlyze_results parsed out of the reference
@@ -725,7 +766,7 @@ def test_evaluate_all_with_the_real_engine(eng_mod, golden_dir, manifest, tmp_pa
     # the clone differs in id only: with zero actuation variance the reference evaluates both (the cache is filled after the
     # generation) and both get the same value
     evaluate_all(Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1), env, pop, log, save_vxa_every=1,
-                 run_directory=run, run_name="E")
+                 run_directory=run, run_name="E", in_memory=in_memory)
     want = manifest["probe6"]
     assert probe.md5 == clone.md5 == want["md5"]
     for ind in (probe, clone):
@@ -739,7 +780,7 @@ def test_evaluate_all_with_the_real_engine(eng_mod, golden_dir, manifest, tmp_pa
     pop2 = make_pop([other, again], 1)
     pop2.already_evaluated, pop2.best_fit_so_far = pop.already_evaluated, pop.best_fit_so_far
     evaluate_all(Sim(dt_frac=0.9, simulation_time=0.25, fitness_eval_init_time=0.1), env, pop2, log, save_vxa_every=0,
-                 run_directory=run, run_name="E", save_lineages=True)
+                 run_directory=run, run_name="E", save_lineages=True, in_memory=in_memory)
     want2 = manifest["rand6_col"]
     assert other.md5 == want2["md5"]
     assert (other.fitness, other.y, other.touch) == (want2["read_results"]["0"], want2["read_results"]["2"], want2["read_results"]["3"])
