@@ -101,6 +101,14 @@ VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doub
     return L;
 }
 
+// what CVX_SimGA::WriteResultFile needs of a robot's final state, reduced on the device (k_results): the host derives every tag from it
+struct DResult {
+    double cm[3];                 // SS.CurCM: mass-weighted sum in voxel order, like GetCM (VX_Sim.cpp:2415-2430)
+    double d2max, d2min;          // max / min over the voxels of (x - IniCM.x)^2 + (y - IniCM.y)^2 (getAnteriorDist / getPosteriorDist :2584-2616)
+    double ymax, ymin;            // max / min y of the voxels that are not material 5 (getAnteriorY / getPosteriorY :2620-2656)
+    int touching, feet;           // voxels below the floor plane, and those of material 6 among them (GetNumTouchingFloor :2660-2712)
+};
+
 enum { VXH_MAXCOL = 64 };     // collision partners kept per surface voxel (overflow -> VXH_ROBOT_COL_OVERFLOW)
 
 // all device pointers of a batch; passed to kernels by value

@@ -79,6 +79,7 @@ struct Engine::Device {
     hipStream_t tile_stream = nullptr;        // ONE stream for every tiled launch: two of them must never share the chip
     hipEvent_t tile_t0 = nullptr, tile_t1 = nullptr;
     int n_cu = 0;
+    DResult* results = nullptr;               // [robots] output of k_results (freed with the batch)
     int reb_blocks = 0;                   // streaming path: collision-rebuild blocks appended to k_bonds
     const int* reb_robot = nullptr;
     const int* reb_i0 = nullptr;
@@ -109,6 +110,7 @@ struct Engine::Device {
         if (graph) { hipGraphDestroy(graph); graph = nullptr; }
         for (void* p : allocs) hipFree(p);
         allocs.clear();
+        results = nullptr;
         B = DBatch{};
     }
 };
@@ -169,7 +171,7 @@ int Engine::add_vxa(const char* data, size_t len)
     }
     robots_.push_back(build_robot(vxa));
     prepared_ = false;
-    state_downloaded_ = control_downloaded_ = false;
+    state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
     return (int)robots_.size() - 1;
 }
 
@@ -213,7 +215,7 @@ int Engine::add_vxa_files(const std::vector<std::string>& paths)
     const int first = (int)robots_.size();
     for (int i = 0; i < n; ++i) robots_.push_back(std::move(built[i]));
     prepared_ = false;
-    state_downloaded_ = control_downloaded_ = false;
+    state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
     return first;
 }
 
@@ -287,7 +289,7 @@ int Engine::add_arrays(const char* template_vxa, size_t len, const vxh_robot_arr
     const int first = (int)robots_.size();
     for (int i = 0; i < n; ++i) robots_.push_back(std::move(built[i]));
     prepared_ = false;
-    state_downloaded_ = control_downloaded_ = false;
+    state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
     return first;
 }
 
@@ -327,7 +329,7 @@ void Engine::clear()
     dev_->free_all();
     robots_.clear();
     host_.clear();
-    prepared_ = state_downloaded_ = control_downloaded_ = false;
+    prepared_ = state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
     rounds_done_ = 0;
 }
 
@@ -338,6 +340,7 @@ void Engine::set_option(const std::string& key, double value)
     else
 #endif
     if (key == "fused") fused_ = value != 0;
+    else if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
     else if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); steps_per_launch_ = (int)value; }
     else if (key == "tiled" || key == "tiles_per_robot") {
         // the tiling is part of the uploaded batch: set before the first vxh_run / vxh_step, or follow with vxh_reset
@@ -818,7 +821,7 @@ void Engine::prepare()
     B.smallish_angle_w = std::cos(VXH_HYST * VXH_SMALL_ANGLE_RAD * 0.5);
     B.slthresh_acos2sqrt = 1.0 - 0.9988 * 0.9988;
     prepared_ = true;
-    state_downloaded_ = control_downloaded_ = false;
+    state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
     host_.clear();
     rounds_done_ = 0;
     counters_ = vxh_counters{};
@@ -959,7 +962,7 @@ void Engine::advance(long long max_rounds)
     counters_.kernel_seconds += ms * 1e-3;
     counters_.launches += launches;
     rounds_done_ += todo;
-    state_downloaded_ = false;
+    state_downloaded_ = reduced_downloaded_ = false;
     download_control();
 
     // dominant kernel of this call: the launch group that processed most voxel-steps (fused) / the whole call (streaming)
@@ -1076,12 +1079,6 @@ void Engine::download()
             H.scale[v] = plane(4 * b + 3)[base + v];
         }
     }
-    if (D.total_trace > 0) {
-        std::vector<double> tr((size_t)D.total_trace * 4);
-        HIP_OK(hipMemcpy(tr.data(), B.trace, sizeof(double) * tr.size(), hipMemcpyDeviceToHost));
-        for (int r = 0; r < nr; ++r)
-            for (size_t k = 0; k < host_[r].cm_trace.size(); ++k) host_[r].cm_trace[k] = tr[(size_t)D.trace_begin[r] * 4 + k];
-    }
     // land_water robots: directional strains of the last step (RobotVolumeEnd)
     bool any_mesh = false;
     for (int r = 0; r < nr; ++r) any_mesh = any_mesh || robots_[r].nmv > 0;
@@ -1105,7 +1102,7 @@ void Engine::download()
 const std::vector<double>& Engine::trace_of(int robot)
 {
     if (!prepared_) throw std::logic_error("trace requested before vxh_run/vxh_step");
-    if (!state_downloaded_) download();
+    if (!reduced_downloaded_) download_reduced();
     return host_[robot].cm_trace;
 }
 
@@ -1134,11 +1131,48 @@ void Engine::bond_modes(long long* large_angle, long long* total)
     *large_angle = l; *total = t;
 }
 
+// What the results need of the final state, reduced on the device (k_results: 72 bytes per robot instead of 144 per voxel), and the
+// centre-of-mass traces
+void Engine::download_reduced()
+{
+    HIP_OK(hipSetDevice(device_id_));
+    Device& D = *dev_;
+    const int nr = (int)robots_.size();
+    if (!control_downloaded_) download_control();
+    if (nr > 0) {
+        if (!D.results) D.results = D.alloc_zero<DResult>(nr);
+        hipLaunchKernelGGL(k_results, dim3(nr), dim3(256), 0, D.stream, D.B, D.results);
+        HIP_OK(hipGetLastError());
+        std::vector<DResult> h(nr);
+        HIP_OK(hipMemcpyAsync(h.data(), D.results, sizeof(DResult) * nr, hipMemcpyDeviceToHost, D.stream));
+        HIP_OK(hipStreamSynchronize(D.stream));
+        for (int r = 0; r < nr; ++r) {
+            HostState& H = host_[r];
+            H.reduced = true;
+            for (int k = 0; k < 3; ++k) H.red_cm[k] = h[r].cm[k];
+            H.d2max = h[r].d2max; H.d2min = h[r].d2min; H.ymax = h[r].ymax; H.ymin = h[r].ymin; H.touching = h[r].touching; H.feet = h[r].feet;
+        }
+    }
+    if (D.total_trace > 0) {
+        std::vector<double> tr((size_t)D.total_trace * 4);
+        HIP_OK(hipMemcpy(tr.data(), D.B.trace, sizeof(double) * tr.size(), hipMemcpyDeviceToHost));
+        for (int r = 0; r < nr; ++r)
+            for (size_t k = 0; k < host_[r].cm_trace.size(); ++k) host_[r].cm_trace[k] = tr[(size_t)D.trace_begin[r] * 4 + k];
+    }
+    reduced_downloaded_ = true;
+}
+
 void Engine::result(int robot, vxh_result* out)
 {
     if (!prepared_) throw std::logic_error("results requested before vxh_run/vxh_step");
-    if (!state_downloaded_) download();
-    compute_result(robots_[robot], host_[robot], out);
+    // _voxcad: every tag from the device-side reductions; land_water: the RobotVolume tags need the surface mesh of the final state
+    // (poses + strains of every voxel), evaluated on the host
+    const bool need_state = variant_ == 1 || host_results_;
+    if (need_state && !state_downloaded_) download();
+    if (!need_state && !reduced_downloaded_) download_reduced();
+    HostState& H = host_[robot];
+    if (need_state) { const bool keep = H.reduced; H.reduced = false; compute_result(robots_[robot], H, out); H.reduced = keep; }
+    else compute_result(robots_[robot], H, out);
 }
 
 void Engine::state14(int robot, double* out, int capacity)

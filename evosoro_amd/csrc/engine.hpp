@@ -14,6 +14,10 @@ struct HostState {                      // final/current state of one robot, dow
     std::vector<double> strain;                                // land_water: [6*n] StrainPosDirsCur xyz, StrainNegDirsCur xyz of the last step
     double cur_time = 0, ini_cm[3] = {0, 0, 0}, eol_post_y = 0;
     int steps = 0, status = 0, cm_init = 0, rebuilds = 0;
+    // reductions of the final state done on the device (k_results); valid when `reduced`
+    bool reduced = false;
+    double red_cm[3] = {0, 0, 0}, d2max = 0, d2min = 0, ymax = 0, ymin = 0;
+    int touching = 0, feet = 0;
     std::vector<double> cm_trace;                              // [4*k] (time, x, y, z): SS.CMTraceTime / SS.CMTrace
 };
 
@@ -45,11 +49,13 @@ private:
     void advance(long long max_rounds);        // launch step rounds
     void download();
     void download_control();
+    void download_reduced();                   // k_results + the traces: what results need, without the voxel state
     int variant_, device_id_;
     std::vector<RobotModel> robots_;
     std::vector<HostState> host_;
     std::unique_ptr<Device> dev_;
-    bool prepared_ = false, state_downloaded_ = false, control_downloaded_ = false;
+    bool prepared_ = false, state_downloaded_ = false, control_downloaded_ = false, reduced_downloaded_ = false;
+    bool host_results_ = false;                // option host_results: every result from the downloaded voxel state on the host (cross-check)
     long long rounds_done_ = 0;
     int graph_steps_ = 32;                     // streaming path: step rounds captured per hipGraph launch (0 = plain launches)
     int dbg_ = 0;

@@ -712,6 +712,69 @@ __device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobo
     }
 }
 
+// The reductions behind the result file, from the state the stepping kernels left in HBM: one workgroup per robot.  The centre of
+// mass keeps the reference's summation order (thread 0 adds voxel after voxel; the products come from all threads); the extrema
+// and counts are order-free.  Every expression that the host used to evaluate is written with explicit roundings (no contraction),
+// so the numbers are those of the host path bit for bit (option host_results = 1 keeps that path for cross-checks).
+__global__ __launch_bounds__(256) void k_results(DBatch B, DResult* __restrict__ out)
+{
+#pragma clang fp contract(off)      // every product and sum below is rounded on its own, like on the host (HIP's *_rn arithmetic helpers would not
+                                    // do: they are plain operators compiled where they are DEFINED, with contraction on)
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const DRobot& R = B.robot[r];
+    const DRobotState& rs = B.rstate[r];
+    __shared__ double sh[4 * 256];
+    __shared__ double red[4][4];
+    __shared__ int cnt[2][4];
+    const int cur = rs.steps & 1, base = R.vox_begin;
+    double sx = 0, sy = 0, sz = 0, sm = 0;
+    double d2max = 0.0, d2min = 1.0e300, ymax = -1.0e300, ymin = 1.0e300;
+    int touching = 0, feet = 0;
+    const double ix = rs.ini_cm[0], iy = rs.ini_cm[1];
+    for (int c0 = 0; c0 < R.nvox; c0 += 256) {
+        const int k = c0 + tid;
+        if (k < R.nvox) {
+            const int g = base + k;
+            const DVoxClass& C = B.vclass_tab[R.vtab_begin + B.vclass[g]];
+            const double x = POS(cur, 0, g), y = POS(cur, 1, g), z = POS(cur, 2, g), s = SCALE(cur, g);
+            sh[tid] = x * C.mass; sh[256 + tid] = y * C.mass; sh[512 + tid] = z * C.mass; sh[768 + tid] = C.mass;
+            const double dx = x - ix, dy = y - iy;
+            const double dxx = dx * dx, dyy = dy * dy;
+            const double d2 = dxx + dyy;
+            d2max = d2 > d2max ? d2 : d2max; d2min = d2 < d2min ? d2 : d2min;
+            if (C.mat != 5) { ymax = y > ymax ? y : ymax; ymin = y < ymin ? y : ymin; }
+            const double half = 0.5 * s;
+            if (half - z > 0) { ++touching; if (C.mat == 6) ++feet; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int n = min(256, R.nvox - c0);
+            for (int j = 0; j < n; ++j) { sx = sx + sh[j]; sy = sy + sh[256 + j]; sz = sz + sh[512 + j]; sm = sm + sh[768 + j]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double a = __shfl_xor(d2max, off), b = __shfl_xor(d2min, off), c = __shfl_xor(ymax, off), d = __shfl_xor(ymin, off);
+        d2max = a > d2max ? a : d2max; d2min = b < d2min ? b : d2min; ymax = c > ymax ? c : ymax; ymin = d < ymin ? d : ymin;
+        touching += __shfl_xor(touching, off); feet += __shfl_xor(feet, off);
+    }
+    if ((tid & 63) == 0) { const int w = tid >> 6; red[0][w] = d2max; red[1][w] = d2min; red[2][w] = ymax; red[3][w] = ymin; cnt[0][w] = touching; cnt[1][w] = feet; }
+    __syncthreads();
+    if (tid == 0) {
+        DResult o;
+        const double inv = R.nvox > 0 ? 1.0 / sm : 0.0;
+        o.cm[0] = inv * sx; o.cm[1] = inv * sy; o.cm[2] = inv * sz;
+        o.d2max = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+        o.d2min = fmin(fmin(red[1][0], red[1][1]), fmin(red[1][2], red[1][3]));
+        o.ymax = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+        o.ymin = fmin(fmin(red[3][0], red[3][1]), fmin(red[3][2], red[3][3]));
+        o.touching = cnt[0][0] + cnt[0][1] + cnt[0][2] + cnt[0][3];
+        o.feet = cnt[1][0] + cnt[1][1] + cnt[1][2] + cnt[1][3];
+        out[r] = o;
+    }
+}
+
 // stiffness of the collision bond between two voxel classes, first = the earlier voxel (CVX_Bond::LinkVoxels +
 // UpdateConstants for the pair, VX_Bond.cpp:65-173: a1 = E*A/L of a cubic bond)
 __device__ __forceinline__ double contact_a1(const DVoxClass& C1, const DVoxClass& C2)

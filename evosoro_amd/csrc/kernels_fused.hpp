@@ -70,10 +70,12 @@ __device__ __forceinline__ void fused_latch_cm(const DRobot& R, DRobotState& rs,
     if (valid) sh[tid] = (C.mat == 5) ? -C.mass : C.mass;      // sign marks the material excluded from PosteriorY
     __syncthreads();
     if (tid == 0) {
+#pragma clang fp contract(off)      // product and sum rounded separately, like the reference's GetCM
         double sx = 0, sy = 0, sz = 0, sm = 0, miny = 100000.0;
         for (int k = 0; k < R.nvox; ++k) {
             const double ms = sh[k], m = fabs(ms), y = ps[BLOCK + k];
-            sx = __dadd_rn(sx, __dmul_rn(ps[k], m)); sy = __dadd_rn(sy, __dmul_rn(y, m)); sz = __dadd_rn(sz, __dmul_rn(ps[2 * BLOCK + k], m)); sm += m;
+            const double mx = ps[k] * m, my = y * m, mz = ps[2 * BLOCK + k] * m;
+            sx = sx + mx; sy = sy + my; sz = sz + mz; sm += m;
             if (!(ms < 0)) { const double yl = y / R.lat; if (yl < miny) miny = yl; }
         }
         if (latch) { const double inv = 1.0 / sm; rs.ini_cm[0] = inv * sx; rs.ini_cm[1] = inv * sy; rs.ini_cm[2] = inv * sz; rs.cm_init = 1; }

@@ -77,7 +77,9 @@ void compute_result(const RobotModel& M, const HostState& S, vxh_result* r)
     const double lat = X.lattice_dim;
     // SS.CurCM after the last UpdateStats: sequential mass-weighted sum in voxel order (GetCM); zero before any step
     double cm[3] = {0, 0, 0};
-    if (S.steps > 0 && M.nvox > 0) {
+    if (S.reduced) {                         // (k_results: the same sums, formed on the device in the same order)
+        if (S.steps > 0 && M.nvox > 0) for (int k = 0; k < 3; ++k) cm[k] = S.red_cm[k];
+    } else if (S.steps > 0 && M.nvox > 0) {
         double sx = 0, sy = 0, sz = 0, tm = 0;
         for (int v = 0; v < M.nvox; ++v) {
             const double m = M.vox_classes[M.vox_class[v]].mass;
@@ -92,7 +94,18 @@ void compute_result(const RobotModel& M, const HostState& S, vxh_result* r)
         const double fd = std::pow(std::pow(cm[0] - S.ini_cm[0], 2) + std::pow(cm[1] - S.ini_cm[1], 2), 0.5) / lat;
         double ant = 0.0, post = 100000.0, anty = 0.0, posty = 100000.0;
         int touching = 0, feet = 0;
-        for (int v = 0; v < M.nvox; ++v) {
+        if (S.reduced) {
+            // the extrema were taken on the device over the arguments; pow(., 0.5), the division by the lattice constant and the
+            // comparisons with the start values (0 and 100000) are monotone, so they commute with max / min
+            if (M.nvox > 0) {
+                const double a = std::pow(S.d2max, 0.5) / lat, p = std::pow(S.d2min, 0.5) / lat;
+                if (a > ant) ant = a;
+                if (p < post) post = p;
+                if (S.ymax > -1.0e299) { const double y1 = S.ymax / lat, y0 = S.ymin / lat; if (y1 > anty) anty = y1; if (y0 < posty) posty = y0; }
+            }
+            touching = S.touching; feet = S.feet;
+        }
+        for (int v = 0; v < (S.reduced ? 0 : M.nvox); ++v) {
             const VoxClass& C = M.vox_classes[M.vox_class[v]];
             const double x = S.pos[3 * v], y = S.pos[3 * v + 1], z = S.pos[3 * v + 2];
             const double d = std::pow(std::pow(x - S.ini_cm[0], 2) + std::pow(y - S.ini_cm[1], 2), 0.5) / lat;

@@ -168,7 +168,9 @@ int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long 
  *                       (with another process on the same GPU set "tiled" to 0).
  *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 256)
  *   "fused"             0 = robots the tiled kernel does not take go through the streaming kernels (cross-checks)
- *   "graph_steps"       streaming kernels: step rounds per captured hipGraph (0 = plain launches) */
+ *   "graph_steps"       streaming kernels: step rounds per captured hipGraph (0 = plain launches)
+ *   "host_results"      1 = vxh_get_result evaluates every tag on the host from the downloaded voxel state instead of from the
+ *                       device-side reductions (cross-checks; the numbers are the same) */
 int  vxh_set_option(vxh_engine* e, const char* key, double value);
 
 const char* vxh_strerror(int status);

@@ -899,3 +899,25 @@ def test_cm_trace_in_the_result_file(eng_mod, golden_dir, tmp_path):
         streamed = eng.cm_trace(0)
         assert streamed.shape == (13, 4) and np.array_equal(streamed[:, 0], want[:, 0])
         assert np.abs(streamed[:, 1:] - want[:, 1:]).max() / model["lattice_dim"] <= tol
+
+
+def test_device_side_result_reductions_equal_the_host_path(eng_mod, golden_dir):
+    """vxh_get_result of a _voxcad robot comes from reductions done on the device (k_results: centre of mass summed in voxel order,
+    extrema, floor-contact counts) -- every field must equal, bit for bit, what the host computes from the downloaded voxel state
+    (option host_results = 1), after the first step, mid-run and at the end"""
+    names = CASES + ["bench10_0"]
+    seen = {}
+    for host in (0, 1):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("host_results", host)
+            for n in names:
+                eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))
+            eng.step(1)
+            out = [[eng.result(i).as_dict() for i in range(len(names))]]
+            eng.step(332)
+            out.append([eng.result(i).as_dict() for i in range(len(names))])
+            eng.run()
+            out.append([eng.result(i).as_dict() for i in range(len(names))])
+            seen[host] = out
+    assert seen[0] == seen[1]
+    assert all(r["status"] == eng_mod.ROBOT_FINISHED and r["num_touching_floor"] > 0 for r in seen[0][2])
