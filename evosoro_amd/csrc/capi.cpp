@@ -95,6 +95,12 @@ int vxh_plan_tiles_buffer(const char* xml, size_t len, int variant, int k_reques
     }
 }
 
+double vxh_convex_hull_volume(const double* xyz, int n)
+{
+    if (!xyz || n < 0) return -1.0;
+    return vxh::convex_hull_volume(std::vector<double>(xyz, xyz + (size_t)3 * n));
+}
+
 int vxh_create(vxh_engine** out, int variant, int device_id)
 {
     if (!out || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;

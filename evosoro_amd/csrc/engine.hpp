@@ -72,5 +72,6 @@ private:
 void compute_result(const RobotModel& model, const HostState& st, vxh_result* out);
 std::string result_xml(const RobotModel& model, const vxh_result& res, const std::vector<double>& cm_trace);
 const std::vector<double>& empty_trace();
+double convex_hull_volume(const std::vector<double>& xyz);   // results.cpp: what stands in for the reference's external qhull
 
 }  // namespace vxh

@@ -3,7 +3,9 @@
 // (VX_Sim.cpp:1518-1535) with their helpers GetCM / getAnteriorDist / getPosteriorY / GetNumTouchingFloor
 // (VX_Sim.cpp:2415-2441,2584-2712).  Numbers are printed like `ostream << double` (6 significant digits,
 // Utils/XML_Rip.h:57) in TinyXML's layout (4 blanks per level).
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include <cstdio>
 #include <cstring>
@@ -66,7 +68,141 @@ double robot_volume(const RobotModel& M, const double* pos, const double* quat, 
     return volume;
 }
 
+// vertices of the deformable surface mesh (rest state when pos == null), as robot_volume places them
+void mesh_vertices(const RobotModel& M, const double* pos, const double* quat, const double* strain, std::vector<double>& vert)
+{
+    const double nom = M.vxa.lattice_dim;
+    vert.assign((size_t)M.nmv * 3, 0.0);
+    for (int i = 0; i < M.nmv; ++i) {
+        double ax = 0, ay = 0, az = 0, tw = 0;
+        for (int q = 0; q < 8; ++q) {
+            const int comp = M.vert_comp[(size_t)i * 8 + q];
+            if (comp < 0) break;
+            const int u = comp >> 3, corner = comp & 7;
+            double st[6] = {0, 0, 0, 0, 0, 0};
+            if (strain) for (int k = 0; k < 6; ++k) st[k] = strain[(size_t)6 * u + k];
+            const double ox = (corner & 4) ? (1 + st[0]) * nom * 0.5 : -(1 + st[3]) * nom * 0.5;
+            const double oy = (corner & 2) ? (1 + st[1]) * nom * 0.5 : -(1 + st[4]) * nom * 0.5;
+            const double oz = (corner & 1) ? (1 + st[2]) * nom * 0.5 : -(1 + st[5]) * nom * 0.5;
+            double px = M.nom_pos[3 * u], py = M.nom_pos[3 * u + 1], pz = M.nom_pos[3 * u + 2];
+            double qw = 1, qx = 0, qy = 0, qz = 0;
+            if (pos) { px = pos[3 * u]; py = pos[3 * u + 1]; pz = pos[3 * u + 2]; qw = quat[4 * u]; qx = quat[4 * u + 1]; qy = quat[4 * u + 2]; qz = quat[4 * u + 3]; }
+            const double tw_ = ox * qx + oy * qy + oz * qz, tx = ox * qw - oy * qz + oz * qy, ty = ox * qz + oy * qw - oz * qx, tz = -ox * qy + oy * qx + oz * qw;
+            ax += px + (qw * tx + qx * tw_ + qy * tz - qz * ty);
+            ay += py + (qw * ty - qx * tz + qy * tw_ + qz * tx);
+            az += pz + (qw * tz + qx * ty - qy * tx + qz * tw_);
+            tw += 1.0;
+        }
+        const double inv = 1.0 / tw;
+        const double v0x = M.vert_v0[(size_t)3 * i], v0y = M.vert_v0[(size_t)3 * i + 1], v0z = M.vert_v0[(size_t)3 * i + 2];
+        vert[(size_t)3 * i] = v0x + (ax * inv - v0x); vert[(size_t)3 * i + 1] = v0y + (ay * inv - v0y); vert[(size_t)3 * i + 2] = v0z + (az * inv - v0z);
+    }
+}
+
 }  // namespace
+
+// Volume of the convex hull of a point set: what the reference obtains by writing the mesh vertices to a file and running the external
+// `qhull FS` on it (CVX_MeshUtil::writeQhullInputFile / invokeQhull, LW/VX_MeshUtil.cpp:775-900).  Incremental hull: a tetrahedron of
+// four points in general position, then every point that lies outside replaces the faces it sees by a cone over their horizon.  A
+// point closer to a face plane than `eps` counts as not seeing it: lattice corners make thousands of coplanar points, and the volume
+// does not notice the difference.  O(points x faces), a few hundred of each here.
+double convex_hull_volume(const std::vector<double>& pts)
+{
+    const int n = (int)(pts.size() / 3);
+    if (n < 4) return 0.0;
+    auto P = [&](int i) { return &pts[(size_t)3 * i]; };
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], P(i)[k]); hi[k] = std::max(hi[k], P(i)[k]); }
+    const double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    if (!(diag > 0)) return 0.0;
+    const double eps = 1e-9 * diag;
+    struct Face { int a, b, c; double nx, ny, nz, d; bool alive; };
+    auto make = [&](int a, int b, int c) {
+        const double *A = P(a), *B = P(b), *C = P(c);
+        const double ux = B[0] - A[0], uy = B[1] - A[1], uz = B[2] - A[2], vx = C[0] - A[0], vy = C[1] - A[1], vz = C[2] - A[2];
+        double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+        const double l = std::sqrt(nx * nx + ny * ny + nz * nz);
+        if (l > 0) { nx /= l; ny /= l; nz /= l; }
+        return Face{a, b, c, nx, ny, nz, nx * A[0] + ny * A[1] + nz * A[2], true};
+    };
+    auto dist = [&](const Face& f, int i) { return f.nx * P(i)[0] + f.ny * P(i)[1] + f.nz * P(i)[2] - f.d; };
+    // initial tetrahedron: extreme points along x, the point farthest from that line, the point farthest from that plane
+    int i0 = 0, i1 = 0;
+    for (int i = 0; i < n; ++i) { if (P(i)[0] < P(i0)[0]) i0 = i; if (P(i)[0] > P(i1)[0]) i1 = i; }
+    if (i0 == i1) { for (int i = 0; i < n; ++i) { if (P(i)[1] < P(i0)[1]) i0 = i; if (P(i)[1] > P(i1)[1]) i1 = i; } }
+    if (i0 == i1) { for (int i = 0; i < n; ++i) { if (P(i)[2] < P(i0)[2]) i0 = i; if (P(i)[2] > P(i1)[2]) i1 = i; } }
+    if (i0 == i1) return 0.0;
+    int i2 = -1; double best = 0;
+    {
+        const double ex = P(i1)[0] - P(i0)[0], ey = P(i1)[1] - P(i0)[1], ez = P(i1)[2] - P(i0)[2];
+        for (int i = 0; i < n; ++i) {
+            const double px = P(i)[0] - P(i0)[0], py = P(i)[1] - P(i0)[1], pz = P(i)[2] - P(i0)[2];
+            const double cx = ey * pz - ez * py, cy = ez * px - ex * pz, cz = ex * py - ey * px, a2 = cx * cx + cy * cy + cz * cz;
+            if (a2 > best) { best = a2; i2 = i; }
+        }
+    }
+    if (i2 < 0 || !(std::sqrt(best) > eps * diag)) return 0.0;
+    Face base = make(i0, i1, i2);
+    int i3 = -1; best = 0;
+    for (int i = 0; i < n; ++i) { const double h = std::fabs(dist(base, i)); if (h > best) { best = h; i3 = i; } }
+    if (i3 < 0 || !(best > eps)) return 0.0;                          // all points in one plane
+    std::vector<Face> faces;
+    if (dist(base, i3) > 0) std::swap(i1, i2);                        // orient (i0, i1, i2) away from i3
+    faces.push_back(make(i0, i1, i2)); faces.push_back(make(i0, i3, i1)); faces.push_back(make(i1, i3, i2)); faces.push_back(make(i2, i3, i0));
+    std::vector<char> sees;
+    std::vector<std::pair<int, int>> horizon;
+    for (int p = 0; p < n; ++p) {
+        if (p == i0 || p == i1 || p == i2 || p == i3) continue;
+        sees.assign(faces.size(), 0);
+        bool any = false;
+        for (size_t f = 0; f < faces.size(); ++f) if (faces[f].alive && dist(faces[f], p) > eps) { sees[f] = 1; any = true; }
+        if (!any) continue;
+        // horizon: the directed edges of visible faces whose twin belongs to a face that is not visible
+        horizon.clear();
+        for (size_t f = 0; f < faces.size(); ++f) {
+            if (!sees[f]) continue;
+            const int e[3][2] = {{faces[f].a, faces[f].b}, {faces[f].b, faces[f].c}, {faces[f].c, faces[f].a}};
+            for (int k = 0; k < 3; ++k) {
+                bool twin_visible = false;
+                for (size_t g = 0; g < faces.size() && !twin_visible; ++g) {
+                    if (!sees[g] || g == f) continue;
+                    const Face& G = faces[g];
+                    twin_visible = (G.a == e[k][1] && G.b == e[k][0]) || (G.b == e[k][1] && G.c == e[k][0]) || (G.c == e[k][1] && G.a == e[k][0]);
+                }
+                if (!twin_visible) horizon.push_back({e[k][0], e[k][1]});
+            }
+        }
+        for (size_t f = 0; f < faces.size(); ++f) if (sees[f]) faces[f].alive = false;
+        for (const auto& e : horizon) faces.push_back(make(e.first, e.second, p));
+        if (faces.size() > 4096) {                                    // compact now and then
+            std::vector<Face> live;
+            for (const Face& f : faces) if (f.alive) live.push_back(f);
+            faces.swap(live);
+        }
+    }
+    // signed tetrahedra against an interior point
+    const double cx = 0.25 * (P(i0)[0] + P(i1)[0] + P(i2)[0] + P(i3)[0]), cy = 0.25 * (P(i0)[1] + P(i1)[1] + P(i2)[1] + P(i3)[1]),
+                 cz = 0.25 * (P(i0)[2] + P(i1)[2] + P(i2)[2] + P(i3)[2]);
+    double volume = 0;
+    for (const Face& f : faces) {
+        if (!f.alive) continue;
+        const double a[3] = {P(f.a)[0] - cx, P(f.a)[1] - cy, P(f.a)[2] - cz}, b[3] = {P(f.b)[0] - cx, P(f.b)[1] - cy, P(f.b)[2] - cz},
+                     c[3] = {P(f.c)[0] - cx, P(f.c)[1] - cy, P(f.c)[2] - cz};
+        volume += (a[0] * (b[1] * c[2] - b[2] * c[1]) + a[1] * (b[2] * c[0] - b[0] * c[2]) + a[2] * (b[0] * c[1] - b[1] * c[0])) / 6.0;
+    }
+    return std::fabs(volume);
+}
+
+// <ConvexHullVolumeStart/End> of a land_water robot: the hull of its surface-mesh vertices as the reference hands them to qhull,
+// i.e. printed with the stream's 6 significant digits (LW/VX_MeshUtil.cpp:806)
+double robot_hull_volume(const RobotModel& M, const double* pos, const double* quat, const double* strain)
+{
+    if (M.nmv == 0) return 0.0;
+    std::vector<double> vert;
+    mesh_vertices(M, pos, quat, strain, vert);
+    for (double& v : vert) { char buf[48]; std::snprintf(buf, sizeof(buf), "%g", v); v = std::atof(buf); }
+    return convex_hull_volume(vert);
+}
 
 void compute_result(const RobotModel& M, const HostState& S, vxh_result* r)
 {
@@ -129,9 +265,13 @@ void compute_result(const RobotModel& M, const HostState& S, vxh_result* r)
         r->norm_dist_x = (float)dx; r->norm_dist_y = (float)dy; r->norm_dist_z = (float)dz;   // float-typed in the reference
         r->norm_abs_disp = (float)std::sqrt(dx * dx + dy * dy + dz * dz);
         r->robot_volume_start = robot_volume(M, nullptr, nullptr, nullptr);
-        if (S.steps == 0) r->robot_volume_end = r->robot_volume_start;
-        else r->robot_volume_end = ((int)S.strain.size() == 6 * M.nvox) ? robot_volume(M, S.pos.data(), S.quat.data(), S.strain.data())
-                                                                          : -1.0;
+        r->hull_volume_start = robot_hull_volume(M, nullptr, nullptr, nullptr);
+        const bool have = (int)S.strain.size() == 6 * M.nvox;
+        if (S.steps == 0) { r->robot_volume_end = r->robot_volume_start; r->hull_volume_end = r->hull_volume_start; }
+        else {
+            r->robot_volume_end = have ? robot_volume(M, S.pos.data(), S.quat.data(), S.strain.data()) : -1.0;
+            r->hull_volume_end = have ? robot_hull_volume(M, S.pos.data(), S.quat.data(), S.strain.data()) : -1.0;
+        }
     }
 }
 
@@ -172,12 +312,12 @@ std::string result_xml(const RobotModel& M, const vxh_result& r, const std::vect
         tag(out, "normDistX", r.norm_dist_x);
         tag(out, "normDistY", r.norm_dist_y);
         tag(out, "normDistZ", r.norm_dist_z);
-        // the hull volumes need qhull (--computeShapeDescriptors) and the shape complexity an external Python 2 script:
-        // the reference prints -1 for the hull without the flag; -1 here for all four
+        // the hull volumes: the reference shells out to qhull (and prints -1 when that is not installed), here computed in place;
+        // the shape complexity needs curvatureEntropy.py, an external script that the reference repository does not contain: -1
         tag(out, "RobotVolumeStart", r.robot_volume_start);
-        tag(out, "ConvexHullVolumeStart", -1);
+        tag(out, "ConvexHullVolumeStart", r.hull_volume_start);
         tag(out, "RobotVolumeEnd", r.robot_volume_end);
-        tag(out, "ConvexHullVolumeEnd", -1);
+        tag(out, "ConvexHullVolumeEnd", r.hull_volume_end);
         tag(out, "ShapeComplexityStart", -1);
         tag(out, "ShapeComplexityEnd", -1);
     }

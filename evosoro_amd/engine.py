@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_cm_trace", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version"]
@@ -35,7 +35,8 @@ class VxhResult(ctypes.Structure):
                 ("num_touching_floor", ctypes.c_double), ("norm_abs_disp", ctypes.c_double),
                 ("norm_dist_x", ctypes.c_double), ("norm_dist_y", ctypes.c_double), ("norm_dist_z", ctypes.c_double),
                 ("robot_volume_start", ctypes.c_double), ("robot_volume_end", ctypes.c_double),
-                ("col_rebuilds", ctypes.c_int), ("reserved", ctypes.c_int)]
+                ("col_rebuilds", ctypes.c_int), ("reserved", ctypes.c_int),
+                ("hull_volume_start", ctypes.c_double), ("hull_volume_end", ctypes.c_double)]
 
     def as_dict(self):
         out = {}
@@ -107,6 +108,8 @@ def load_library():
                                            ctypes.c_char_p, ctypes.c_size_t]
     lib.vxh_plan_tiles_buffer.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, I, ctypes.POINTER(VxhTilingInfo),
                                           ctypes.POINTER(I), I, ctypes.c_char_p, ctypes.c_size_t]
+    lib.vxh_convex_hull_volume.argtypes = [ctypes.POINTER(ctypes.c_double), I]
+    lib.vxh_convex_hull_volume.restype = D
     lib.vxh_create.argtypes = [ctypes.POINTER(P), I, I]
     lib.vxh_destroy.argtypes = [P]
     lib.vxh_destroy.restype = None
@@ -150,6 +153,12 @@ def inspect_vxa(text_or_path, variant=VOXCAD):
     if rc != 0:
         raise VxhError(rc, "%s (%s)" % (lib.vxh_strerror(rc).decode(), err.value.decode()))
     return info
+
+
+def convex_hull_volume(points):
+    """Host-only: volume of the convex hull of an [n, 3] point set (what <ConvexHullVolume*> is computed with)."""
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+    return load_library().vxh_convex_hull_volume(pts.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(pts))
 
 
 def plan_tiles(text_or_path, k_request, variant=VOXCAD):

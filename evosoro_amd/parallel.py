@@ -18,7 +18,7 @@ RECORD_FIELDS = ["status", "steps", "nvox", "nbond", "dt", "cur_time", "lifetime
                  "anterior_dist", "posterior_dist", "anterior_y", "posterior_y", "end_of_life_posterior_y",
                  "fall_adj_post_y", "num_non_feet_touching_floor", "num_touching_floor",
                  "norm_abs_disp", "norm_dist_x", "norm_dist_y", "norm_dist_z", "robot_volume_start", "robot_volume_end",
-                 "col_rebuilds"]
+                 "col_rebuilds", "hull_volume_start", "hull_volume_end"]
 RECORD_LEN = len(RECORD_FIELDS)
 
 

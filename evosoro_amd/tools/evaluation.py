@@ -54,7 +54,8 @@ _TAG_FIELDS = {"NormFinalDist": "norm_final_dist", "NormRegimeDist": "norm_regim
                "NumNonFeetTouchingFloor": "num_non_feet_touching_floor", "NumTouchingFloor": "num_touching_floor",
                "Lifetime": "lifetime", "normAbsoluteDisplacement": "norm_abs_disp", "normDistX": "norm_dist_x",
                "normDistY": "norm_dist_y", "normDistZ": "norm_dist_z", "RobotVolumeStart": "robot_volume_start",
-               "RobotVolumeEnd": "robot_volume_end"}
+               "RobotVolumeEnd": "robot_volume_end", "ConvexHullVolumeStart": "hull_volume_start",
+               "ConvexHullVolumeEnd": "hull_volume_end"}
 
 
 def _values_from_record(pop, record, parallel):

@@ -64,11 +64,15 @@ typedef struct vxh_result {
     double num_non_feet_touching_floor, num_touching_floor;
     /* _voxcad_land_water tags, LW/VX_SimGA.cpp:58-62 */
     double norm_abs_disp, norm_dist_x, norm_dist_y, norm_dist_z;
-    double robot_volume_start, robot_volume_end;   /* <RobotVolumeStart/End>, LW/VX_MeshUtil.cpp:908-952 (the hull and
-                                                      shape-complexity tags are printed as -1) */
+    double robot_volume_start, robot_volume_end;   /* <RobotVolumeStart/End>, LW/VX_MeshUtil.cpp:908-952 */
     int col_rebuilds;      /* diagnostic: how often CalcL1Bonds ran (VX/VX_Sim.cpp:1741-1747) */
     int reserved;
+    double hull_volume_start, hull_volume_end;     /* <ConvexHullVolumeStart/End>: convex hull of the surface-mesh vertices, which the
+                                                      reference gets from an external qhull (LW/VX_MeshUtil.cpp:775-900); the
+                                                      <ShapeComplexity*> tags are printed as -1 (their script is not in the reference) */
 } vxh_result;
+/* volume of the convex hull of n points (x, y, z per point): the computation behind hull_volume_*, exposed for testing */
+double vxh_convex_hull_volume(const double* xyz, int n);
 
 typedef struct vxh_counters {
     double voxel_steps;        /* sum over robots of nvox * steps taken in vxh_run/vxh_step so far */

@@ -159,6 +159,14 @@ def main():
         only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     work = os.path.join("/tmp", "vx_golden_work")
     shutil.rmtree(work, ignore_errors=True)
+    # the land_water simulator shells out to `qhull` for <ConvexHullVolumeStart/End> (LW/VX_MeshUtil.cpp:821-900) and prints -1 when
+    # there is none: give it the binary the reference vendors (a temporary executable copy, on PATH for the child processes only)
+    qdir = os.path.join("/tmp", "vx_golden_qhull")
+    os.makedirs(qdir, exist_ok=True)
+    if not os.path.exists(os.path.join(qdir, "qhull")):
+        shutil.copy(os.path.join(REF, "evosoro", "_voxcad", "qhull"), os.path.join(qdir, "qhull"))
+        os.chmod(os.path.join(qdir, "qhull"), 0o755)
+    os.environ["PATH"] = qdir + os.pathsep + os.environ["PATH"]
     for sub in ("ref", "ours"):
         for d in ("voxelyzeFiles", "fitnessFiles", "tempFiles"):
             os.makedirs(os.path.join(work, sub, RUN_DIR, d))

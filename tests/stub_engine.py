@@ -22,6 +22,7 @@ class _Result(object):
             setattr(self, name, list(val) if hasattr(val, "__len__") else val)
         self.col_rebuilds = rebuilds
         self.robot_volume_start = self.robot_volume_end = -1.0      # (the oracle does not restate the mesh-volume tags)
+        self.hull_volume_start = self.hull_volume_end = -1.0
 
 
 class Engine(object):

@@ -82,3 +82,24 @@ def test_reader_rejects_bad_input():
     empty = re.sub(r"<!\[CDATA\[[0-9]+\]\]>", lambda m: "<![CDATA[" + "0" * (len(m.group(0)) - 12) + "]]>", good, count=4)
     info = engine.inspect_vxa(re.sub(r"<PhaseOffset>.*?</PhaseOffset>", "", empty, flags=re.S))
     assert info.nvox == 0 and info.nbond == 0        # an empty robot is representable (status EMPTY at run time)
+
+
+def test_convex_hull_volume_known_answers():
+    """the computation behind <ConvexHullVolumeStart/End> (the reference shells out to qhull, LW/VX_MeshUtil.cpp:821-900): closed forms,
+    the degenerate inputs a voxel lattice produces (thousands of coplanar / collinear points), and volumes `qhull FS` printed for
+    seeded point sets (recorded from the binary the reference vendors)"""
+    import numpy as np
+    hull = engine.convex_hull_volume
+    assert abs(hull([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [.1, .1, .1]]) - 1.0 / 6) < 1e-15
+    grid = np.array([[x, y, z] for x in range(5) for y in range(5) for z in range(5)], float) * 0.01
+    assert abs(hull(grid) - 6.4e-05) < 1e-18                                  # a 4 x 4 x 4 cm cube
+    ell = np.array([[x, y, z] for x in range(7) for y in range(7) for z in range(4) if not (x > 3 and y > 3)], float) * 0.01
+    assert abs(hull(ell) - 9.45e-05) < 1e-18                                  # hull of an L: the square minus a corner triangle
+    assert hull(grid[:25]) == 0.0 and hull(grid[:5]) == 0.0 and hull(grid[:3]) == 0.0    # a plane, a line, too few points
+    rs = np.random.RandomState(1)
+    assert abs(hull(rs.uniform(-1, 1, (500, 3))) - 7.13974032262) < 1e-10     # qhull FS: 7.13974032262
+    sphere = rs.normal(size=(800, 3))
+    sphere /= np.linalg.norm(sphere, axis=1)[:, None]
+    assert abs(hull(sphere) - 4.12888859762) < 1e-10                          # qhull FS: 4.12888859762
+    # order of the points does not matter
+    assert abs(hull(sphere[::-1]) - hull(sphere)) < 1e-13

@@ -269,6 +269,9 @@ def test_land_water_variant(eng_mod, golden_dir):
             # mesh-volume tags (LW/VX_MeshUtil.cpp:908-952): rest volume exactly, deformed volume to the printed digits
             assert "%.6g" % res.robot_volume_start == "%.6g" % want["RobotVolumeStart"], name
             assert abs(res.robot_volume_end - want["RobotVolumeEnd"]) <= 2e-5 * want["RobotVolumeEnd"] + 10 * tol * 1e-6, (name, res.robot_volume_end)
+            # convex hull of the surface mesh: the reference ran the qhull binary it vendors on the vertices (tests/golden/make_golden.py)
+            assert "%.6g" % res.hull_volume_start == "%.6g" % want["ConvexHullVolumeStart"], name
+            assert abs(res.hull_volume_end - want["ConvexHullVolumeEnd"]) <= 2e-5 * want["ConvexHullVolumeEnd"] + 10 * tol * 1e-6, (name, res.hull_volume_end)
 
 
 def test_land_water_bench_size_robots_whole_run_vs_reference(eng_mod, golden_dir):
