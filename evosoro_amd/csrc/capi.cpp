@@ -10,7 +10,7 @@
 #include "engine.hpp"
 
 struct vxh_engine {
-    vxh::Engine* impl = nullptr;
+    vxh::EngineSet* impl = nullptr;
     std::string last_error;
 };
 
@@ -105,9 +105,16 @@ int vxh_create(vxh_engine** out, int variant, int device_id)
 {
     if (!out || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;
     *out = nullptr;
+    return vxh_create_multi(out, variant, &device_id, 1);
+}
+
+int vxh_create_multi(vxh_engine** out, int variant, const int* device_ids, int n_devices)
+{
+    if (!out || !device_ids || n_devices < 1 || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;
+    *out = nullptr;
     vxh_engine* e = new vxh_engine;
     try {
-        e->impl = new vxh::Engine(variant, device_id);
+        e->impl = new vxh::EngineSet(variant, std::vector<int>(device_ids, device_ids + n_devices));
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "libvxhip: %s\n", ex.what());
         delete e;

@@ -293,6 +293,24 @@ int Engine::add_arrays(const char* template_vxa, size_t len, const vxh_robot_arr
     return first;
 }
 
+std::vector<RobotModel> Engine::take_robots()
+{
+    HIP_OK(hipSetDevice(device_id_));
+    dev_->free_all();
+    std::vector<RobotModel> out = std::move(robots_);
+    robots_.clear();
+    host_.clear();
+    prepared_ = state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
+    rounds_done_ = 0;
+    return out;
+}
+
+void Engine::give_robots(std::vector<RobotModel>&& models)
+{
+    for (auto& m : models) robots_.push_back(std::move(m));
+    prepared_ = state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
+}
+
 void Engine::clear()
 {
     HIP_OK(hipSetDevice(device_id_));

@@ -1,7 +1,9 @@
 // Batched engine: owns the robots of one population shard and their SoA state on ONE HIP device.
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/vxhip.h"
@@ -42,6 +44,10 @@ public:
     void bond_modes(long long* large_angle, long long* total);   // SmallAngle flags of every bond, downloaded
     void set_option(const std::string& key, double value);
     int variant() const { return variant_; }
+    int device() const { return device_id_; }
+    // EngineSet moves robots between the engines of a handle (host-side models only; the batch is rebuilt on the next run)
+    std::vector<RobotModel> take_robots();
+    void give_robots(std::vector<RobotModel>&& models);
 
 private:
     struct Device;                             // HIP-side members (engine.hip)
@@ -66,6 +72,41 @@ private:
     int tiles_per_robot_ = 0;                  // 0 = chosen from the population size; > 0: requested for every tiled robot (tests)
     unsigned tile_gen_ = 0;                    // launch generation of the tiled kernel (high half of the tiles' flag words)
     vxh_counters counters_{};
+};
+
+// One handle of the C ABI: one engine per device.  With a single device everything is forwarded; with several (vxh_create_multi)
+// the robots are collected by the first engine and, at the first run / step after an addition, partitioned over the devices by
+// cost (greedy longest-processing-time on voxels x planned steps, like evosoro_amd/parallel.py does across processes); every
+// device then steps its share from its own host thread.  The results stay in host memory of the one process, so this path needs
+// no collective at all -- the RCCL gather of SURVEY section 8(e) belongs to the one-process-per-GPU route (parallel.py).
+class EngineSet {
+public:
+    EngineSet(int variant, const std::vector<int>& device_ids);
+    int add_vxa(const char* data, size_t len);
+    int add_vxa_files(const std::vector<std::string>& paths);
+    int add_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text);
+    int num_robots() const;
+    const RobotModel& robot(int i) const;
+    void run();
+    void step(long long n);
+    void reset();
+    void clear();
+    void result(int robot, vxh_result* out);
+    void state14(int robot, double* out, int capacity);
+    void counters(vxh_counters* out) const;
+    void set_option(const std::string& key, double value);
+    int cm_trace(int robot, double* out4n, int capacity);
+    const std::vector<double>& trace_of(int robot);
+    void bond_modes(long long* large_angle, long long* total);
+    int n_devices() const { return (int)engines_.size(); }
+
+private:
+    void gather();          // every robot back to engine 0, in order (before an addition)
+    void distribute();      // ... and out to the devices (before a run)
+    void each(const std::function<void(Engine&)>& body);   // on every engine that holds robots, concurrently; rethrows the first failure
+    std::vector<std::unique_ptr<Engine>> engines_;
+    std::vector<std::pair<int, int>> where_;   // robot -> (engine, index there), valid while distributed_
+    bool distributed_ = false;
 };
 
 // results.cpp: the numbers of CVX_SimGA::WriteResultFile from a final state, and the XML text

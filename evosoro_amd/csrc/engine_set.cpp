@@ -1,0 +1,140 @@
+// EngineSet: the engines behind one C-ABI handle (engine.hpp).  Host-only code.
+#include <algorithm>
+#include <exception>
+#include <stdexcept>
+#include <thread>
+
+#include "engine.hpp"
+
+namespace vxh {
+
+EngineSet::EngineSet(int variant, const std::vector<int>& device_ids)
+{
+    if (device_ids.empty()) throw std::invalid_argument("no device");
+    for (int d : device_ids) engines_.emplace_back(new Engine(variant, d));
+    // two engines on ONE device would have their multi-workgroup launches compete for the CUs (kernels_tiled.hpp: the tiles of a robot
+    // wait for each other): such a handle -- a test configuration, one engine per GPU is the point -- steps with the other kernels
+    std::vector<int> sorted = device_ids;
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+        for (auto& e : engines_) e->set_option("tiled", 0);
+}
+
+void EngineSet::gather()
+{
+    if (!distributed_) return;
+    std::vector<std::vector<RobotModel>> held(engines_.size());
+    for (size_t k = 0; k < engines_.size(); ++k) held[k] = engines_[k]->take_robots();
+    std::vector<RobotModel> all(where_.size());
+    for (size_t i = 0; i < where_.size(); ++i) all[i] = std::move(held[where_[i].first][where_[i].second]);
+    engines_[0]->give_robots(std::move(all));
+    where_.clear();
+    distributed_ = false;
+}
+
+void EngineSet::distribute()
+{
+    if (distributed_) return;
+    const int n = engines_[0]->num_robots(), nd = (int)engines_.size();
+    where_.assign(n, {0, 0});
+    if (nd == 1) {
+        for (int i = 0; i < n; ++i) where_[i] = {0, i};
+        distributed_ = true;
+        return;
+    }
+    std::vector<RobotModel> all = engines_[0]->take_robots();
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    auto cost = [&](int i) { return (double)all[i].nvox * (double)std::max<long long>(1, all[i].planned_steps); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+    std::vector<double> load(nd, 0.0);
+    std::vector<std::vector<int>> share(nd);
+    for (int i : order) {
+        const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        share[k].push_back(i);
+        load[k] += cost(i);
+    }
+    for (int k = 0; k < nd; ++k) {
+        std::sort(share[k].begin(), share[k].end());
+        std::vector<RobotModel> mine;
+        for (size_t j = 0; j < share[k].size(); ++j) { where_[share[k][j]] = {k, (int)j}; mine.push_back(std::move(all[share[k][j]])); }
+        engines_[k]->give_robots(std::move(mine));
+    }
+    distributed_ = true;
+}
+
+void EngineSet::each(const std::function<void(Engine&)>& body)
+{
+    std::vector<std::exception_ptr> errors(engines_.size());
+    std::vector<std::thread> pool;
+    auto work = [&](size_t k) { try { if (engines_[k]->num_robots() > 0) body(*engines_[k]); } catch (...) { errors[k] = std::current_exception(); } };
+    for (size_t k = 1; k < engines_.size(); ++k) pool.emplace_back(work, k);
+    work(0);
+    for (auto& t : pool) t.join();
+    for (auto& e : errors) if (e) std::rethrow_exception(e);
+}
+
+int EngineSet::add_vxa(const char* data, size_t len) { gather(); return engines_[0]->add_vxa(data, len); }
+int EngineSet::add_vxa_files(const std::vector<std::string>& paths) { gather(); return engines_[0]->add_vxa_files(paths); }
+int EngineSet::add_arrays(const char* t, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text)
+{ gather(); return engines_[0]->add_arrays(t, len, robots, n, round_like_text); }
+
+int EngineSet::num_robots() const { return distributed_ ? (int)where_.size() : engines_[0]->num_robots(); }
+const RobotModel& EngineSet::robot(int i) const
+{ return distributed_ ? engines_[where_[i].first]->robot(where_[i].second) : engines_[0]->robot(i); }
+
+void EngineSet::run() { distribute(); each([](Engine& e) { e.run(); }); }
+void EngineSet::step(long long n) { distribute(); each([n](Engine& e) { e.step(n); }); }
+void EngineSet::reset() { each([](Engine& e) { e.reset(); }); }
+void EngineSet::clear() { for (auto& e : engines_) e->clear(); where_.clear(); distributed_ = false; }
+
+void EngineSet::result(int robot, vxh_result* out)
+{
+    if (!distributed_) throw std::logic_error("results requested before vxh_run/vxh_step");
+    engines_[where_[robot].first]->result(where_[robot].second, out);
+}
+void EngineSet::state14(int robot, double* out, int capacity)
+{
+    distribute();
+    engines_[where_[robot].first]->state14(where_[robot].second, out, capacity);
+}
+int EngineSet::cm_trace(int robot, double* out4n, int capacity)
+{
+    if (!distributed_) throw std::logic_error("trace requested before vxh_run/vxh_step");
+    return engines_[where_[robot].first]->cm_trace(where_[robot].second, out4n, capacity);
+}
+const std::vector<double>& EngineSet::trace_of(int robot)
+{
+    if (!distributed_) throw std::logic_error("trace requested before vxh_run/vxh_step");
+    return engines_[where_[robot].first]->trace_of(where_[robot].second);
+}
+void EngineSet::bond_modes(long long* large_angle, long long* total)
+{
+    if (!distributed_) throw std::logic_error("bond modes requested before vxh_run/vxh_step");
+    *large_angle = *total = 0;
+    for (auto& e : engines_) { if (e->num_robots() == 0) continue; long long l = 0, t = 0; e->bond_modes(&l, &t); *large_angle += l; *total += t; }
+}
+
+// sums over the devices; the times are those of the slowest device (they ran side by side), the dominant kernel that of the device that
+// did most of the work
+void EngineSet::counters(vxh_counters* out) const
+{
+    *out = vxh_counters{};
+    double best = -1;
+    for (const auto& e : engines_) {
+        vxh_counters c;
+        e->counters(&c);
+        out->voxel_steps += c.voxel_steps; out->bond_steps += c.bond_steps; out->algorithmic_bytes += c.algorithmic_bytes;
+        out->kernel_seconds = std::max(out->kernel_seconds, c.kernel_seconds); out->run_seconds = std::max(out->run_seconds, c.run_seconds);
+        out->launches += c.launches; out->max_steps = std::max(out->max_steps, c.max_steps);
+        if (c.voxel_steps > best) {
+            best = c.voxel_steps;
+            out->dominant_block = c.dominant_block; out->dominant_robots = c.dominant_robots; out->dominant_launches = c.dominant_launches;
+            out->dominant_seconds = c.dominant_seconds; out->dominant_alg_bytes = c.dominant_alg_bytes; out->dominant_voxel_steps = c.dominant_voxel_steps;
+        }
+    }
+}
+
+void EngineSet::set_option(const std::string& key, double value) { for (auto& e : engines_) e->set_option(key, value); }
+
+}  // namespace vxh

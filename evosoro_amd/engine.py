@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_create_multi", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_cm_trace", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version"]
@@ -111,6 +111,7 @@ def load_library():
     lib.vxh_convex_hull_volume.argtypes = [ctypes.POINTER(ctypes.c_double), I]
     lib.vxh_convex_hull_volume.restype = D
     lib.vxh_create.argtypes = [ctypes.POINTER(P), I, I]
+    lib.vxh_create_multi.argtypes = [ctypes.POINTER(P), I, ctypes.POINTER(I), I]
     lib.vxh_destroy.argtypes = [P]
     lib.vxh_destroy.restype = None
     lib.vxh_add_vxa_file.argtypes = [P, ctypes.c_char_p, ctypes.POINTER(I)]
@@ -182,9 +183,11 @@ class Engine(object):
     """One population shard on one GPU: add .vxa robots, run them all at once, read results."""
 
     def __init__(self, variant=VOXCAD, device=0):
+        """device: one HIP device index, or a sequence of them (one handle over several GPUs: the batch is partitioned by cost)"""
         self._lib = load_library()
         self._h = ctypes.c_void_p()
-        rc = self._lib.vxh_create(ctypes.byref(self._h), variant, device)
+        devices = [int(device)] if np.isscalar(device) else [int(d) for d in device]
+        rc = self._lib.vxh_create_multi(ctypes.byref(self._h), variant, (ctypes.c_int * len(devices))(*devices), len(devices))
         if rc != 0:
             self._h = ctypes.c_void_p()
             raise VxhError(rc, self._lib.vxh_strerror(rc).decode())

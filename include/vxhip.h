@@ -117,6 +117,11 @@ int  vxh_plan_tiles_buffer(const char* xml, size_t len, int variant, int k_reque
                            char* errbuf, size_t errcap);
 
 int  vxh_create(vxh_engine** out, int variant, int device_id);
+/* One handle over several GPUs of the node: the robots are partitioned over the devices by cost (voxels x
+ * planned steps, largest first) at the first vxh_run / vxh_step after an addition, every device steps its share from its own host
+ * thread, and every other call works on the global robot numbering as with one device.  (The results of one process live in its
+ * host memory: no collective is involved; the RCCL gather belongs to the one-process-per-GPU route, evosoro_amd/parallel.py.) */
+int  vxh_create_multi(vxh_engine** out, int variant, const int* device_ids, int n_devices);
 void vxh_destroy(vxh_engine* e);
 
 int  vxh_add_vxa_file(vxh_engine* e, const char* path, int* robot_index_out);

@@ -397,3 +397,14 @@ if __name__ == "__main__" and "tilenocol" in sys.argv[1:]:
     for t in (0.04, 0.16):
         timing_cfg(engine.VOXCAD, 1, (20, 20, 20), t, Env(), {"tiled": 2, "tiles_per_robot": 125}, full=True, selfcol=False)
         timing_cfg(engine.VOXCAD, 1, (20, 20, 20), t, Env(), {"tiled": 2, "tiles_per_robot": 125}, full=True, selfcol=True)
+
+
+if __name__ == "__main__" and "tileprof" in sys.argv[1:]:
+    # the other BASELINE configs at their stated sizes, engine defaults (what scripts/profile_bench.sh traces)
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.16, Env(), {}, full=True)                                   # configs[4]
+    timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.1, Env(), {})                                                 # configs[1]
+    timing_cfg(engine.VOXCAD, 64, (10, 10, 10), 0.06, Env(), {})                                             # configs[2] as sharded over 8 GPUs
+    timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, {}, per_voxel_phase=True)                # configs[3]

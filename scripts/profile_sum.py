@@ -20,14 +20,34 @@ def counter_per_kernel(sub):
     return tot, n
 
 
+prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+os.makedirs(prof_dir, exist_ok=True)
+if len(sys.argv) > 3:          # `profile_sum.py <out_root> <tag> tiled`: only the per-kernel table of that trace
+    sub = sys.argv[3]
+    dur, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for r in rows(sub, "kernel_trace.csv"):
+        dur[r["Kernel_Name"]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); cnt[r["Kernel_Name"]] += 1
+    total = sum(dur.values()) or 1.0
+    path = os.path.join(prof_dir, "%s_%s_kernel_stats.csv" % (tag, sub))
+    with open(path, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python scripts/dev_gpu_diag.py tileprof (the populations are printed in "
+                "profiles/%s_%s_run.log); durations in ns\n" % (tag, sub))
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+        for k in sorted(dur, key=dur.get, reverse=True):
+            f.write('"%s",%d,%.0f,%.1f,%.2f\n' % (k, cnt[k], dur[k], dur[k] / cnt[k], 100 * dur[k] / total))
+    log = os.path.join(out_root, "prof_%s_%s.log" % (tag, sub))
+    if os.path.exists(log):
+        with open(os.path.join(prof_dir, "%s_%s_run.log" % (tag, sub)), "w") as f:
+            f.write("".join(l for l in open(log) if l.startswith(("variant", "   broad"))))
+    print(open(path).read())
+    sys.exit(0)
+
 dur, cnt = collections.defaultdict(float), collections.defaultdict(int)
 for r in rows("stats", "kernel_trace.csv"):
     dur[r["Kernel_Name"]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); cnt[r["Kernel_Name"]] += 1
-prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
-os.makedirs(prof_dir, exist_ok=True)
 total = sum(dur.values()) or 1.0
 with open(os.path.join(prof_dir, "%s_bench_kernel_stats.csv" % tag), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (N=1); durations in ns\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-other-configs (N=1); durations in ns\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
     for k in sorted(dur, key=dur.get, reverse=True):
         f.write('"%s",%d,%.0f,%.1f,%.2f\n' % (k, cnt[k], dur[k], dur[k] / cnt[k], 100 * dur[k] / total))
@@ -37,7 +57,7 @@ write, wn = counter_per_kernel("write")
 cf, _ = counter_per_kernel("calfetch")
 cw, _ = counter_per_kernel("calwrite")
 cal_bytes = float((1 << 28) * 8)
-info = {"command": "python bench.py --no-cpu-baseline", "dominant_kernel": dom,
+info = {"command": "python bench.py --no-cpu-baseline --no-other-configs", "dominant_kernel": dom,
         "units_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-like units of 1024 B per count on this image; "
                       "raw counter sums are stored, bytes = raw * 1024"}
 if dom:
