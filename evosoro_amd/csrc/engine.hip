@@ -315,6 +315,23 @@ void Engine::clear()
 {
     HIP_OK(hipSetDevice(device_id_));
 #ifdef VXH_PHASE_TIMING
+    if (std::getenv("VXH_COL_STATS") && dev_->B.col_rows > 0) {    // lengths of the contact rows as the last broad-phase runs left them
+        std::vector<int> cnt(dev_->B.col_rows);
+        HIP_OK(hipMemcpy(cnt.data(), dev_->B.col_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+        long long hist[9] = {0}, total = 0; int mx = 0;
+        for (int c : cnt) { total += c; mx = std::max(mx, c); ++hist[c == 0 ? 0 : std::min(8, 1 + (c - 1) / 8)]; }
+        fprintf(stderr, "contact rows: %zu surface voxels, %.1f partners on average, longest %d; rows by length 0 | 1-8 | 9-16 | ... | 57-64:", cnt.size(), (double)total / cnt.size(), mx);
+        for (long long v : hist) fprintf(stderr, " %lld", v);
+        long long per_robot_max = 0, wave_max_sum = 0, waves = 0;
+        for (size_t r = 0; r < robots_.size(); ++r) {
+            long long sum = 0;
+            const int b = dev_->surf_begin[r], n = robots_[r].nsurf;
+            for (int i = 0; i < n; ++i) sum += cnt[b + i];
+            per_robot_max = std::max(per_robot_max, sum);
+        }
+        fprintf(stderr, "\n  most partners in one robot: %lld\n", per_robot_max);
+        (void)wave_max_sum; (void)waves;
+    }
     if (dev_->B.prof) {
         unsigned long long h[16 * 8 + 256 * 8];
         HIP_OK(hipMemcpy(h, dev_->B.prof, sizeof(h), hipMemcpyDeviceToHost));
@@ -667,6 +684,13 @@ void Engine::prepare()
         const int tabg = need(nacc, true) > lds_max ? 1 : 0;
         if (need(nacc, !tabg) > lds_max) return fv;                   // (e.g. a mesh with thousands of vertices)
         fv.block = block; fv.nacc = nacc; fv.fluid = fluid; fv.tabg = tabg; fv.lds = need(nacc, !tabg);
+        // colliding robots: what the workgroup can spare without lowering the number of workgroups a CU holds (two of the 256-thread
+        // variant, by its registers; one of the others) takes the contact rows, 12 bytes per listed pair
+        if (M.vxa.self_col_enabled) {
+            const size_t room = (block == 256 ? (size_t)80 * 1024 - VXH_FUSED_STATIC_LDS : lds_max);
+            if (room > fv.lds) fv.lds += std::min<size_t>(room - fv.lds, (size_t)24 * 1024);
+        }
+        fv.lds &= ~(size_t)7;
         return fv;
     };
     // Tiled kernel (kernels_tiled.hpp), several workgroups per robot: for robots the resident kernel cannot take, and for
@@ -866,7 +890,7 @@ static void launch_variant(const DBatch& B, const int* list, int count, size_t l
 {
     static size_t granted[64] = {};
     grant_dynamic_lds((const void*)k_robot_steps<BLOCK, NACC, FLUID, TABG>, granted, lds);
-    hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters);
+    hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
 }
 
 template <bool TABG>

@@ -173,6 +173,31 @@ __device__ __forceinline__ double vacos(double x)
     return 1.5707963267948966 - (x + __builtin_fma(x, p, -6.123233995736766e-17));
 }
 
+// max of a non-negative double over the 64 lanes of a (fully active) wavefront, returned in every lane: four DPP row shifts, two
+// row broadcasts (VALU speed; a shuffle through the LDS crossbar costs ten times as much per stage, an LDS atomic on one address
+// serialises its 64 lanes)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_stage(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    const double o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));     // 0.0 where no lane feeds this one
+    return o > v ? o : v;
+}
+__device__ __forceinline__ double wave_max_nonneg(double v)
+{
+    v = dpp_max_stage<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_max_stage<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_max_stage<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_max_stage<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row of 16 holds the row's maximum
+    v = dpp_max_stage<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_max_stage<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 #define VXH_PI 3.14159265358979
 #define VXH_DISCARD_ANGLE_RAD 1e-7
 #define VXH_SMALL_ANGLE_RAD 1.732e-2

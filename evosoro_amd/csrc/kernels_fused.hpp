@@ -27,7 +27,7 @@
 
 namespace vxh {
 
-enum { VXH_FUSED_STATIC_LDS = 320 };      // upper bound of the kernel's static __shared__ variables
+enum { VXH_FUSED_STATIC_LDS = 448 };      // upper bound of the kernel's static __shared__ variables
 
 // developer instrumentation (scripts/dev_gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
 // of the phases of a step
@@ -406,13 +406,76 @@ __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, co
     if (has) fused_accumulate<BLOCK, A == 0 && NACC == 2>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
 }
 
-struct FusedCtl { double time, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild, damp_on, trace, trace_index, pad; };
+// Contact forces of my voxel (the head of voxel_update: same arithmetic, same order), in two passes over the wavefront's segment
+// of the workgroup's LDS copy of the contact rows (`seg`, `nseg` pairs: the rows of its lanes one after the other).  Contact rows
+// are short and very uneven (most hold none or one partner, a few a dozen) and nearly all listed pairs are out of reach, so
+//   pass 1  the lanes share the wavefront's pairs evenly: reach test of pair p (CalcContactForce's cheap reject, the same
+//           arithmetic), a bit in the owner's mask for the pairs in reach;
+//   pass 2  every lane adds the forces of its pairs in reach, in list order (the order the reference adds its collision bonds).
+// A pair: partner | owner << 10 | place in the owner's row << 20 (rc_code), pair stiffness (rc_a1).  `rowd`: partner count |
+// (start of my row in the copy + 1) << 7; a wavefront whose rows did not fit (nseg < 0) reads them from memory.
+template <int BLOCK>
+__device__ __forceinline__ void fused_contact_reach(const double* ps, int seg, int nseg, unsigned long long* mask, const int* rc_code)
+{
+    for (int p = (int)(threadIdx.x & 63); p < nseg; p += 64) {
+        const int code = rc_code[seg + p];
+        const int l2 = code & 1023, l1 = (code >> 10) & 1023;
+        const d3 d = mk3(ps[l2] - ps[l1], ps[BLOCK + l2] - ps[BLOCK + l1], ps[2 * BLOCK + l2] - ps[2 * BLOCK + l1]);
+        const double nom = (ps[3 * BLOCK + l2] + ps[3 * BLOCK + l1]) * 0.75;
+        if (len2(d) < nom * nom) atomicOr(&mask[l1], 1ull << ((unsigned)code >> 20));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (LDS of one wavefront: in order; this keeps the compiler from moving the reads up)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int BLOCK>
+__device__ __forceinline__ d3 fused_contact_forces(const DBatch& B, const DRobot& R, const double* ps, d3 F, d3 pos, double scale, int self, int v, int rowd,
+                                                   unsigned long long* mask, const int* rc_code, const double* rc_a1)
+{
+    if ((rowd >> 7) != 0) {                    // my row is in the LDS copy
+        unsigned long long m = mask[self];
+        if (m) {
+            mask[self] = 0;
+            const int roff = (rowd >> 7) - 1;
+            do {
+                const int k = __builtin_ctzll(m);
+                m &= m - 1;
+                const int q = rc_code[roff + k] & 1023;
+                F = contact_force_add(F, pos, scale, ps[q], ps[BLOCK + q], ps[2 * BLOCK + q], ps[3 * BLOCK + q], rc_a1[roff + k]);
+            } while (m);
+        }
+        return F;
+    }
+    const int ccnt = rowd & 127;
+    const int row = R.surf_begin + B.surf_ord[v];
+    for (int k0 = 0; k0 < ccnt; k0 += 2) {
+        int l[2]; double a1[2], qx[2], qy[2], qz[2], qs[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool on = k0 + j < ccnt;
+            const size_t at = (size_t)(k0 + j) * B.col_rows + row;   // partner-major: coalesced across the wave
+            l[j] = on ? B.col_partner[at] - R.vox_begin : -1;
+            a1[j] = on ? B.col_a1[at] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int q = l[j] < 0 ? self : l[j]; qx[j] = ps[q]; qy[j] = ps[BLOCK + q]; qz[j] = ps[2 * BLOCK + q]; qs[j] = ps[3 * BLOCK + q]; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) if (l[j] >= 0) F = contact_force_add(F, pos, scale, qx[j], qy[j], qz[j], qs[j], a1[j]);
+    }
+    return F;
+}
+
+// `flags`: go | latch << 1 | eol << 2 | rebuild << 3 | trace << 4 | damp_on << 5 -- the resident kernel reads the step's decisions with one
+// LDS access instead of a chain of them
+struct FusedCtl { double time, act_sin, act_cos, prenatal_c; int go, latch, eol, rebuild, damp_on, trace, trace_index, flags; };
 
 __device__ __forceinline__ void fused_control_begin(const DRobot& R, DRobotState& rs, long long step_cap, int begin_new_step, FusedCtl& K)
 {
     const StepCtl c = step_control_begin(R, rs, step_cap, begin_new_step);
     K.go = c.go; K.latch = c.latch; K.eol = c.eol; K.rebuild = 0; K.trace = c.trace; K.trace_index = c.trace_index;
     K.time = rs.cur_time; K.damp_on = rs.dt_prev != 0;
+    K.flags = (c.go ? 1 : 0) | (c.latch ? 2 : 0) | (c.eol ? 4 : 0) | (c.trace ? 16 : 0) | (K.damp_on ? 32 : 0);
     K.prenatal_c = actuation_prenatal_c(R, rs.cur_time);
     K.act_sin = K.act_cos = 0;
     if (c.go) actuation_sincos(R, rs.cur_time, K.act_sin, K.act_cos);
@@ -422,12 +485,14 @@ __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotSta
     StepCtl c; c.go = K.go; c.latch = c.eol = c.rebuild = c.trace = c.trace_index = 0;
     step_control_horizon(R, rs, c, dt_prev);
     K.rebuild = c.rebuild;
+    if (c.rebuild) K.flags |= 8;
 }
 __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K) { fused_control_horizon(R, rs, K, rs.dt_prev); }
 
 template <int BLOCK, int NACC, bool MESH, bool TABG>
 __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const DRobot* __restrict__ robots,
-                                                                            const int* __restrict__ robot_list, long long step_cap, int iters)
+                                                                            const int* __restrict__ robot_list, long long step_cap, int iters,
+                                                                            int lds_doubles)
 {
     extern __shared__ __align__(16) double lds[];
     double* const ps = lds;
@@ -444,8 +509,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // still in the voxel phase of step n (it idles at the barrier otherwise); only the collision-horizon decision,
     // which needs every voxel's new velocity, stays between the barriers
     __shared__ FusedCtl s_ctl[2];
-    __shared__ int s_div;
-    static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + sizeof(int) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
+    __shared__ int s_div, s_pool, s_seg[2 * (BLOCK / 64)];
+    static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + 2 * sizeof(int) + 2 * 16 * sizeof(int) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
     const int r = __builtin_amdgcn_readfirstlane(robot_list[blockIdx.x]);   // robots of one launch group, longest-running first; uniform -> scalar loads of R
@@ -476,6 +541,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     double* const st = STRAIN_LDS ? tabs + nbd + nvd : B.strain + R.vox_begin;
     const unsigned st_stride = STRAIN_LDS ? (unsigned)BLOCK : nv;
     double* const mesh = tabs + nbd + nvd + (STRAIN_LDS ? 6 * BLOCK : 0);
+    // what is left of the dynamic LDS (lds_doubles in all) holds the contact rows of colliding robots: a mask per voxel (fused_contacts),
+    // then the pairs: stiffnesses, codes
+    unsigned long long* const cmask = (unsigned long long*)(mesh + ((MESH && (R.flags & RF_FLUID)) ? 3 * R.nmv : 0));
+    double* const rc_a1 = (double*)cmask + BLOCK;
+    const int pool_cap = ((R.flags & RF_SELF_COL) && !VXH_DBG(4)) ? max(0, (int)((lds_doubles - (int)(rc_a1 - lds)) * 2 / 3) - 1) : 0;
+    int* const rc_code = (int*)(rc_a1 + pool_cap);
     if constexpr (STRAIN_LDS) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) st[k * BLOCK + tid] = tid < R.nvox ? B.strain[(unsigned)k * nv + (unsigned)(R.vox_begin + tid)] : 0.0;
@@ -486,7 +557,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     const DVoxClass& C = vct[valid ? B.vclass[v] : 0];
     int entry[3];                             // my bond of each axis round (DBatch::blist), -1 = none
     unsigned modebits = 0;                    // 2 bits per bond: SmallAngle, history layout (DBatch::hist)
-    int row = -1;                             // my row of collision partners (surface voxels of colliding robots)
     float amp_damp = 1.f;
     d3 lm = mk3(0, 0, 0), am = mk3(0, 0, 0);
 #pragma unroll
@@ -496,7 +566,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     }
     if (valid) {
         const int b0 = rs.steps & 1;
-        if (R.flags & RF_SELF_COL) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
         amp_damp = B.amp_damp[v];
         if constexpr (!SLIM) { pht[tid] = B.act_sb[v]; pht[BLOCK + tid] = B.act_cb[v]; }
         lm = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v));
@@ -509,36 +578,71 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     const FetchLds<BLOCK> fetch{ps, base};
     DragCache<BLOCK> dcache;
     if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) dcache.load(B, R, tid); }
-    int ccnt = 0;                             // number of collision partners of my voxel (refreshed after a broad-phase run)
+    // my contact row: partner count | (start of the workgroup's LDS copy of it + 1) << 7; s_seg: where the rows of each wavefront's
+    // lanes start in the copy and how many pairs they hold (-1: they did not fit, that wavefront reads its rows from memory).
+    // Refreshed after every broad-phase run.  (every thread calls: barriers inside)
+    int rowd = 0;
+    auto rows_to_lds = [&]() {
+        rowd = 0;
+        if (!(R.flags & RF_SELF_COL)) return;
+        int row = -1;
+        if (valid) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
+        const int ccnt = (row >= 0 && !VXH_DBG(1)) ? B.col_cnt[row] : 0;
+        if (tid == 0) s_pool = 0;
+        if (pool_cap > 0) cmask[tid] = 0;
+        __syncthreads();
+        int incl = ccnt;                      // places in the copy: prefix sum within the wavefront, one atomic per wavefront
+        const int lane = tid & 63;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const int wave_total = __shfl(incl, 63);
+        int wave_base = 0;
+        if (lane == 63 && wave_total > 0) wave_base = atomicAdd(&s_pool, wave_total);
+        wave_base = __shfl(wave_base, 63);
+        const bool fits = wave_base + wave_total <= pool_cap;
+        if (lane == 0) { s_seg[2 * (tid >> 6)] = wave_base; s_seg[2 * (tid >> 6) + 1] = fits ? wave_total : -1; }
+        const int off = wave_base + incl - ccnt;
+        rowd = ccnt;
+        if (fits && ccnt > 0) {
+            rowd = ccnt | ((off + 1) << 7);
+            for (int k = 0; k < ccnt; ++k) {
+                const size_t at = (size_t)k * B.col_rows + row;
+                rc_code[off + k] = (B.col_partner[at] - base) | (tid << 10) | (k << 20);
+                rc_a1[off + k] = B.col_a1[at];
+            }
+        }
+        __syncthreads();
+    };
 
     // the control thread sits in the LAST wave: the one with the fewest (often no) voxels, so its serial work hides
     // behind the other waves' voxel phase
     const bool ctl_thread = tid == BLOCK - 64;
     if (ctl_thread) { fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]); fused_control_horizon(R, rs, s_ctl[0]); s_div = 0; }
+    rows_to_lds();
     __syncthreads();                           // control of the first step + every voxel's pose visible
     VXH_T_DECL
     for (int it = 0;; ++it) {
         const FusedCtl& K = s_ctl[it & 1];
         FusedCtl& Knext = s_ctl[(it + 1) & 1];
-        if (!K.go && !K.trace) break;
+        const int kf = __builtin_amdgcn_readfirstlane(K.flags);
+        const bool k_go = kf & 1, k_latch = kf & 2, k_eol = kf & 4, k_rebuild = kf & 8, k_trace = kf & 16;
+        if (!k_go && !k_trace) break;
         // opaque per-step copies: keeps the compiler from hoisting every address of the step out of the loop (dozens of
         // loop-invariant 64-bit pointers, which it then spills)
-        int vv = v, rowv = row;
-        asm volatile("" : "+v"(vv), "+v"(rowv));
+        int vv = v;
+        asm volatile("" : "+v"(vv));
         bool scratch_used = false;            // latch / broad-phase borrow the accumulator tile
-        if (K.latch || K.eol || K.trace) {
-            fused_latch_cm<BLOCK>(R, rs, ps, acc, valid, C, K.latch != 0, K.eol != 0, K.trace != 0, B.trace + (size_t)(R.trace_begin + K.trace_index) * 4);
+        if (k_latch || k_eol || k_trace) {
+            fused_latch_cm<BLOCK>(R, rs, ps, acc, valid, C, k_latch, k_eol, k_trace, B.trace + (size_t)(R.trace_begin + K.trace_index) * 4);
             scratch_used = true;
         }
-        if (!K.go) break;                      // (the robot has stopped; the last step's trace point, if one was due, is in)
-        if (K.rebuild) { fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct); scratch_used = true; }
+        if (!k_go) break;                      // (the robot has stopped; the last step's trace point, if one was due, is in)
+        if (k_rebuild) { fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct); rows_to_lds(); scratch_used = true; }
         if (scratch_used) { acc[tid] = 0.0; __syncthreads(); }
-        // the partner count only changes when the broad-phase ran; no global load sits at the head of the step's queue
-        if (K.rebuild || it == 0) ccnt = (rowv >= 0 && !VXH_DBG(1)) ? B.col_cnt[rowv] : 0;
         d3 drag = mk3(0, 0, 0);
         const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
         if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK, NACC * 6 * BLOCK>(B, R, ps, st, st_stride, mesh, acc, valid, vv, lm, C.mass_inv, dcache); }
-        const bool damp_on = K.damp_on != 0;
+        const bool damp_on = (kf & 32) != 0;
         VXH_T_MARK(1)
 
         // ---- bond phase: three axis rounds over the compacted bond lists
@@ -562,6 +666,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // registers; contact partners from the pose tile
         double vel2 = 0;
         VoxState S;
+        if (R.flags & RF_SELF_COL) {
+            const int nseg = s_seg[2 * (tid >> 6) + 1];     // pairs in the LDS copy of my wavefront's contact rows (-1: the rows are read from memory)
+            if (nseg > 0) fused_contact_reach<BLOCK>(ps, s_seg[2 * (tid >> 6)], nseg, cmask, rc_code);   // every lane: the wavefront shares the pairs
+        }
         if (valid) {
             d3 F = mk3(acc[tid], acc[BLOCK + tid], acc[2 * BLOCK + tid]), M = mk3(acc[3 * BLOCK + tid], acc[4 * BLOCK + tid], acc[5 * BLOCK + tid]);
             if constexpr (NACC == 2) {
@@ -575,14 +683,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             S.lm = lm; S.am = am;
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
-            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, rowv, ccnt, fluid, drag,
+            if (rowd != 0) F = fused_contact_forces<BLOCK>(B, R, ps, F, S.pos, S.scale, tid, vv, rowd, cmask, rc_code, rc_a1);
+            vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, -1, 0, fluid, drag,
                                 SLIM ? B.act_sb[vv] : pht[tid], SLIM ? B.act_cb[vv] : pht[BLOCK + tid], amp_damp);
             lm = S.lm; am = S.am;
         }
         if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
         if ((R.flags & RF_SELF_COL) && !VXH_DBG(2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { double o2 = __shfl_xor(vel2, off); vel2 = o2 > vel2 ? o2 : vel2; }
+            vel2 = wave_max_nonneg(vel2);       // (DPP: VALU speed)
             if ((tid & 63) == 0) atomicMax(&rs.maxvel2_bits, (unsigned long long)__double_as_longlong(vel2));
         }
         VXH_T_MARK(4)

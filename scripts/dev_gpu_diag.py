@@ -408,3 +408,10 @@ if __name__ == "__main__" and "tileprof" in sys.argv[1:]:
     timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.1, Env(), {})                                                 # configs[1]
     timing_cfg(engine.VOXCAD, 64, (10, 10, 10), 0.06, Env(), {})                                             # configs[2] as sharded over 8 GPUs
     timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, {}, per_voxel_phase=True)                # configs[3]
+
+
+if __name__ == "__main__" and "ab" in sys.argv[1:]:      # A/B of the resident kernel on the bench population: time, or (phases) shares
+    timing2(8, (10, 10, 10), 0.002, True, {"tiled": 0})          # (the first launch of a process loads the code object: ~3 ms)
+    for _ in range(2):
+        timing2(512, (10, 10, 10), 0.03, True, {"tiled": 0})
+        timing2(512, (10, 10, 10), 0.03, False, {"tiled": 0})
