@@ -345,6 +345,8 @@ void Engine::clear()
                 fprintf(stderr, "\n");
             }
         }
+        if (h[112]) fprintf(stderr, "contact rows in LDS: %llu wavefront copies, %llu did not fit (mean capacity %.0f pairs); cross-check (dbg 8): %llu lanes, %llu with different bits, %llu whose LDS row differs from memory; of the differing lanes: %llu with fewer mask bits than pairs in reach, %llu with more, %llu with as many\n",
+                            h[112], h[113], h[114] ? (double)h[114] * 12.0 / (double)h[112] : 0.0, h[115], h[116], h[117], h[118], h[119], h[111]);
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
         static const char* tnames[8] = {"halo-wait", "bond", "svc:poll", "barB", "latch/rebuild", "voxel", "barC+mv", "svc:reduce+horizon"};
         const bool tiled = !dev_->tile_launches.empty();

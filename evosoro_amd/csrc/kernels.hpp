@@ -448,18 +448,34 @@ struct VoxState { d3 pos, lm, am; dq ang; double scale; };
 // CalcContactForce (VXS_BondCollision.cpp:41-59) of one listed partner at (qx, qy, qz), scale qs, on the voxel at `pos`: Force2 =
 // unit(p2 - p1) * a1 * overlap on Vox2 (the later surface voxel), -Force2 on Vox1.  Seen from this voxel that is
 // -unit(partner - me) * a1 * overlap in both roles, bit for bit (negation is exact, the sums commute).
+// The function is inlined into every stepping kernel (resident: LDS rows and rows in memory; tiled; streaming); its roundings are
+// pinned -- every product and sum rounded on its own, like the reference's x86-64 build, which has no fused multiply-add -- so
+// that all of these sites produce the same bits: with contraction left to the compiler two sites of one kernel came out differently
+// (measured: scripts/dev_gpu_diag.py contactcheck).  contact_in_reach is the reject test alone (resident kernel, pass 1).
+#pragma clang fp contract(off)
+__device__ __forceinline__ bool contact_in_reach(double dx, double dy, double dz, double nom)
+{
+    const double d2 = (dx * dx + dy * dy) + dz * dz;
+    return d2 < nom * nom;
+}
 __device__ __forceinline__ d3 contact_force_add(d3 F, d3 pos, double scale, double qx, double qy, double qz, double qs, double a1)
 {
-    const d3 d = mk3(qx - pos.x, qy - pos.y, qz - pos.z);
+    const double dx = qx - pos.x, dy = qy - pos.y, dz = qz - pos.z;
     const double nom = (qs + scale) * 0.75;
-    const double d2 = len2(d);
+    const double d2 = (dx * dx + dy * dy) + dz * dz;
     if (d2 < nom * nom) {                                  // cheap reject: most listed partners are out of reach
         const double l = vsqrt_nn(d2);
         const double reld = nom - l;
-        if (reld > 0) F = F - ((d * vrcp(l)) * a1) * reld;
+        if (reld > 0) {
+            const double il = vrcp(l);
+            F.x = F.x - ((dx * il) * a1) * reld;
+            F.y = F.y - ((dy * il) * a1) * reld;
+            F.z = F.z - ((dz * il) * a1) * reld;
+        }
     }
     return F;
 }
+#pragma clang fp contract(fast)
 
 // position + scale of another voxel of the same robot, for the contact forces
 struct FetchGlobal {       // streaming path: previous-step buffer in HBM

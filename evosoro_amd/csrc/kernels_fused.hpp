@@ -420,9 +420,9 @@ __device__ __forceinline__ void fused_contact_reach(const double* ps, int seg, i
     for (int p = (int)(threadIdx.x & 63); p < nseg; p += 64) {
         const int code = rc_code[seg + p];
         const int l2 = code & 1023, l1 = (code >> 10) & 1023;
-        const d3 d = mk3(ps[l2] - ps[l1], ps[BLOCK + l2] - ps[BLOCK + l1], ps[2 * BLOCK + l2] - ps[2 * BLOCK + l1]);
         const double nom = (ps[3 * BLOCK + l2] + ps[3 * BLOCK + l1]) * 0.75;
-        if (len2(d) < nom * nom) atomicOr(&mask[l1], 1ull << ((unsigned)code >> 20));
+        if (contact_in_reach(ps[l2] - ps[l1], ps[BLOCK + l2] - ps[BLOCK + l1], ps[2 * BLOCK + l2] - ps[2 * BLOCK + l1], nom))
+            atomicOr(&mask[l1], 1ull << ((unsigned)code >> 20));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (LDS of one wavefront: in order; this keeps the compiler from moving the reads up)
     __builtin_amdgcn_wave_barrier();
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // still in the voxel phase of step n (it idles at the barrier otherwise); only the collision-horizon decision,
     // which needs every voxel's new velocity, stays between the barriers
     __shared__ FusedCtl s_ctl[2];
-    __shared__ int s_div, s_pool, s_seg[2 * (BLOCK / 64)];
+    __shared__ int s_div, s_seg[2 * (BLOCK / 64)];
     static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + 2 * sizeof(int) + 2 * 16 * sizeof(int) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
@@ -588,7 +588,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         int row = -1;
         if (valid) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
         const int ccnt = (row >= 0 && !VXH_DBG(1)) ? B.col_cnt[row] : 0;
-        if (tid == 0) s_pool = 0;
         if (pool_cap > 0) cmask[tid] = 0;
         __syncthreads();
         int incl = ccnt;                      // places in the copy: prefix sum within the wavefront, one atomic per wavefront
@@ -596,11 +595,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
         const int wave_total = __shfl(incl, 63);
+        // the wavefronts' segments follow each other in wavefront order: which rows fit (and which are read from memory) must not
+        // depend on who got there first, the two paths need not round alike
+        if (lane == 0) s_seg[2 * (tid >> 6) + 1] = wave_total;
+        __syncthreads();
         int wave_base = 0;
-        if (lane == 63 && wave_total > 0) wave_base = atomicAdd(&s_pool, wave_total);
-        wave_base = __shfl(wave_base, 63);
+        for (int w = 0; w < (tid >> 6); ++w) wave_base += s_seg[2 * w + 1];
+        __syncthreads();                      // (s_seg is rewritten below)
         const bool fits = wave_base + wave_total <= pool_cap;
         if (lane == 0) { s_seg[2 * (tid >> 6)] = wave_base; s_seg[2 * (tid >> 6) + 1] = fits ? wave_total : -1; }
+#ifdef VXH_PHASE_TIMING
+        if (B.prof && lane == 0) { atomicAdd(&B.prof[112], 1ull); if (!fits) atomicAdd(&B.prof[113], 1ull); if (tid == 0) atomicAdd(&B.prof[114], (unsigned long long)pool_cap); }
+#endif
         const int off = wave_base + incl - ccnt;
         rowd = ccnt;
         if (fits && ccnt > 0) {
@@ -683,7 +689,38 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             S.lm = lm; S.am = am;
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
+#ifdef VXH_PHASE_TIMING
+            const d3 F_before = F;
+            const unsigned long long mask_seen = ((rowd >> 7) != 0) ? cmask[tid] : 0ull;     // what pass 2 is about to consume
+#endif
             if (rowd != 0) F = fused_contact_forces<BLOCK>(B, R, ps, F, S.pos, S.scale, tid, vv, rowd, cmask, rc_code, rc_a1);
+#ifdef VXH_PHASE_TIMING
+            if (VXH_DBG(8) && B.prof && (rowd >> 7) != 0) {     // the same sum through the rows in memory: must give the same bits
+                const d3 G = fused_contact_forces<BLOCK>(B, R, ps, F_before, S.pos, S.scale, tid, vv, rowd & 127, cmask, rc_code, rc_a1);
+                atomicAdd(&B.prof[115], 1ull);
+                if (!(G.x == F.x && G.y == F.y && G.z == F.z)) {
+                    atomicAdd(&B.prof[116], 1ull);
+                    // pairs of my row in reach by CalcContactForce's own test, against the bits pass 1 set for me
+                    int reach = 0;
+                    const int crow0 = R.surf_begin + B.surf_ord[vv];
+                    for (int k = 0; k < (rowd & 127); ++k) {
+                        const int q = B.col_partner[(size_t)k * B.col_rows + crow0] - base;
+                        if (contact_in_reach(ps[q] - S.pos.x, ps[BLOCK + q] - S.pos.y, ps[2 * BLOCK + q] - S.pos.z, (ps[3 * BLOCK + q] + S.scale) * 0.75)) ++reach;
+                    }
+                    const int bits = __builtin_popcountll(mask_seen);
+                    atomicAdd(&B.prof[bits < reach ? 118 : (bits > reach ? 119 : 111)], 1ull);
+                }
+                // is the LDS copy of my row what memory holds now?  (partner and stiffness of every entry, bit for bit)
+                const int crow = R.surf_begin + B.surf_ord[vv], coff = (rowd >> 7) - 1;
+                bool same = true;
+                for (int k = 0; k < (rowd & 127); ++k) {
+                    const size_t at = (size_t)k * B.col_rows + crow;
+                    same = same && (rc_code[coff + k] & 1023) == B.col_partner[at] - base && rc_a1[coff + k] == B.col_a1[at];
+                }
+                if (B.col_cnt[crow] != (rowd & 127)) same = false;
+                if (!same) atomicAdd(&B.prof[117], 1ull);
+            }
+#endif
             vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, -1, 0, fluid, drag,
                                 SLIM ? B.act_sb[vv] : pht[tid], SLIM ? B.act_cb[vv] : pht[BLOCK + tid], amp_damp);
             lm = S.lm; am = S.am;

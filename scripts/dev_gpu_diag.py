@@ -415,3 +415,26 @@ if __name__ == "__main__" and "ab" in sys.argv[1:]:      # A/B of the resident k
     for _ in range(2):
         timing2(512, (10, 10, 10), 0.03, True, {"tiled": 0})
         timing2(512, (10, 10, 10), 0.03, False, {"tiled": 0})
+
+
+if __name__ == "__main__" and "contactcheck" in sys.argv[1:]:
+    # Resident kernel, developer library: (1) two identical runs of a colliding 10x10x10 robot must agree bit for bit at every checkpoint;
+    # (2) with dbg = 8 every lane whose contact row is in LDS recomputes its contact sum through the rows in memory -- the library prints
+    # how many lanes got different bits (must be 0), and whether the wavefronts that did not fit were the same ones in both runs.
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "vxa", "bench10_0.vxa")
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    for dbg in (8, 0):
+        runs = []
+        for _ in range(2):
+            states = []
+            with engine.Engine(engine.VOXCAD, 0) as eng:
+                eng.set_option("tiled", 0)
+                eng.set_option("dbg", dbg)
+                eng.add_vxa_file(golden)
+                for k in (1, 332, 2000, 100000):
+                    eng.step(k)
+                    states.append(eng.state(0))
+                eng.clear()
+            runs.append(states)
+        same = [bool(np.array_equal(a, b)) for a, b in zip(*runs)]
+        print("dbg", dbg, "two runs bit-identical at the checkpoints:", same, flush=True)
