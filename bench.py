@@ -20,7 +20,12 @@ N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak
 The JSON line also carries
   roofline      HBM: algorithmic bytes (224*Nvox + 144*Nbond per voxel-step) of the dominant kernel over its
                 HIP-event time, in GB/s against the 8 TB/s peak; `traffic` = what the PMC counters saw for the same kernel on
-                this workload (newest profiles/r*_hbm_traffic.json), also in GB/s -- rates, comparable whatever the launch length
+                this workload (newest profiles/r*_hbm_traffic.json), also in GB/s -- rates, comparable whatever the launch length.
+                `traffic` counts the L2's MEMORY-SIDE requests (FETCH_SIZE / WRITE_SIZE; Infinity-Cache hits included), i.e. an
+                upper bound of the HBM bytes, and it lies far BELOW `achieved`: the bond history of the robots resident on an
+                XCD fits its L2 (hit rate 0.95, profiles/r02_l2_counters.txt), so most algorithmic bytes never leave the chip.
+                `achieved / peak` is therefore not a statement that the kernel is HBM-bound -- it is bound by FP64 issue
+                (DESIGN.md section 4).
   other_configs the other BASELINE configs at their stated sizes (64 x 6^3 walkers, 64 x 8^3 swimmers, one 20^3 lattice),
                 N = 1 only: value, us per step, algorithmic roofline fraction, kernel
   cpu_baseline  the reference C++ voxelyze (oracle/_ref/voxelyze_ref, built from the reference sources) on this box's host
@@ -124,7 +129,8 @@ def cpu_baseline(shape):
 
 
 def measured_traffic(robots_per_gpu, lattice):
-    """HBM GB/s the dominant kernel really moved, from the newest rocprofv3 counter summary under profiles/
+    """GB/s between the L2 and the memory side (an upper bound of the HBM GB/s: Infinity-Cache hits are counted) that the dominant
+    kernel really moved, from the newest rocprofv3 counter summary under profiles/
     (scripts/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes over this same command; FETCH_SIZE scaled by
     the calibration kernels of the same passes).  PMC counters cannot be read from inside this process, so the figure is
     only reported for the profiled workload; it is a RATE (bytes of a launch over that launch's duration in the profile)."""
@@ -141,7 +147,8 @@ def measured_traffic(robots_per_gpu, lattice):
     nbytes = t["fetch_raw_per_launch"] * 1024.0 * fetch_scale + t["write_raw_per_launch"] * 1024.0 * write_scale
     return {"traffic": nbytes / t["avg_launch_ns"],
             "traffic_source": os.path.relpath(files[-1], REPO) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                              "command; FETCH x%.2f, WRITE x%.2f from the calibration kernels)" % (fetch_scale, write_scale)}
+                              "command; FETCH x%.2f, WRITE x%.2f from the calibration kernels; L2 memory-side bytes incl. Infinity-Cache hits = "
+                              "upper bound of HBM bytes)" % (fetch_scale, write_scale)}
 
 
 def kernel_name(block):
@@ -321,7 +328,9 @@ def main():
                              "avg_launch_ms": dom_seconds / max(1, c1.dominant_launches) * 1e3,
                              "alg_bytes_per_voxel_step": c1.dominant_alg_bytes / max(1.0, c1.dominant_voxel_steps),
                              "note": "achieved = (224*Nvox + 144*Nbond) bytes per voxel-step x steps / HIP-event time of "
-                                     "the dominant kernel on its stream; achieved and traffic are both rates (GB/s)"},
+                                     "the dominant kernel on its stream; achieved and traffic are both rates (GB/s); traffic << "
+                                     "achieved because the resident robots' bond history is served by the L2 (hit rate 0.95): the "
+                                     "kernel is FP64-issue-bound, not HBM-bound"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,
             }

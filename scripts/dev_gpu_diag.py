@@ -438,3 +438,7 @@ if __name__ == "__main__" and "contactcheck" in sys.argv[1:]:
             runs.append(states)
         same = [bool(np.array_equal(a, b)) for a, b in zip(*runs)]
         print("dbg", dbg, "two runs bit-identical at the checkpoints:", same, flush=True)
+
+
+if __name__ == "__main__" and "l2pop" in sys.argv[1:]:      # the bench population for scripts/profile_l2.sh: `l2pop 1` / `l2pop 0` = self-collision on / off
+    timing2(512, (10, 10, 10), 0.03, sys.argv[-1] == "1", {"tiled": 0})

@@ -13,6 +13,16 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ro
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $root/gpurun_out/prof_${tag}_calfetch -- /tmp/calib_stream > $root/gpurun_out/prof_${tag}_calfetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $root/gpurun_out/prof_${tag}_calwrite -- /tmp/calib_stream > $root/gpurun_out/prof_${tag}_calwrite.log 2>&1
 python $root/scripts/profile_sum.py $root/gpurun_out $tag
+# SQ counters of the dominant kernel (instruction mix, VALU activity, waits, LDS bank conflicts): a few counters per pass, each pass
+# with --kernel-trace only; summed per kernel into profiles/<tag>_pmc_sq.txt
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_IFETCH"; do
+    i=$((i+1))
+    timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $root/gpurun_out/prof_${tag}_sq$i -- $BENCH > $root/gpurun_out/prof_${tag}_sq$i.log 2>&1
+done
+python $root/scripts/profile_sum.py $root/gpurun_out $tag sq
 # the other BASELINE configs (multi-workgroup kernel k_tile_steps on the small populations and the 20^3 lattice, resident MESH kernel
 # on the swimmers): kernel trace + stats of scripts/dev_gpu_diag.py tileprof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag}_tiled -- python $root/scripts/dev_gpu_diag.py tileprof > $root/gpurun_out/prof_${tag}_tiled.log 2>&1

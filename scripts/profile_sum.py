@@ -22,6 +22,25 @@ def counter_per_kernel(sub):
 
 prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 os.makedirs(prof_dir, exist_ok=True)
+if len(sys.argv) > 3 and sys.argv[3] == "sq":      # `profile_sum.py <out_root> <tag> sq`: SQ counters summed per kernel over the passes
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    for d in sorted(glob.glob(os.path.join(out_root, "prof_%s_sq*" % tag))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                tot[(r["Kernel_Name"], r["Counter_Name"])] += float(r["Counter_Value"]); n[(r["Kernel_Name"], r["Counter_Name"])] += 1
+    path = os.path.join(prof_dir, "%s_pmc_sq.txt" % tag)
+    with open(path, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc <a few SQ counters per pass> -- python bench.py --no-cpu-baseline --no-other-configs (N=1); "
+                "sums over all dispatches of the kernel in that run\n")
+        for kern in sorted({k for k, _ in tot}, key=lambda k: -sum(v for (kk, _), v in tot.items() if kk == k)):
+            f.write(kern[:110] + "\n")
+            for (kk, c) in sorted(tot):
+                if kk == kern:
+                    f.write("   %-28s %16.0f  (%d dispatches)\n" % (c, tot[(kk, c)], n[(kk, c)]))
+    print("wrote", path)
+    sys.exit(0)
 if len(sys.argv) > 3:          # `profile_sum.py <out_root> <tag> tiled`: only the per-kernel table of that trace
     sub = sys.argv[3]
     dur, cnt = collections.defaultdict(float), collections.defaultdict(int)
