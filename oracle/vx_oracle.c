@@ -11,8 +11,10 @@
  * Paths below abbreviate: VX/ = evosoro/_voxcad/Voxelyze/, LW/ = evosoro/_voxcad_land_water/Voxelyze/.
  * Scope: what evosoro's writer can switch on (App. B of SURVEY.md).  Not restated (all off by default and
  * never written by evosoro/tools/read_write_voxelyze.py): boundary-condition regions, volume effects,
- * plasticity/failure, blending, max-velocity limit, equilibrium mode, growth/development tags,
- * environmental sources, needle-in-haystack, limited floor.
+ * plasticity/failure, blending, max-velocity limit, equilibrium mode, environmental sources, needle-in-haystack,
+ * limited floor, and of the _voxcad development model the velocity-adjusted part (NumTimeStepsInWindow > 0).  The
+ * growth / development tags themselves (InitialVoxelSize, FinalVoxelSize, GrowthTime, StartGrowthTime, FinalPhaseOffset,
+ * FinalTempAmpDamp, MidLifeFreezeTime, MinGrowthTime) ARE restated (SCALE section below).
  */
 #include "vx_oracle.h"
 #include <math.h>
