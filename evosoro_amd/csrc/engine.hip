@@ -370,13 +370,22 @@ void Engine::clear()
     rounds_done_ = 0;
 }
 
+// A captured step graph holds the kernel arguments (the whole DBatch, by value) of the moment it was captured: every option that
+// changes one of them, or which kernels a round consists of, drops it; the next graph-sized call captures afresh.
+void Engine::drop_graph()
+{
+    HIP_OK(hipSetDevice(device_id_));
+    if (dev_->graph_exec) { hipGraphExecDestroy(dev_->graph_exec); dev_->graph_exec = nullptr; }
+    if (dev_->graph) { hipGraphDestroy(dev_->graph); dev_->graph = nullptr; }
+}
+
 void Engine::set_option(const std::string& key, double value)
 {
 #ifdef VXH_PHASE_TIMING
-    if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; }    // physics-skipping what-if switches: developer library only
+    if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; drop_graph(); }    // physics-skipping what-if switches: developer library only
     else
 #endif
-    if (key == "fused") fused_ = value != 0;
+    if (key == "fused") { fused_ = value != 0; drop_graph(); }
     else if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
     else if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); steps_per_launch_ = (int)value; }
     else if (key == "tiled" || key == "tiles_per_robot") {
@@ -385,7 +394,7 @@ void Engine::set_option(const std::string& key, double value)
         if (key == "tiled") { if (value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2"); tiled_ = (int)value; }
         else { if (!(value >= 0 && value <= 4096)) throw std::invalid_argument("tiles_per_robot out of range"); tiles_per_robot_ = (int)value; }
     }
-    else if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); graph_steps_ = (int)value; if (dev_->graph_exec) { hipGraphExecDestroy(dev_->graph_exec); dev_->graph_exec = nullptr; } }
+    else if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); graph_steps_ = (int)value; drop_graph(); }
     else throw std::invalid_argument("unknown option " + key);
 }
 

@@ -48,6 +48,7 @@ public:
     // EngineSet moves robots between the engines of a handle (host-side models only; the batch is rebuilt on the next run)
     std::vector<RobotModel> take_robots();
     void give_robots(std::vector<RobotModel>&& models);
+    void drop_graph();
 
 private:
     struct Device;                             // HIP-side members (engine.hip)

@@ -140,6 +140,39 @@ def test_cli_writes_reference_xml(eng_mod, golden_dir, tmp_path):
         assert [l for l in got_lines if "NormFinalDist" in l] == [l for l in want_lines if "NormFinalDist" in l]
 
 
+def test_options_changed_between_runs_of_one_engine(eng_mod, golden_dir):
+    """A captured step graph holds the kernel arguments of the moment of capture: switching the stepping kernels on ONE engine
+    between runs (streaming with a graph -> resident -> streaming again) must leave nothing stale behind -- the streaming runs
+    before and after equal each other and a fresh engine's, bit for bit."""
+    paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in ("probe6", "rand6_col")]
+
+    def run(eng, fused):
+        eng.set_option("fused", fused)
+        eng.reset()
+        eng.step(400)                       # > graph_steps: the streaming path replays its captured graph
+        return [eng.state(i) for i in range(len(paths))]
+
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 0)
+        eng.set_option("graph_steps", 32)
+        for p in paths:
+            eng.add_vxa_file(p)
+        first = run(eng, 0)
+        resident = run(eng, 1)
+        again = run(eng, 0)
+        eng.set_option("graph_steps", 16)   # a different graph length: captured afresh as well
+        shorter = run(eng, 0)
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 0)
+        eng.set_option("graph_steps", 32)
+        for p in paths:
+            eng.add_vxa_file(p)
+        fresh = run(eng, 0)
+    for a, b, c, d, r in zip(first, again, shorter, fresh, resident):
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
+        assert np.abs(a[:, :8] - r[:, :8]).max() < 1e-12          # (and the two kernels agree, as in the test below)
+
+
 def test_streaming_path_matches_fused_path(eng_mod, golden_dir):
     names = ["probe6", "rand6_col", "soft5_init0"]
     states = {}
