@@ -51,6 +51,17 @@ enum { VXH_FUSED_STATIC_LDS = 448 };      // upper bound of the kernel's static 
 #define VXH_T_SUB(k)
 #endif
 
+// The thread index as a value the compiler cannot see through.  The rare whole-robot passes of a step (CoM latch, broad-phase, the
+// copy of the contact rows) index everything by the thread: taken from threadIdx.x their address arithmetic and lane predicates
+// are invariants of the step loop, get computed once before it and are then held for the whole launch -- in scratch, at 128
+// registers per lane, and reloaded inside the hot phases.  Zero instructions.  Effect: 5-10 registers fewer in the 256-, 512- and
+// 768-thread variants; 512 random 10^3 robots (768 threads), warm, against the code without it on the same box, interleaved
+// (scripts/ab_lib.py): 33.6-33.8 -> 33.2-33.4 us per population step with self-collision, 23.4-23.7 -> 23.2-23.3 without (about 1 %;
+// numbers from different boxes differ by as much and must not be compared).  Not applied to the 1024-thread variant, whose scratch
+// it barely changes (196 -> 192 B: that is peak pressure of the bond / voxel arithmetic at 128 registers per lane).
+template <int BLOCK>
+__device__ __forceinline__ int opaque_tid() { int t = (int)threadIdx.x; if constexpr (BLOCK != 1024) asm volatile("" : "+v"(t)); return t; }
+
 // plane `plane` (of nv doubles) of a SoA array, element at byte offset voff: uniform 64-bit base + 32-bit lane offset
 __device__ __forceinline__ double ld_plane(const double* base, unsigned plane, unsigned nv, unsigned voff)
 {
@@ -66,7 +77,7 @@ template <int BLOCK>
 __device__ __forceinline__ void fused_latch_cm(const DRobot& R, DRobotState& rs, const double* ps, double* sh, bool valid,
                                                const DVoxClass& C, bool latch, bool eol, bool trace, double* trace_entry)
 {
-    const int tid = threadIdx.x;
+    const int tid = opaque_tid<BLOCK>();
     if (valid) sh[tid] = (C.mat == 5) ? -C.mass : C.mass;      // sign marks the material excluded from PosteriorY
     __syncthreads();
     if (tid == 0) {
@@ -90,7 +101,7 @@ template <int BLOCK>
 __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, int* shi,
                                               const DVoxClass* vct)
 {
-    const int tid = threadIdx.x, ns = R.nsurf;
+    const int tid = opaque_tid<BLOCK>(), ns = R.nsurf;
     for (int k = tid; k < ns; k += BLOCK) {      // local voxel index | class of every surface voxel
         const int g = B.surf[R.surf_begin + k];
         shi[k] = (g - R.vox_begin) | ((int)B.vclass[g] << 10);
@@ -585,27 +596,32 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     auto rows_to_lds = [&]() {
         rowd = 0;
         if (!(R.flags & RF_SELF_COL)) return;
+        // (see opaque_tid.  The 1024-thread variant uses the kernel's own index: with a local `tid` re-read from threadIdx.x here -- the
+        // same value -- dense 10^3 robots ran 4-5 % slower, 56.1-56.7 against 53.3-54.5 us per step, same box, interleaved; without it
+        // they run as before, 52.9-53.6 against 53.2-53.5.  Why is not known: the ISA of the two differs by register numbering.)
+        int tid_r = tid;
+        if constexpr (BLOCK != 1024) tid_r = opaque_tid<BLOCK>();
         int row = -1;
         if (valid) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
         const int ccnt = (row >= 0 && !VXH_DBG(1)) ? B.col_cnt[row] : 0;
-        if (pool_cap > 0) cmask[tid] = 0;
+        if (pool_cap > 0) cmask[tid_r] = 0;
         __syncthreads();
         int incl = ccnt;                      // places in the copy: prefix sum within the wavefront, one atomic per wavefront
-        const int lane = tid & 63;
+        const int lane = tid_r & 63;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
         const int wave_total = __shfl(incl, 63);
         // the wavefronts' segments follow each other in wavefront order: which rows fit (and which are read from memory) must not
         // depend on who got there first, the two paths need not round alike
-        if (lane == 0) s_seg[2 * (tid >> 6) + 1] = wave_total;
+        if (lane == 0) s_seg[2 * (tid_r >> 6) + 1] = wave_total;
         __syncthreads();
         int wave_base = 0;
-        for (int w = 0; w < (tid >> 6); ++w) wave_base += s_seg[2 * w + 1];
+        for (int w = 0; w < (tid_r >> 6); ++w) wave_base += s_seg[2 * w + 1];
         __syncthreads();                      // (s_seg is rewritten below)
         const bool fits = wave_base + wave_total <= pool_cap;
-        if (lane == 0) { s_seg[2 * (tid >> 6)] = wave_base; s_seg[2 * (tid >> 6) + 1] = fits ? wave_total : -1; }
+        if (lane == 0) { s_seg[2 * (tid_r >> 6)] = wave_base; s_seg[2 * (tid_r >> 6) + 1] = fits ? wave_total : -1; }
 #ifdef VXH_PHASE_TIMING
-        if (B.prof && lane == 0) { atomicAdd(&B.prof[112], 1ull); if (!fits) atomicAdd(&B.prof[113], 1ull); if (tid == 0) atomicAdd(&B.prof[114], (unsigned long long)pool_cap); }
+        if (B.prof && lane == 0) { atomicAdd(&B.prof[112], 1ull); if (!fits) atomicAdd(&B.prof[113], 1ull); if (tid_r == 0) atomicAdd(&B.prof[114], (unsigned long long)pool_cap); }
 #endif
         const int off = wave_base + incl - ccnt;
         rowd = ccnt;
@@ -613,7 +629,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             rowd = ccnt | ((off + 1) << 7);
             for (int k = 0; k < ccnt; ++k) {
                 const size_t at = (size_t)k * B.col_rows + row;
-                rc_code[off + k] = (B.col_partner[at] - base) | (tid << 10) | (k << 20);
+                rc_code[off + k] = (B.col_partner[at] - base) | (tid_r << 10) | (k << 20);
                 rc_a1[off + k] = B.col_a1[at];
             }
         }

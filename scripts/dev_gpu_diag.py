@@ -442,3 +442,10 @@ if __name__ == "__main__" and "contactcheck" in sys.argv[1:]:
 
 if __name__ == "__main__" and "l2pop" in sys.argv[1:]:      # the bench population for scripts/profile_l2.sh: `l2pop 1` / `l2pop 0` = self-collision on / off
     timing2(512, (10, 10, 10), 0.03, sys.argv[-1] == "1", {"tiled": 0})
+
+
+if __name__ == "__main__" and "dense" in sys.argv[1:]:
+    # the 1024-thread resident variant: 512 FULL 10x10x10 lattices (1000 voxels each), with and without self-collision, warm, twice
+    for _ in range(2):
+        timing_cfg(engine.VOXCAD, 512, (10, 10, 10), 0.03, Env(), {"tiled": 0}, full=True, selfcol=True)
+        timing_cfg(engine.VOXCAD, 512, (10, 10, 10), 0.03, Env(), {"tiled": 0}, full=True, selfcol=False)
