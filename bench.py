@@ -17,6 +17,13 @@ of the timed window).  After the timed region the fitness records of all ranks a
 With N > 1 the same line carries `strong`: BASELINE configs[2] as stated -- ONE population of 512, partitioned over the
 N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak run.
 
+READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 256 steps (engine option steps_per_launch), and a
+launch of a self-colliding population carries ~0.27 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
+robots run a ~0.17 ms collision broad-phase).  `--steps 20 --warmup 5` (what the round-end driver runs) therefore reports ~7.6e9
+voxel-steps/s (~47 us per step), the default `--steps 2000` ~1.10e10 (~32.6 us) -- same kernel, same population; `timed_region` in
+the line says which case it is.  (Round 1's line for `--steps 20` was 9.5e9, on CHEAPER physics: it timed steps 6-25 from rest;
+this one pre-advances past InitCmTime first, as the round-1 review asked.)
+
 The JSON line also carries
   roofline      HBM: algorithmic bytes (224*Nvox + 144*Nbond per voxel-step) of the dominant kernel over its
                 HIP-event time, in GB/s against the 8 TB/s peak; `traffic` = what the PMC counters saw for the same kernel on
@@ -331,6 +338,15 @@ def main():
                                      "the dominant kernel on its stream; achieved and traffic are both rates (GB/s); traffic << "
                                      "achieved because the resident robots' bond history is served by the L2 (hit rate 0.95): the "
                                      "kernel is FP64-issue-bound, not HBM-bound"},
+                "timed_region": {
+                    "launches": int(c1.dominant_launches),          # (of the timed call: this counter is per call, not cumulative)
+                    "mean_steps_per_launch": args.steps / max(1, int(c1.dominant_launches)),
+                    "note": "a launch of the resident kernel ends with its slowest workgroup and carries a fixed cost: ~0.02 ms for a "
+                            "population without self-collision, ~0.27 ms for this one (prologue/epilogue of two robots per CU ~0.07 ms; the "
+                            "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.17 ms per run, ~50 of 512 robots in "
+                            "any 20-step launch).  Per step WITHOUT that cost: ~30.5 us.  --steps 20 times ONE 20-step launch (~47 us per "
+                            "step, ~7.6e9 voxel-steps/s); the default --steps 2000 times eight launches of up to 256 steps (~32.6 us, ~1.10e10).  "
+                            "DESIGN.md section 4 'The cost of a launch'"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,
             }

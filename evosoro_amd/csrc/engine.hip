@@ -347,6 +347,8 @@ void Engine::clear()
         }
         if (h[112]) fprintf(stderr, "contact rows in LDS: %llu wavefront copies, %llu did not fit (mean capacity %.0f pairs); cross-check (dbg 8): %llu lanes, %llu with different bits, %llu whose LDS row differs from memory; of the differing lanes: %llu with fewer mask bits than pairs in reach, %llu with more, %llu with as many\n",
                             h[112], h[113], h[114] ? (double)h[114] * 12.0 / (double)h[112] : 0.0, h[115], h[116], h[117], h[118], h[119], h[111]);
+        if (h[108]) fprintf(stderr, "broad-phase runs (resident kernel, with the copy of the rows): %llu, %.0f cycles each on average; workgroup-launches with at least one: %llu; "
+                            "most cycles one workgroup spent in them in one launch (maximum over ALL launches): %llu\n", h[108], (double)h[109] / (double)h[108], h[107], h[110]);
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
         static const char* tnames[8] = {"halo-wait", "bond", "svc:poll", "barB", "latch/rebuild", "voxel", "barC+mv", "svc:reduce+horizon"};
         const bool tiled = !dev_->tile_launches.empty();
@@ -358,7 +360,7 @@ void Engine::clear()
             if (tiled) for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %5.1f%%", tnames[k], 100.0 * h[w * 8 + k] / tot);
             else for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %5.1f%%", names[k], 100.0 * h[w * 8 + k] / tot);
             fprintf(stderr, "  total %.3e cycles", tot);
-            if (!tiled && h[w * 8 + 6] + h[w * 8 + 7]) fprintf(stderr, "  (aux: mesh vertices %4.1f%%, facets %4.1f%%)", 100.0 * h[w * 8 + 6] / tot, 100.0 * h[w * 8 + 7] / tot);
+            if (!tiled && h[w * 8 + 6] + h[w * 8 + 7]) fprintf(stderr, "  (MESH: mesh vertices / facets inside aux; else: before the step loop / after it, cycles)  %.3e  %.3e", (double)h[w * 8 + 6], (double)h[w * 8 + 7]);
             fprintf(stderr, "\n");
         }
     }

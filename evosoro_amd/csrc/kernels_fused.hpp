@@ -524,6 +524,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + 2 * sizeof(int) + 2 * 16 * sizeof(int) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
+#ifdef VXH_PHASE_TIMING
+    const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
     const int r = __builtin_amdgcn_readfirstlane(robot_list[blockIdx.x]);   // robots of one launch group, longest-running first; uniform -> scalar loads of R
     const DRobot& R = robots[r];            // separate noalias argument: its loads stay scalar although the kernel stores to HBM
     const unsigned nv = B.nv;
@@ -643,6 +646,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     rows_to_lds();
     __syncthreads();                           // control of the first step + every voxel's pose visible
     VXH_T_DECL
+#ifdef VXH_PHASE_TIMING
+    unsigned long long reb_cycles = 0;
+    if (!MESH && B.prof && (tid & 63) == 0) atomicAdd(&B.prof[(tid >> 6) * 8 + 6], __builtin_readcyclecounter() - t_entry);   // prologue
+#endif
     for (int it = 0;; ++it) {
         const FusedCtl& K = s_ctl[it & 1];
         FusedCtl& Knext = s_ctl[(it + 1) & 1];
@@ -659,7 +666,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             scratch_used = true;
         }
         if (!k_go) break;                      // (the robot has stopped; the last step's trace point, if one was due, is in)
+#ifdef VXH_PHASE_TIMING
+        const unsigned long long t_reb0 = __builtin_readcyclecounter();
+#endif
         if (k_rebuild) { fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct); rows_to_lds(); scratch_used = true; }
+#ifdef VXH_PHASE_TIMING
+        // developer build: broad-phase runs (incl. the copy of the rows) and their cycles, wave 0 of every workgroup; the largest
+        // number of cycles any one workgroup spent in them during its launch goes to slot 110 (atomicMax at the kernel's end)
+        if (k_rebuild && B.prof && tid == 0) { const unsigned long long dtc = __builtin_readcyclecounter() - t_reb0; atomicAdd(&B.prof[108], 1ull); atomicAdd(&B.prof[109], dtc); reb_cycles += dtc; }
+#endif
         if (scratch_used) { acc[tid] = 0.0; __syncthreads(); }
         d3 drag = mk3(0, 0, 0);
         const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
@@ -758,6 +773,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         VXH_T_MARK(0)
     }
     VXH_T_FLUSH
+#ifdef VXH_PHASE_TIMING
+    const unsigned long long t_loop_end = __builtin_readcyclecounter();
+    if (B.prof && tid == 0) { atomicMax(&B.prof[110], reb_cycles); atomicAdd(&B.prof[107], reb_cycles > 0 ? 1ull : 0ull); }
+#endif
     // ---- back to HBM: state into the buffer the step count selects, flag bits, control block
     if (valid) {
         const int b1 = rs.steps & 1;
@@ -777,6 +796,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     for (int a = 0; a < 3; ++a)
         if (entry[a] != -1) B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] = (unsigned char)((modebits >> (2 * a)) & 3u);
     if (tid == 0) B.rstate[r] = rs;
+#ifdef VXH_PHASE_TIMING
+    __builtin_amdgcn_s_waitcnt(0);          // (the write-back has left the wavefront)
+    if (!MESH && B.prof && (tid & 63) == 0) atomicAdd(&B.prof[(tid >> 6) * 8 + 7], __builtin_readcyclecounter() - t_loop_end);   // epilogue
+#endif
 }
 
 }  // namespace vxh

@@ -449,3 +449,63 @@ if __name__ == "__main__" and "dense" in sys.argv[1:]:
     for _ in range(2):
         timing_cfg(engine.VOXCAD, 512, (10, 10, 10), 0.03, Env(), {"tiled": 0}, full=True, selfcol=True)
         timing_cfg(engine.VOXCAD, 512, (10, 10, 10), 0.03, Env(), {"tiled": 0}, full=True, selfcol=False)
+
+
+if __name__ == "__main__" and "launchcost" in sys.argv[1:]:
+    # Fixed cost of a launch of the resident kernel: the bench population stepped 1000 steps past a 900-step pre-advance in launches of
+    # L steps each; kernel time = launches x (fixed + L x per-step).  The driver's bench command times ONE launch of 20 steps.
+    # VXH_LC_DBG=<n>: developer library with the what-if switch n (1: contact rows ignored, 4: no LDS copy of the rows), collisions only
+    lc_dbg = int(os.environ.get("VXH_LC_DBG", "0"))
+    if lc_dbg:
+        engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    for col in ((True,) if lc_dbg else (True, False)):
+        sim = Sim(self_collisions_enabled=col, dt_frac=0.9, simulation_time=2.0, fitness_eval_init_time=0.4)
+        paths = []
+        for ind in workloads.population(512, (10, 10, 10)):
+            write_voxelyze_file(sim, Env(), ind, tmp, "c%d" % col)
+            paths.append(os.path.join(tmp, "voxelyzeFiles", "c%d--id_%05i.vxa" % (col, ind.id)))
+        rows = []
+        for L in ((250, 20) if lc_dbg else (250, 100, 50, 20, 10, 5)):
+            with engine.Engine(engine.VOXCAD, 0) as eng:
+                eng.set_option("tiled", 0)
+                eng.set_option("steps_per_launch", L)
+                if lc_dbg:
+                    eng.set_option("dbg", lc_dbg)
+                eng.add_vxa_files(paths)
+                eng.step(900)
+                c0 = eng.counters()
+                t0 = time.perf_counter()
+                eng.step(1000)
+                wall = time.perf_counter() - t0
+                c1 = eng.counters()
+                ks, nl = c1.kernel_seconds - c0.kernel_seconds, c1.launches - c0.launches
+                rows.append((L, nl, ks, wall))
+                if col:
+                    reb = [eng.result(i).col_rebuilds for i in range(len(paths))]
+                    print("        broad-phase runs per robot over the 1900 steps: mean %.1f, max %d" % (np.mean(reb), max(reb)), flush=True)
+                print("col=%d  %3d steps per launch: %4d launches, kernel %.4f s = %.1f us per step, %.1f us per launch; wall %.4f s" % (col, L, nl, ks, 1e3 * ks, 1e6 * ks / nl, wall), flush=True)
+        (La, na, ka, _), (Lb, nb, kb, _) = rows[0], rows[1 if lc_dbg else 3]
+        fixed = (kb - ka) / (nb - na)
+        print("col=%d  -> fixed cost per launch %.0f us, per step %.1f us (from the 250- and 20-step rows)" % (col, 1e6 * fixed, 1e6 * (ka - na * fixed) / 1000), flush=True)
+
+
+if __name__ == "__main__" and "proepi" in sys.argv[1:]:
+    # developer library: cycles a wavefront of the resident kernel spends before the step loop and after it, per launch, colliding vs not
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    for col in (True, False):
+        sim = Sim(self_collisions_enabled=col, dt_frac=0.9, simulation_time=2.0, fitness_eval_init_time=0.4)
+        paths = []
+        for ind in workloads.population(512, (10, 10, 10)):
+            write_voxelyze_file(sim, Env(), ind, tmp, "p%d" % col)
+            paths.append(os.path.join(tmp, "voxelyzeFiles", "p%d--id_%05i.vxa" % (col, ind.id)))
+        with engine.Engine(engine.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 0)
+            eng.set_option("steps_per_launch", 20)
+            eng.add_vxa_files(paths)
+            eng.step(1000)                   # 50 launches of 20 steps
+            print("self-collision %d: 50 launches x 512 robots; the two last numbers of a wave's line / (50 x 512) = cycles per launch" % col, flush=True)
+            eng.clear()                      # prints the per-wave lines
