@@ -349,6 +349,9 @@ void Engine::clear()
                             h[112], h[113], h[114] ? (double)h[114] * 12.0 / (double)h[112] : 0.0, h[115], h[116], h[117], h[118], h[119], h[111]);
         if (h[108]) fprintf(stderr, "broad-phase runs (resident kernel, with the copy of the rows): %llu, %.0f cycles each on average; workgroup-launches with at least one: %llu; "
                             "most cycles one workgroup spent in them in one launch (maximum over ALL launches): %llu\n", h[108], (double)h[109] / (double)h[108], h[107], h[110]);
+        if (h[108] && h[100]) fprintf(stderr, "   of a broad-phase run, cycles on average (first wavefront): staging the surface list %.0f | its own scan %.0f | count write + wait for the "
+                                      "slowest wavefront %.0f | the rest (copy of the rows to LDS) %.0f\n", (double)h[100] / h[108], (double)h[101] / h[108], (double)h[102] / h[108],
+                                      ((double)h[109] - (double)h[100] - (double)h[101] - (double)h[102]) / h[108]);
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
         static const char* tnames[8] = {"halo-wait", "bond", "svc:poll", "barB", "latch/rebuild", "voxel", "barC+mv", "svc:reduce+horizon"};
         const bool tiled = !dev_->tile_launches.empty();

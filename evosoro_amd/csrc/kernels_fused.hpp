@@ -102,11 +102,18 @@ __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, 
                                               const DVoxClass* vct)
 {
     const int tid = opaque_tid<BLOCK>(), ns = R.nsurf;
+#ifdef VXH_PHASE_TIMING
+    unsigned long long t_rb = __builtin_readcyclecounter();
+#define VXH_RB_MARK(slot) { const unsigned long long t_now = __builtin_readcyclecounter(); if (B.prof && tid == 0) atomicAdd(&B.prof[slot], t_now - t_rb); t_rb = t_now; }
+#else
+#define VXH_RB_MARK(slot)
+#endif
     for (int k = tid; k < ns; k += BLOCK) {      // local voxel index | class of every surface voxel
         const int g = B.surf[R.surf_begin + k];
         shi[k] = (g - R.vox_begin) | ((int)B.vclass[g] << 10);
     }
     __syncthreads();
+    VXH_RB_MARK(100)
     if (tid < ns) {
         const int i = tid, mine = shi[i], li = mine & 1023;
         const DVoxClass& Ci = vct[mine >> 10];
@@ -144,10 +151,12 @@ __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, 
                 }
             }
         }
+        VXH_RB_MARK(101)      // (wave 0's own scan: lanes of one wavefront finish together)
         if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
         B.col_cnt[R.surf_begin + i] = cnt;
     }
     __syncthreads();
+    VXH_RB_MARK(102)      // count write + waiting for the slowest wavefront's scan
 }
 
 // land_water fluid drag (LW/VX_Sim.cpp:1516-1597) inside the resident kernel; the per-corner and per-facet arithmetic is

@@ -505,6 +505,8 @@ if __name__ == "__main__" and "proepi" in sys.argv[1:]:
         with engine.Engine(engine.VOXCAD, 0) as eng:
             eng.set_option("tiled", 0)
             eng.set_option("steps_per_launch", 20)
+            if os.environ.get("VXH_LC_DBG"):  # e.g. 16: every broad-phase run also executes the scan it replaced and compares the rows
+                eng.set_option("dbg", int(os.environ["VXH_LC_DBG"]))
             eng.add_vxa_files(paths)
             eng.step(1000)                   # 50 launches of 20 steps
             print("self-collision %d: 50 launches x 512 robots; the two last numbers of a wave's line / (50 x 512) = cycles per launch" % col, flush=True)
