@@ -345,13 +345,14 @@ void Engine::clear()
                 fprintf(stderr, "\n");
             }
         }
-        if (h[112]) fprintf(stderr, "contact rows in LDS: %llu wavefront copies, %llu did not fit (mean capacity %.0f pairs); cross-check (dbg 8): %llu lanes, %llu with different bits, %llu whose LDS row differs from memory; of the differing lanes: %llu with fewer mask bits than pairs in reach, %llu with more, %llu with as many\n",
-                            h[112], h[113], h[114] ? (double)h[114] * 12.0 / (double)h[112] : 0.0, h[115], h[116], h[117], h[118], h[119], h[111]);
-        if (h[108]) fprintf(stderr, "broad-phase runs (resident kernel, with the copy of the rows): %llu, %.0f cycles each on average; workgroup-launches with at least one: %llu; "
-                            "most cycles one workgroup spent in them in one launch (maximum over ALL launches): %llu\n", h[108], (double)h[109] / (double)h[108], h[107], h[110]);
-        if (h[108] && h[100]) fprintf(stderr, "   of a broad-phase run, cycles on average (first wavefront): staging the surface list %.0f | its own scan %.0f | count write + wait for the "
-                                      "slowest wavefront %.0f | the rest (copy of the rows to LDS) %.0f\n", (double)h[100] / h[108], (double)h[101] / h[108], (double)h[102] / h[108],
-                                      ((double)h[109] - (double)h[100] - (double)h[101] - (double)h[102]) / h[108]);
+        if (h[2112]) fprintf(stderr, "contact rows in LDS: %llu wavefront copies, %llu did not fit (mean capacity %.0f pairs); cross-check (dbg 8): %llu lanes, %llu with different bits, %llu whose LDS row differs from memory; of the differing lanes: %llu with fewer mask bits than pairs in reach, %llu with more, %llu with as many\n",
+                            h[2112], h[2113], h[2114] ? (double)h[2114] * 12.0 / (double)h[2112] : 0.0, h[2115], h[2116], h[2117], h[2118], h[2119], h[2111]);
+        if (h[2108]) fprintf(stderr, "broad-phase runs (resident kernel, with the copy of the rows): %llu, %.0f cycles each on average; workgroup-launches with at least one: %llu; "
+                            "most cycles one workgroup spent in them in one launch (maximum over ALL launches): %llu\n", h[2108], (double)h[2109] / (double)h[2108], h[2107], h[2110]);
+        if (h[2108] && h[2100]) fprintf(stderr, "   of a broad-phase run, cycles on average (first wavefront): staging the surface list %.0f | its own scan %.0f | count write + wait for the "
+                                      "slowest wavefront %.0f | the rest (copy of the rows to LDS) %.0f\n", (double)h[2100] / h[2108], (double)h[2101] / h[2108], (double)h[2102] / h[2108],
+                                      ((double)h[2109] - (double)h[2100] - (double)h[2101] - (double)h[2102]) / h[2108]);
+        if (h[2104]) fprintf(stderr, "   broad-phase cross-check (dbg 16): %llu rows built by both scans, %llu differ\n", h[2104], h[2105]);
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
         static const char* tnames[8] = {"halo-wait", "bond", "svc:poll", "barB", "latch/rebuild", "voxel", "barC+mv", "svc:reduce+horizon"};
         const bool tiled = !dev_->tile_launches.empty();

@@ -96,9 +96,11 @@ __device__ __forceinline__ void fused_latch_cm(const DRobot& R, DRobotState& rs,
     __syncthreads();
 }
 
-// CalcL1Bonds (VX_Sim.cpp:2357-2413) from the pose tile; thread i owns surface voxel i (see rebuild_rows in kernels.hpp)
+// CalcL1Bonds (VX_Sim.cpp:2357-2413) from the pose tile; thread i owns surface voxel i (see rebuild_rows in kernels.hpp).  This scan
+// (every lane reads every candidate's index and pose from LDS) is what the 256-, 512- and 768-thread variants run; the 1024-thread
+// variant runs fused_rebuild_staged below.  The developer build runs both (what-if switch 16) and compares the rows.
 template <int BLOCK>
-__device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, int* shi,
+__device__ __forceinline__ void fused_rebuild_plain(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, int* shi,
                                               const DVoxClass* vct)
 {
     const int tid = opaque_tid<BLOCK>(), ns = R.nsurf;
@@ -113,7 +115,7 @@ __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, 
         shi[k] = (g - R.vox_begin) | ((int)B.vclass[g] << 10);
     }
     __syncthreads();
-    VXH_RB_MARK(100)
+    VXH_RB_MARK(2100)
     if (tid < ns) {
         const int i = tid, mine = shi[i], li = mine & 1023;
         const DVoxClass& Ci = vct[mine >> 10];
@@ -151,12 +153,95 @@ __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, 
                 }
             }
         }
-        VXH_RB_MARK(101)      // (wave 0's own scan: lanes of one wavefront finish together)
+        VXH_RB_MARK(2101)      // (wave 0's own scan: lanes of one wavefront finish together)
         if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
         B.col_cnt[R.surf_begin + i] = cnt;
     }
     __syncthreads();
-    VXH_RB_MARK(102)      // count write + waiting for the slowest wavefront's scan
+    VXH_RB_MARK(2102)      // count write + waiting for the slowest wavefront's scan
+}
+// CalcL1Bonds (VX_Sim.cpp:2357-2413) from the pose tile; thread i owns surface voxel i (see rebuild_rows in kernels.hpp) and tests
+// all others in ascending order (= creation order of the reference's collision bonds).  A run is 4 % of an average step but what a
+// LAUNCH waits for (it ends with its slowest workgroup, and in any 20-step launch a tenth of the robots run one), so its common
+// path -- fetch a candidate, squared distance, compare; nearly every pair fails -- is kept to the arithmetic:
+//   * the surface voxels' positions are staged by surface ordinal (`stg`, four planes behind the index array in the borrowed
+//     accumulator tile), so a candidate's address is the loop counter: uniform, no index read, no per-lane address arithmetic;
+//   * the three tests of a candidate are integer arithmetic on compare results, eight candidates per branch ("some lane has one
+//     inside the filter": rare); the accepted-pair path recomputes its distance with the same expression.
+// Where the time of the scan it replaces went was established with timers, what-if switches and a micro-benchmark of the loop
+// (scripts/ubench/scan_loop.hip: 306 -> 196 cycles per candidate and wavefront for this change); DESIGN.md "The cost of a launch"
+// lists what did NOT help.  Same arithmetic per pair, hence the same rows (cross-checked in the developer build).
+// Used by the 1024-thread variant only.  Measured against fused_rebuild_plain on one box, interleaved: a run 355 k -> 299 k cycles;
+// dense 10^3 robots (1024 threads) 53.8-54.4 -> 52.5-52.9 us per step with self-collision, 51.5-51.9 -> 50.5-50.6 without.  In the
+// 768-thread variant the fixed cost of a launch fell from 265 to 230 us, but the STEP got slower, 30.5 -> 31.3 us (a population
+// without collisions, which never runs this code, 22.9 -> 23.5-23.8): with the larger function inlined the kernel spills 54 scalar
+// registers instead of 36, reloaded inside the hot phases.  (Hiding the function's uniform arguments from the compiler, the way
+// opaque_tid hides the thread index, made that worse: 65.)
+// `shi`: BLOCK ints, then (from shi + 2 * BLOCK ints = one plane of doubles on) 4 planes of BLOCK doubles; the caller re-zeroes them.
+template <int BLOCK>
+__device__ __forceinline__ void fused_rebuild_staged(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, int* shi,
+                                                     const DVoxClass* vct)
+{
+    const int tid = opaque_tid<BLOCK>(), ns = R.nsurf;
+    double* const stg = (double*)shi + BLOCK;     // x y z scale by surface ordinal
+    for (int k = tid; k < ns; k += BLOCK) {       // local voxel index | class of every surface voxel; its pose by ordinal
+        const int g = B.surf[R.surf_begin + k], l = g - R.vox_begin;
+        shi[k] = l | ((int)B.vclass[g] << 10);
+        stg[k] = ps[l]; stg[BLOCK + k] = ps[BLOCK + l]; stg[2 * BLOCK + k] = ps[2 * BLOCK + l]; stg[3 * BLOCK + k] = ps[3 * BLOCK + l];
+    }
+    __syncthreads();
+    if (tid < ns) {
+        const int i = tid, mine = shi[i];
+        const DVoxClass& Ci = vct[mine >> 10];
+        const d3 pi = mk3(stg[i], stg[BLOCK + i], stg[2 * BLOCK + i]);
+        const double si = stg[3 * BLOCK + i];
+        const unsigned long long* row = B.excl + R.excl_begin + (long long)i * R.excl_wpr;
+        const double H = R.col_horizon, filter2 = R.filter_dist2;
+        int cnt = 0;
+        unsigned long long word = 0;
+        for (int j0 = 0; j0 < ns; j0 += 8) {       // (a group may reach up to 7 entries past ns: inside the planes, masked below)
+            if ((j0 & 63) == 0) word = row[j0 >> 6];
+            int any = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                const d3 d = pi - mk3(stg[j], stg[BLOCK + j], stg[2 * BLOCK + j]);
+                any |= (int)(len2(d) < filter2) & (int)(j != i) & (int)(j < ns);
+            }
+            if (!any) continue;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j >= ns || j == i) continue;
+                const d3 d = pi - mk3(stg[j], stg[BLOCK + j], stg[2 * BLOCK + j]);
+                const double d2 = len2(d);
+                if (!(d2 < filter2)) continue;
+                if ((word >> (j & 63)) & 1ull) continue;          // !pV1->IsNearbyVox(SIndex2)
+                const double s1 = (j > i) ? si : stg[3 * BLOCK + j];   // scale of Vox1 = the earlier one, used twice (:2382)
+                const double act = H * (s1 + s1) * 0.5;
+                if (d2 < act * act) {
+                    if (cnt < VXH_MAXCOL) {
+                        const int other = shi[j];
+                        const DVoxClass& Cj = vct[other >> 10];
+                        const size_t at = (size_t)cnt * B.col_rows + (R.surf_begin + i);
+                        B.col_partner[at] = R.vox_begin + (other & 1023);
+                        B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
+                    }
+                    ++cnt;
+                }
+            }
+        }
+        if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
+        B.col_cnt[R.surf_begin + i] = cnt;
+    }
+    __syncthreads();
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, int* shi, const DVoxClass* vct)
+{
+    if constexpr (BLOCK == 1024) fused_rebuild_staged<BLOCK>(B, R, rs, ps, shi, vct);
+    else fused_rebuild_plain<BLOCK>(B, R, rs, ps, shi, vct);
 }
 
 // land_water fluid drag (LW/VX_Sim.cpp:1516-1597) inside the resident kernel; the per-corner and per-facet arithmetic is
@@ -633,7 +718,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         const bool fits = wave_base + wave_total <= pool_cap;
         if (lane == 0) { s_seg[2 * (tid_r >> 6)] = wave_base; s_seg[2 * (tid_r >> 6) + 1] = fits ? wave_total : -1; }
 #ifdef VXH_PHASE_TIMING
-        if (B.prof && lane == 0) { atomicAdd(&B.prof[112], 1ull); if (!fits) atomicAdd(&B.prof[113], 1ull); if (tid_r == 0) atomicAdd(&B.prof[114], (unsigned long long)pool_cap); }
+        if (B.prof && lane == 0) { atomicAdd(&B.prof[2112], 1ull); if (!fits) atomicAdd(&B.prof[2113], 1ull); if (tid_r == 0) atomicAdd(&B.prof[2114], (unsigned long long)pool_cap); }
 #endif
         const int off = wave_base + incl - ccnt;
         rowd = ccnt;
@@ -678,11 +763,38 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #ifdef VXH_PHASE_TIMING
         const unsigned long long t_reb0 = __builtin_readcyclecounter();
 #endif
-        if (k_rebuild) { fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct); rows_to_lds(); scratch_used = true; }
+        if (k_rebuild) {
+            fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct);
+#ifdef VXH_PHASE_TIMING
+            if (VXH_DBG(16) && B.prof) {     // cross-check: the scan it replaces must leave the same rows (count, partners, stiffness bits)
+                int my_row = -1, n_new = 0; unsigned long long sum_new = 0;
+                if (tid < R.nsurf) {
+                    my_row = R.surf_begin + tid; n_new = B.col_cnt[my_row];
+                    for (int k = 0; k < n_new; ++k) { const size_t at = (size_t)k * B.col_rows + my_row; sum_new += (unsigned long long)(k + 1) * ((unsigned long long)B.col_partner[at] * 1000003ull + (unsigned long long)__double_as_longlong(B.col_a1[at])); }
+                }
+                __syncthreads();
+                if constexpr (BLOCK == 1024) fused_rebuild_plain<BLOCK>(B, R, rs, ps, (int*)acc, vct);     // (the other scan)
+                else fused_rebuild_staged<BLOCK>(B, R, rs, ps, (int*)acc, vct);
+                if (tid < R.nsurf) {
+                    const int n_old = B.col_cnt[my_row]; unsigned long long sum_old = 0;
+                    for (int k = 0; k < n_old; ++k) { const size_t at = (size_t)k * B.col_rows + my_row; sum_old += (unsigned long long)(k + 1) * ((unsigned long long)B.col_partner[at] * 1000003ull + (unsigned long long)__double_as_longlong(B.col_a1[at])); }
+                    atomicAdd(&B.prof[2104], 1ull);
+                    if (n_old != n_new || sum_old != sum_new) atomicAdd(&B.prof[2105], 1ull);
+                }
+                __syncthreads();
+            }
+#endif
+            rows_to_lds();
+            if (BLOCK == 1024 || VXH_DBG(16)) {                            // the staged planes of the broad-phase (plane 0: below)
+#pragma unroll
+                for (int k = 1; k < 5; ++k) acc[k * BLOCK + tid] = 0.0;
+            }
+            scratch_used = true;
+        }
 #ifdef VXH_PHASE_TIMING
         // developer build: broad-phase runs (incl. the copy of the rows) and their cycles, wave 0 of every workgroup; the largest
         // number of cycles any one workgroup spent in them during its launch goes to slot 110 (atomicMax at the kernel's end)
-        if (k_rebuild && B.prof && tid == 0) { const unsigned long long dtc = __builtin_readcyclecounter() - t_reb0; atomicAdd(&B.prof[108], 1ull); atomicAdd(&B.prof[109], dtc); reb_cycles += dtc; }
+        if (k_rebuild && B.prof && tid == 0) { const unsigned long long dtc = __builtin_readcyclecounter() - t_reb0; atomicAdd(&B.prof[2108], 1ull); atomicAdd(&B.prof[2109], dtc); reb_cycles += dtc; }
 #endif
         if (scratch_used) { acc[tid] = 0.0; __syncthreads(); }
         d3 drag = mk3(0, 0, 0);
@@ -737,9 +849,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #ifdef VXH_PHASE_TIMING
             if (VXH_DBG(8) && B.prof && (rowd >> 7) != 0) {     // the same sum through the rows in memory: must give the same bits
                 const d3 G = fused_contact_forces<BLOCK>(B, R, ps, F_before, S.pos, S.scale, tid, vv, rowd & 127, cmask, rc_code, rc_a1);
-                atomicAdd(&B.prof[115], 1ull);
+                atomicAdd(&B.prof[2115], 1ull);
                 if (!(G.x == F.x && G.y == F.y && G.z == F.z)) {
-                    atomicAdd(&B.prof[116], 1ull);
+                    atomicAdd(&B.prof[2116], 1ull);
                     // pairs of my row in reach by CalcContactForce's own test, against the bits pass 1 set for me
                     int reach = 0;
                     const int crow0 = R.surf_begin + B.surf_ord[vv];
@@ -748,7 +860,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
                         if (contact_in_reach(ps[q] - S.pos.x, ps[BLOCK + q] - S.pos.y, ps[2 * BLOCK + q] - S.pos.z, (ps[3 * BLOCK + q] + S.scale) * 0.75)) ++reach;
                     }
                     const int bits = __builtin_popcountll(mask_seen);
-                    atomicAdd(&B.prof[bits < reach ? 118 : (bits > reach ? 119 : 111)], 1ull);
+                    atomicAdd(&B.prof[bits < reach ? 2118 : (bits > reach ? 2119 : 2111)], 1ull);
                 }
                 // is the LDS copy of my row what memory holds now?  (partner and stiffness of every entry, bit for bit)
                 const int crow = R.surf_begin + B.surf_ord[vv], coff = (rowd >> 7) - 1;
@@ -758,7 +870,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
                     same = same && (rc_code[coff + k] & 1023) == B.col_partner[at] - base && rc_a1[coff + k] == B.col_a1[at];
                 }
                 if (B.col_cnt[crow] != (rowd & 127)) same = false;
-                if (!same) atomicAdd(&B.prof[117], 1ull);
+                if (!same) atomicAdd(&B.prof[2117], 1ull);
             }
 #endif
             vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, -1, 0, fluid, drag,
@@ -784,7 +896,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     VXH_T_FLUSH
 #ifdef VXH_PHASE_TIMING
     const unsigned long long t_loop_end = __builtin_readcyclecounter();
-    if (B.prof && tid == 0) { atomicMax(&B.prof[110], reb_cycles); atomicAdd(&B.prof[107], reb_cycles > 0 ? 1ull : 0ull); }
+    if (B.prof && tid == 0) { atomicMax(&B.prof[2110], reb_cycles); atomicAdd(&B.prof[2107], reb_cycles > 0 ? 1ull : 0ull); }
 #endif
     // ---- back to HBM: state into the buffer the step count selects, flag bits, control block
     if (valid) {

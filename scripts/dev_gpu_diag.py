@@ -499,7 +499,10 @@ if __name__ == "__main__" and "proepi" in sys.argv[1:]:
     for col in (True, False):
         sim = Sim(self_collisions_enabled=col, dt_frac=0.9, simulation_time=2.0, fitness_eval_init_time=0.4)
         paths = []
-        for ind in workloads.population(512, (10, 10, 10)):
+        # VXH_LC_FULL=1: full lattices (1000 voxels: the 1024-thread variant) instead of the random robots (768-thread variant)
+        full = os.environ.get("VXH_LC_FULL") == "1"
+        inds = [workloads.make_individual(k, workloads.full_material(10, 1 + k)) for k in range(512)] if full else workloads.population(512, (10, 10, 10))
+        for ind in inds:
             write_voxelyze_file(sim, Env(), ind, tmp, "p%d" % col)
             paths.append(os.path.join(tmp, "voxelyzeFiles", "p%d--id_%05i.vxa" % (col, ind.id)))
         with engine.Engine(engine.VOXCAD, 0) as eng:
