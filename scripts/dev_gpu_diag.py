@@ -315,6 +315,40 @@ if __name__ == "__main__" and "e2e" in sys.argv[1:]:
                   t1 - t0, tc - t1, t2 - tc, t3 - t2, c.kernel_seconds, c.max_steps, t4 - t3, t4 - tc, c.voxel_steps / (t4 - tc), c.voxel_steps / c.kernel_seconds))
 
 
+if __name__ == "__main__" and "e2emem" in sys.argv[1:]:
+    # the same generation through the in-memory hand-off (vxh_add_robots): the template's text once, then arrays; result values from
+    # vxh_get_result (device reductions) instead of result XMLs.  VERDICT item 7: below the 0.38 s of the file route?
+    import time
+    from evosoro_amd.tools.read_write_voxelyze import phenotype_arrays
+    tmp = tempfile.mkdtemp()
+    for d in ("voxelyzeFiles", "fitnessFiles"):
+        os.makedirs(os.path.join(tmp, d))
+    sim = Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1)
+    env = Env()
+    pop = list(workloads.population(512, (10, 10, 10)))
+    with engine.Engine(engine.VOXCAD, 0) as eng:
+        eng.add_vxa_text(write_voxelyze_file(sim, env, pop[0], tmp, "w", write=False, want_text=True)[1]); eng.step(1); eng.clear()   # (HIP runtime, code objects: once per process)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            template = write_voxelyze_file(sim, env, pop[0], tmp, "t", write=False, want_text=True)[1]      # (returns (md5, text))
+            robots = []
+            for ind in pop:
+                material, layers = phenotype_arrays(ind)
+                robots.append((material, layers, None))
+            t1 = time.perf_counter()
+            eng.add_robots(template, robots)
+            t2 = time.perf_counter()
+            eng.run()
+            t3 = time.perf_counter()
+            fit = [eng.result(i).norm_final_dist for i in range(len(pop))]
+            t4 = time.perf_counter()
+            c = eng.counters()
+            print("e2e in memory, 512 x 10^3, 0.5 s simulated (rep %d): arrays from the genotypes %.3f s | vxh_add_robots (build) %.3f s | upload+run %.3f s (kernel %.3f s, "
+                  "%d max steps) | results %.3f s | generation total %.3f s -> %.3e vox-steps/s end to end vs %.3e in-kernel" % (
+                      rep, t1 - t0, t2 - t1, t3 - t2, c.kernel_seconds, c.max_steps, t4 - t3, t4 - t0, c.voxel_steps / (t4 - t0), c.voxel_steps / c.kernel_seconds), flush=True)
+            eng.clear()
+
+
 if __name__ == "__main__" and "small" in sys.argv[1:]:
     timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), {})
     timing_cfg(engine.VOXCAD, 2048, (6, 6, 6), 0.05, Env(), {})
