@@ -342,7 +342,7 @@ def main():
                     "launches": int(c1.dominant_launches),          # (of the timed call: this counter is per call, not cumulative)
                     "mean_steps_per_launch": args.steps / max(1, int(c1.dominant_launches)),
                     "note": "a launch of the resident kernel ends with its slowest workgroup and carries a fixed cost: ~0.02 ms for a "
-                            "population without self-collision, ~0.27 ms for this one (prologue/epilogue of two robots per CU ~0.07 ms; the "
+                            "population without self-collision, ~0.27 ms for this one (prologue/epilogue of two robots per CU ~0.04 ms; the "
                             "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.17 ms per run, ~50 of 512 robots in "
                             "any 20-step launch).  Per step WITHOUT that cost: ~30.5 us.  --steps 20 times ONE 20-step launch (~47-48 us per "
                             "step, ~7.4-7.6e9 voxel-steps/s); the default --steps 2000 times eight launches of up to 256 steps (~32.4 us, ~1.10e10).  "

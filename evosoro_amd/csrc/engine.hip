@@ -353,6 +353,9 @@ void Engine::clear()
                                       "slowest wavefront %.0f | the rest (copy of the rows to LDS) %.0f\n", (double)h[2100] / h[2108], (double)h[2101] / h[2108], (double)h[2102] / h[2108],
                                       ((double)h[2109] - (double)h[2100] - (double)h[2101] - (double)h[2102]) / h[2108]);
         if (h[2104]) fprintf(stderr, "   broad-phase cross-check (dbg 16): %llu rows built by both scans, %llu differ\n", h[2104], h[2105]);
+        if (h[2103]) fprintf(stderr, "   prologue of the resident kernel, cycle sums of the first thread over all workgroup-launches: tables + first barrier %.3e | state load, zeroing, "
+                             "first control %.3e | rows_to_lds %.3e  = (its parts, incl. the calls after broad-phase runs) ordinal -> count loads + barrier %.3e | scan + allotment %.3e | copy + barrier %.3e\n",
+                             (double)h[2103], (double)h[2106], (double)h[2113], (double)h[2114], (double)h[2115], (double)h[2116]);
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
         static const char* tnames[8] = {"halo-wait", "bond", "svc:poll", "barB", "latch/rebuild", "voxel", "barC+mv", "svc:reduce+horizon"};
         const bool tiled = !dev_->tile_launches.empty();

@@ -661,6 +661,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     }
     __syncthreads();
 
+#ifdef VXH_PHASE_TIMING
+    unsigned long long t_pro = __builtin_readcyclecounter();
+    if (!MESH && B.prof && tid == 0) atomicAdd(&B.prof[2103], t_pro - t_entry);          // tables -> LDS, first barrier
+#endif
     // ---- this thread's voxel (momenta -> registers, pose -> LDS, accumulators zeroed) and its three bonds
     const DVoxClass& C = vct[valid ? B.vclass[v] : 0];
     int entry[3];                             // my bond of each axis round (DBatch::blist), -1 = none
@@ -698,11 +702,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // they run as before, 52.9-53.6 against 53.2-53.5.  Why is not known: the ISA of the two differs by register numbering.)
         int tid_r = tid;
         if constexpr (BLOCK != 1024) tid_r = opaque_tid<BLOCK>();
+#ifdef VXH_PHASE_TIMING
+        unsigned long long t_r2l = __builtin_readcyclecounter();
+#define VXH_R2L_MARK(slot) { const unsigned long long t_now = __builtin_readcyclecounter(); if (B.prof && tid == 0) atomicAdd(&B.prof[slot], t_now - t_r2l); t_r2l = t_now; }
+#else
+#define VXH_R2L_MARK(slot)
+#endif
         int row = -1;
         if (valid) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
         const int ccnt = (row >= 0 && !VXH_DBG(1)) ? B.col_cnt[row] : 0;
         if (pool_cap > 0) cmask[tid_r] = 0;
         __syncthreads();
+        VXH_R2L_MARK(2114)     // surface ordinal -> row count (two dependent loads), first barrier
         int incl = ccnt;                      // places in the copy: prefix sum within the wavefront, one atomic per wavefront
         const int lane = tid_r & 63;
 #pragma unroll
@@ -715,11 +726,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         int wave_base = 0;
         for (int w = 0; w < (tid_r >> 6); ++w) wave_base += s_seg[2 * w + 1];
         __syncthreads();                      // (s_seg is rewritten below)
+        VXH_R2L_MARK(2115)     // scan, totals, two barriers, prefix over the wavefronts
         const bool fits = wave_base + wave_total <= pool_cap;
         if (lane == 0) { s_seg[2 * (tid_r >> 6)] = wave_base; s_seg[2 * (tid_r >> 6) + 1] = fits ? wave_total : -1; }
-#ifdef VXH_PHASE_TIMING
-        if (B.prof && lane == 0) { atomicAdd(&B.prof[2112], 1ull); if (!fits) atomicAdd(&B.prof[2113], 1ull); if (tid_r == 0) atomicAdd(&B.prof[2114], (unsigned long long)pool_cap); }
-#endif
+        // (the developer build used to count wavefront copies and overflows here with global atomics from every wavefront: contended, and the
+        // barrier below waits for them -- this function took 52 k cycles per call with them and takes 13.5 k without, and the difference
+        // was for a while mistaken for a cost of copying the rows; removed)
         const int off = wave_base + incl - ccnt;
         rowd = ccnt;
         if (fits && ccnt > 0) {
@@ -731,13 +743,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             }
         }
         __syncthreads();
+        VXH_R2L_MARK(2116)     // the copy itself, last barrier
     };
 
     // the control thread sits in the LAST wave: the one with the fewest (often no) voxels, so its serial work hides
     // behind the other waves' voxel phase
     const bool ctl_thread = tid == BLOCK - 64;
     if (ctl_thread) { fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]); fused_control_horizon(R, rs, s_ctl[0]); s_div = 0; }
+#ifdef VXH_PHASE_TIMING
+    { const unsigned long long t_now = __builtin_readcyclecounter(); if (!MESH && B.prof && tid == 0) atomicAdd(&B.prof[2106], t_now - t_pro); t_pro = t_now; }   // state load, zeroing, control
+#endif
     rows_to_lds();
+#ifdef VXH_PHASE_TIMING
+    { const unsigned long long t_now = __builtin_readcyclecounter(); if (!MESH && B.prof && tid == 0) atomicAdd(&B.prof[2113], t_now - t_pro); t_pro = t_now; }   // rows_to_lds as a whole
+#endif
     __syncthreads();                           // control of the first step + every voxel's pose visible
     VXH_T_DECL
 #ifdef VXH_PHASE_TIMING
