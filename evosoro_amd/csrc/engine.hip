@@ -397,10 +397,11 @@ void Engine::set_option(const std::string& key, double value)
     if (key == "fused") { fused_ = value != 0; drop_graph(); }
     else if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
     else if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); steps_per_launch_ = (int)value; }
-    else if (key == "tiled" || key == "tiles_per_robot") {
+    else if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small") {
         // the tiling is part of the uploaded batch: set before the first vxh_run / vxh_step, or follow with vxh_reset
         if (prepared_) throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or call vxh_reset after it)");
         if (key == "tiled") { if (value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2"); tiled_ = (int)value; }
+        else if (key == "tile_small") { if (value != 0 && value != 1) throw std::invalid_argument("tile_small: 0 or 1"); tile_small_ = value != 0; }
         else { if (!(value >= 0 && value <= 4096)) throw std::invalid_argument("tiles_per_robot out of range"); tiles_per_robot_ = (int)value; }
     }
     else if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); graph_steps_ = (int)value; drop_graph(); }
@@ -726,12 +727,23 @@ void Engine::prepare()
         const size_t lds_cap = 160 * 1024 - VXH_TILE_STATIC_LDS;
         int n_work = 0;
         for (int r = 0; r < nr; ++r) if (robots_[r].nvox > 0) ++n_work;
-        const bool small_population = n_work * 4 <= D.n_cu * 3;
+        // Which robots are tiled.  By default only those the resident kernel cannot take (more than 1024 voxels, oversized tables): the
+        // kernel that steps a robot is then a function of the robot ALONE, and so is its trajectory, bit for bit, whatever the batch --
+        // a robot re-evaluated alone gives the bits it gave inside a generation of 512 (tests/test_gpu_parity.py
+        // test_full_size_batch_properties; the tiled and the resident kernel agree to 1e-12 voxel, not to the bit).
+        // Option tile_small = 1 gives that up for speed where it was measured to pay (scripts/dev_gpu_diag.py tilepolicy, one box, us per
+        // population step, resident | tiled): 64 robots of 6^3 10.2 | 11.1, 7^3 11.0 | 11.3, 8^3 11.1 | 11.7, 9^3 13.7 | 14.2, 10^3 15.6 |
+        // 14.7; 16 of 10^3 15.1 | 13.2; 128 of 8^3 11.3 | 14.0; 128 of 10^3 16.0 | 32.9 (their tiles no longer fit one co-resident
+        // launch) -- i.e. large robots (the 768- and 1024-thread variants) in populations of at most a quarter of the CUs.  (Until late in
+        // round 2 the default was "any robot, up to three quarters of the CUs": slower for every size below 10^3, 2x slower at 128 robots,
+        // and population-dependent in the last bits.)
+        const bool small_population = tile_small_ && n_work * 4 <= D.n_cu;
         std::vector<int> cand;
         for (int r = 0; r < nr; ++r) {
             const RobotModel& M = robots_[r];
             if (M.nvox == 0 || M.nmv > 0) continue;                   // (robots with the land_water surface mesh: resident / streaming kernels)
-            if (tiled_ == 2 || small_population || !fused_ || fused_variant(M).block == 0) cand.push_back(r);
+            const int block = fused_variant(M).block;
+            if (tiled_ == 2 || !fused_ || block == 0 || (small_population && block >= 768)) cand.push_back(r);
         }
         // tiles per robot: one bond per lane if the CUs allow it (a step then costs one bond evaluation + one voxel update + the
         // barrier), fewer when the candidates outnumber the CUs

@@ -1,7 +1,7 @@
 // Tiled path of the batched Voxelyze stepper: k_tile_steps<TABG>, SEVERAL workgroups per robot, all of them resident for a
-// whole launch of many time steps (included at the end of kernels.hpp).  It serves the cases the one-workgroup-per-robot
-// kernel (kernels_fused.hpp) cannot fill the chip with: a lattice of more than 1024 voxels (BASELINE configs[4], one
-// 20x20x20 robot), and populations smaller than the number of CUs (64 robots on 256 CUs).  Loop being tiled:
+// whole launch of many time steps (included at the end of kernels.hpp).  By default it steps the robots the one-workgroup-per-
+// robot kernel (kernels_fused.hpp) cannot take: lattices of more than 1024 voxels (BASELINE configs[4], one 20x20x20 robot).
+// With the option tile_small also small populations of large robots (measured to pay only there: engine.hip).  Loop being tiled:
 // CVX_Sim::Integrate, VX_Sim.cpp:1763-1933.
 //
 // A robot is cut into tiles (model.cpp plan_tiles: a grid of boxes with equal voxel counts).  A tile's workgroup

@@ -548,3 +548,18 @@ if __name__ == "__main__" and "proepi" in sys.argv[1:]:
             eng.step(1000)                   # 50 launches of 20 steps
             print("self-collision %d: 50 launches x 512 robots; the two last numbers of a wave's line / (50 x 512) = cycles per launch" % col, flush=True)
             eng.clear()                      # prints the per-wave lines
+
+
+if __name__ == "__main__" and "tilesweep" in sys.argv[1:]:
+    # BASELINE configs[1] (64 random 6x6x6 robots): the resident kernel against the tiled kernel with 1, 2, 3, 4 tiles per robot
+    for opts in ({"tiled": 0}, {"tiled": 2, "tiles_per_robot": 1}, {"tiled": 2, "tiles_per_robot": 2}, {"tiled": 2, "tiles_per_robot": 3}, {"tiled": 2, "tiles_per_robot": 4}, {}):
+        timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.1, Env(), opts)
+    for opts in ({"tiled": 0}, {"tiled": 2, "tiles_per_robot": 1}, {"tiled": 2, "tiles_per_robot": 2}, {"tiled": 2, "tiles_per_robot": 4}, {}):
+        timing_cfg(engine.VOXCAD, 64, (8, 8, 8), 0.06, Env(), opts)
+
+
+if __name__ == "__main__" and "tilepolicy" in sys.argv[1:]:
+    # where the tiled kernel pays for robots the resident kernel could take: populations too small to fill the chip, by robot size
+    for count, n, sim_time in ((64, 6, 0.1), (64, 7, 0.08), (64, 8, 0.06), (64, 9, 0.05), (64, 10, 0.04), (16, 10, 0.04), (128, 8, 0.06), (128, 10, 0.04)):
+        for opts in ({"tiled": 0}, {}):
+            timing_cfg(engine.VOXCAD, count, (n, n, n), sim_time, Env(), opts)

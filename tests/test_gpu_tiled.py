@@ -80,3 +80,32 @@ def test_stepping_in_pieces_equals_one_run(golden_dir):
     whole = _states(eng_mod, paths, opts, (556,))[-1]
     for a, b in zip(pieces, whole):
         assert np.array_equal(a, b)
+
+
+def test_kernel_choice_follows_the_robot_alone_unless_tile_small(golden_dir):
+    """Default: a robot the resident kernel can take is never tiled, whatever the population -- so its trajectory does not depend on
+    the batch, bit for bit (test_full_size_batch_properties).  Option tile_small = 1 lets small populations of LARGE robots (the
+    768- and 1024-thread variants) use the tiled kernel: faster there (scripts/dev_gpu_diag.py tilepolicy), equal to 1e-12 voxel,
+    not to the bit."""
+    from evosoro_amd import engine as eng_mod
+    big, small = os.path.join(golden_dir, "vxa", "bench10_0.vxa"), os.path.join(golden_dir, "vxa", "rand6_col.vxa")
+
+    def run(path, options):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 1)                                 # the automatic policy, whatever kernel the test matrix forces
+            eng.set_option("tiles_per_robot", 0)                       # (conftest.py: VXH_ENGINE_OPTIONS)
+            for key, val in options.items():
+                eng.set_option(key, val)
+            eng.add_vxa_file(path)
+            eng.step(600)
+            return eng.state(0), eng.counters().dominant_block        # (dominant_block: 1 = the tiled kernel, else the resident variant)
+
+    big_default, blk = run(big, {})
+    assert blk == 768                                                  # a lone 10x10x10 robot: resident by default
+    big_small, blk = run(big, {"tile_small": 1})
+    assert blk == 1                                                    # ... tiled on request
+    assert np.abs(big_small[:, :8] - big_default[:, :8]).max() < 1e-12
+    small_default, blk = run(small, {})
+    assert blk == 256
+    small_small, blk = run(small, {"tile_small": 1})
+    assert blk == 256 and np.array_equal(small_small, small_default)  # small robots are never worth tiling: unchanged
