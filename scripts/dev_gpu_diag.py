@@ -441,6 +441,7 @@ if __name__ == "__main__" and "tileprof" in sys.argv[1:]:
     timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.16, Env(), {}, full=True)                                   # configs[4]
     timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.1, Env(), {})                                                 # configs[1]
     timing_cfg(engine.VOXCAD, 64, (10, 10, 10), 0.06, Env(), {})                                             # configs[2] as sharded over 8 GPUs
+    timing_cfg(engine.VOXCAD, 64, (10, 10, 10), 0.06, Env(), {"tile_small": 1})                              # ... with the option under which they are tiled
     timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, {}, per_voxel_phase=True)                # configs[3]
 
 
