@@ -17,7 +17,7 @@ of the timed window).  After the timed region the fitness records of all ranks a
 With N > 1 the same line carries `strong`: BASELINE configs[2] as stated -- ONE population of 512, partitioned over the
 N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak run.
 
-READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 256 steps (engine option steps_per_launch), and a
+READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 1024 steps (engine option steps_per_launch), and a
 launch of a self-colliding population carries ~0.27 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
 robots run a ~0.17 ms collision broad-phase).  `--steps 20 --warmup 5` (what the round-end driver runs) therefore reports ~7.4-7.6e9
 voxel-steps/s (~47-48 us per step), the default `--steps 2000` ~1.10e10 (~32.4 us) -- same kernel, same population; `timed_region` in
@@ -345,7 +345,8 @@ def main():
                             "population without self-collision, ~0.27 ms for this one (prologue/epilogue of two robots per CU ~0.04 ms; the "
                             "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.17 ms per run, ~50 of 512 robots in "
                             "any 20-step launch).  Per step WITHOUT that cost: ~30.5 us.  --steps 20 times ONE 20-step launch (~47-48 us per "
-                            "step, ~7.4-7.6e9 voxel-steps/s); the default --steps 2000 times eight launches of up to 256 steps (~32.4 us, ~1.10e10).  "
+                            "step, ~7.4-7.6e9 voxel-steps/s); the default --steps 2000 times two launches of up to 1024 steps (~31.5 us, ~1.13e10; eight launches of 250 "
+                            "steps until late in round 2: ~32.2 us).  "
                             "DESIGN.md section 4 'The cost of a launch'"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,

@@ -67,7 +67,10 @@ private:
     int graph_steps_ = 32;                     // streaming path: step rounds captured per hipGraph launch (0 = plain launches)
     int dbg_ = 0;
     bool fused_ = true;                        // one-workgroup-per-robot fused kernel when every robot has <= 1024 voxels
-    int steps_per_launch_ = 256;               // fused and tiled paths: time steps per kernel launch
+    // fused and tiled paths: time steps per kernel launch.  A launch of a self-colliding population carries ~0.27 ms of fixed cost (it
+    // ends with its slowest workgroup: DESIGN.md "The cost of a launch"); a whole evaluation of the bench population (7806 steps),
+    // us per step by launch length: 256: 31.2 | 512: 30.7 | 1024: 30.6 | 2048: 30.6 | 8192 (one launch): 30.3.  (256 until late in round 2.)
+    int steps_per_launch_ = 1024;
     int tiled_ = 1;                            // several workgroups per robot (kernels_tiled.hpp): 0 never, 1 when the population is too
                                                // small to fill the CUs one robot each or a robot has more than 1024 voxels, 2 always
     int tiles_per_robot_ = 0;                  // 0 = chosen from the population size; > 0: requested for every tiled robot (tests)

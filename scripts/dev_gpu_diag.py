@@ -564,3 +564,26 @@ if __name__ == "__main__" and "tilepolicy" in sys.argv[1:]:
     for count, n, sim_time in ((64, 6, 0.1), (64, 7, 0.08), (64, 8, 0.06), (64, 9, 0.05), (64, 10, 0.04), (16, 10, 0.04), (128, 8, 0.06), (128, 10, 0.04)):
         for opts in ({"tiled": 0}, {}):
             timing_cfg(engine.VOXCAD, count, (n, n, n), sim_time, Env(), opts)
+
+
+if __name__ == "__main__" and "launchlen" in sys.argv[1:]:
+    # how long should a launch of the resident kernel be?  A whole evaluation (0.5 s simulated, 7806 steps) of the bench population with
+    # launches of L steps: kernel time and wall time of vxh_run
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    sim = Sim(self_collisions_enabled=True, dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1)
+    paths = []
+    for ind in workloads.population(512, (10, 10, 10)):
+        write_voxelyze_file(sim, Env(), ind, tmp, "L")
+        paths.append(os.path.join(tmp, "voxelyzeFiles", "L--id_%05i.vxa" % ind.id))
+    _warm_up(engine.VOXCAD, {"tiled": 0})
+    for L in (256, 512, 1024, 2048, 4096, 8192, 256):
+        with engine.Engine(engine.VOXCAD, 0) as eng:
+            eng.set_option("steps_per_launch", L)
+            eng.add_vxa_files(paths)
+            t0 = time.perf_counter()
+            eng.run()
+            wall = time.perf_counter() - t0
+            c = eng.counters()
+            print("steps per launch %5d: %3d launches, kernel %.4f s = %.2f us per step, vxh_run wall %.4f s; all finished: %s" % (
+                L, c.launches, c.kernel_seconds, 1e6 * c.kernel_seconds / c.max_steps, wall, all(eng.result(i).status == 1 for i in range(len(paths)))), flush=True)
