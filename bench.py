@@ -20,7 +20,7 @@ N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak
 READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 1024 steps (engine option steps_per_launch), and a
 launch of a self-colliding population carries ~0.27 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
 robots run a ~0.17 ms collision broad-phase).  `--steps 20 --warmup 5` (what the round-end driver runs) therefore reports ~7.4-7.6e9
-voxel-steps/s (~47-48 us per step), the default `--steps 2000` ~1.10e10 (~32.4 us) -- same kernel, same population; `timed_region` in
+voxel-steps/s (~47-48 us per step), the default `--steps 2000` ~1.13e10 (~31.4 us) -- same kernel, same population; `timed_region` in
 the line says which case it is.  (Round 1's line for `--steps 20` was 9.5e9, on CHEAPER physics: it timed steps 6-25 from rest;
 this one pre-advances past InitCmTime first, as the round-1 review asked.)
 
@@ -30,7 +30,7 @@ The JSON line also carries
                 this workload (newest profiles/r*_hbm_traffic.json), also in GB/s -- rates, comparable whatever the launch length.
                 `traffic` counts the L2's MEMORY-SIDE requests (FETCH_SIZE / WRITE_SIZE; Infinity-Cache hits included), i.e. an
                 upper bound of the HBM bytes, and it lies far BELOW `achieved`: the bond history of the robots resident on an
-                XCD fits its L2 (hit rate 0.96, profiles/r02_l2_counters.txt), so most algorithmic bytes never leave the chip.
+                XCD fits its L2 (hit rate 0.97, profiles/r02_l2_counters.txt), so most algorithmic bytes never leave the chip.
                 `achieved / peak` is therefore not a statement that the kernel is HBM-bound -- it is bound by FP64 issue
                 (DESIGN.md section 4).
   other_configs the other BASELINE configs at their stated sizes (64 x 6^3 walkers, 64 x 8^3 swimmers, one 20^3 lattice),
@@ -336,7 +336,7 @@ def main():
                              "alg_bytes_per_voxel_step": c1.dominant_alg_bytes / max(1.0, c1.dominant_voxel_steps),
                              "note": "achieved = (224*Nvox + 144*Nbond) bytes per voxel-step x steps / HIP-event time of "
                                      "the dominant kernel on its stream; achieved and traffic are both rates (GB/s); traffic << "
-                                     "achieved because the resident robots' bond history is served by the L2 (hit rate 0.96): the "
+                                     "achieved because the resident robots' bond history is served by the L2 (hit rate 0.97): the "
                                      "kernel is FP64-issue-bound, not HBM-bound"},
                 "timed_region": {
                     "launches": int(c1.dominant_launches),          # (of the timed call: this counter is per call, not cumulative)
