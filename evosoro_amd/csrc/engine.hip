@@ -408,11 +408,30 @@ void Engine::set_option(const std::string& key, double value)
     else throw std::invalid_argument("unknown option " + key);
 }
 
+// where the host-side time of a run goes (VXH_PROF_HOST=1: one line per prepare() / advance() on stderr)
+namespace {
+struct HostStages {
+    const bool on = std::getenv("VXH_PROF_HOST") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    std::string line;
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96]; std::snprintf(buf, sizeof(buf), " %s %.1f ms |", what, 1e3 * std::chrono::duration<double>(now - t).count());
+        line += buf; t = now;
+    }
+    void print(const char* head) { if (on) std::fprintf(stderr, "%s:%s\n", head, line.c_str()); }
+};
+}
+
 void Engine::prepare()
 {
+    HostStages hs;
     HIP_OK(hipSetDevice(device_id_));
     Device& D = *dev_;
     D.free_all();
+    hs.mark("free");
     const int nr = (int)robots_.size();
     std::vector<DVoxClass> vtab;
     std::vector<DBondClass> btab;
@@ -629,6 +648,7 @@ void Engine::prepare()
         worker();
         for (auto& t : pool) t.join();
     }
+    hs.mark("host assembly");
     DBatch& B = D.B;
     B.n_robots = nr; B.nv = nv; B.dbg = dbg_;
     B.robot = D.upload(D.h_robot);
@@ -679,6 +699,7 @@ void Engine::prepare()
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
     B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
     B.col_a1 = D.alloc_zero<double>((size_t)std::max(ns, 1) * VXH_MAXCOL);
+    hs.mark("allocations + uploads");
     // Which kernel steps which robot.  Resident kernel (kernels_fused.hpp), one workgroup per robot: its variant is a function
     // of the robot alone (size, fluid, LDS need of its own tables), never of the batch.
     struct FusedVariant { int block = 0, nacc = 0, fluid = 0, tabg = 0; size_t lds = 0; };
@@ -894,6 +915,8 @@ void Engine::prepare()
     B.small_angle_w = std::cos(VXH_SMALL_ANGLE_RAD * 0.5);                    // Vec3D.h:55-59
     B.smallish_angle_w = std::cos(VXH_HYST * VXH_SMALL_ANGLE_RAD * 0.5);
     B.slthresh_acos2sqrt = 1.0 - 0.9988 * 0.9988;
+    hs.mark("kernel choice, tiling, launch groups");
+    hs.print("prepare");
     prepared_ = true;
     state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
     host_.clear();
@@ -966,6 +989,7 @@ void Engine::advance(long long max_rounds)
     // per-robot step counts before, to attribute the work of this call
     std::vector<int> steps_before(robots_.size());
     for (size_t r = 0; r < robots_.size(); ++r) steps_before[r] = host_.size() == robots_.size() ? host_[r].steps : 0;
+    HostStages hs;
     HIP_OK(hipEventRecord(D.ev0, D.stream));
     long long launches = 0;
     std::vector<long long> group_launches(D.groups.size(), 0);
@@ -1037,7 +1061,10 @@ void Engine::advance(long long max_rounds)
     counters_.launches += launches;
     rounds_done_ += todo;
     state_downloaded_ = reduced_downloaded_ = false;
+    hs.mark("launches + wait for the GPU");
     download_control();
+    hs.mark("control blocks back");
+    hs.print("advance");
 
     // dominant kernel of this call: the launch group that processed most voxel-steps (fused) / the whole call (streaming)
     std::vector<double> grp_vs(D.groups.size(), 0.0), grp_ab(D.groups.size(), 0.0);
