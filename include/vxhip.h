@@ -170,12 +170,20 @@ int  vxh_get_counters(const vxh_engine* e, vxh_counters* out);
  * should say which mix it was measured on */
 int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long long* total_out);
 /* Options (all have working defaults):
- *   "tiled"             0 = never, 1 (default) = robots of more than 1024 voxels and populations smaller than 3/4 of the CUs are
- *                       stepped by the multi-workgroup kernel, 2 = every robot it supports; "tiles_per_robot" > 0 requests a tile count.
- *                       Both belong to the uploaded batch: set them before the first vxh_run / vxh_step (VXH_ERR_STATE afterwards,
- *                       until vxh_reset).  The tiles of a robot wait for each other on the device: the engine must own its GPU
- *                       (with another process on the same GPU set "tiled" to 0).
- *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 256)
+ *   "tiled"             0 = never; 1 (default) = the robots the one-workgroup-per-robot kernel cannot take (more than 1024 voxels,
+ *                       oversized class tables) are stepped by the multi-workgroup kernel; 2 = every robot it supports (tests).
+ *                       With the default, which kernel steps a robot depends on the robot alone, so its result is the same, bit for
+ *                       bit, whatever batch it is in.
+ *   "tile_small"        1 = also tile large robots (more than 512 voxels) when the population occupies at most a quarter of the CUs:
+ *                       6-14 % faster there (64 or fewer robots of 10x10x10 per GPU), at the price that such a robot's last bits then
+ *                       depend on the population it is evaluated in (the two kernels agree to 1e-12 voxel, not to the bit).  Default 0.
+ *   "tiles_per_robot"   > 0 requests a tile count (tests).
+ *                       These three belong to the uploaded batch: set them before the first vxh_run / vxh_step (VXH_ERR_STATE
+ *                       afterwards, until vxh_reset).  The tiles of a robot wait for each other on the device: an engine that tiles
+ *                       must own its GPU (with another process on the same GPU set "tiled" to 0).
+ *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 1024).  A launch of a self-colliding population
+ *                       carries ~0.27 ms of fixed cost, so vxh_step(e, n) with a small n is paid for: 20 steps at a time run at
+ *                       ~47 us per step where 1000 at a time run at ~31.5 (512 robots of 10x10x10).
  *   "fused"             0 = robots the tiled kernel does not take go through the streaming kernels (cross-checks)
  *   "graph_steps"       streaming kernels: step rounds per captured hipGraph (0 = plain launches)
  *   "host_results"      1 = vxh_get_result evaluates every tag on the host from the downloaded voxel state instead of from the
