@@ -37,7 +37,8 @@ The JSON line also carries
                 N = 1 only: value, us per step, algorithmic roofline fraction, kernel
   cpu_baseline  the reference C++ voxelyze (oracle/_ref/voxelyze_ref, built from the reference sources) on this box's host
                 cores: `nproc` concurrent processes on 2 x nproc robots of the bench population (evaluation.py:89 launches
-                one process per robot and lets the OS schedule them), plus the single-process figure; rank 0, N = 1 only.
+                one process per robot and lets the OS schedule them), plus the single-process figure, plus the single-process figure of the
+                build the reference SHIPS (-O0 library objects; the others are -O3); rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -115,13 +116,20 @@ def cpu_baseline(shape):
             used = min(walls, key=walls.get)
             wall = walls[used]
             one = run_reference(ref, paths[:1], tmp, 1)
+            # context: the same robot with the optimisation level the reference SHIPS with (its library objects are compiled with an
+            # empty CXXFLAGS = -O0); every other figure here is the -O3 build, which flatters the reference
+            ref_O0 = ref + "_O0"
+            one_O0 = run_reference(ref_O0, paths[:1], tmp, 1) if os.path.exists(ref_O0) else None
             return {"value": work_of(paths) / wall, "unit": "voxel-timesteps/s", "cores": used, "kind": "reference",
                     "nproc": nproc, "single_core_value": work_of(paths[:1]) / one,
+                    "single_core_value_shipped_flags": (work_of(paths[:1]) / one_O0) if one_O0 else None,
                     "sample": "%d random %dx%dx%d robots of the bench population, %.2f s simulated each (%.3g voxel-steps), one process per "
                               "robot (evaluation.py:89), g++ -O3 build of the reference sources, host with %d hardware threads: %s; "
-                              "value = the faster; single_core_value: one robot alone, %.1f s"
+                              "value = the faster; single_core_value: one robot alone, %.1f s; single_core_value_shipped_flags: the same robot "
+                              "with the reference's own -O0 library build, %s"
                               % (len(paths), shape[0], shape[1], shape[2], sim_time, work_of(paths), nproc,
-                                 ", ".join("%d at a time %.1f s" % (u, w) for u, w in sorted(walls.items())), one)}
+                                 ", ".join("%d at a time %.1f s" % (u, w) for u, w in sorted(walls.items())), one,
+                                 ("%.1f s" % one_O0) if one_O0 else "binary not built")}
         from oracle import vxoracle
         t0 = time.time()
         for p in paths[:4]:
