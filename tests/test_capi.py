@@ -103,3 +103,23 @@ def test_convex_hull_volume_known_answers():
     assert abs(hull(sphere) - 4.12888859762) < 1e-10                          # qhull FS: 4.12888859762
     # order of the points does not matter
     assert abs(hull(sphere[::-1]) - hull(sphere)) < 1e-13
+
+
+def test_every_engine_option_is_documented_in_the_header():
+    """include/vxhip.h is where a caller learns the keys of vxh_set_option and their defaults.  Its list went stale once (round 2: it
+    still described a tiling policy and a launch length that had been replaced), so: every key Engine::set_option accepts must be
+    named there -- except "dbg", which only exists in the developer library -- and the default launch length it states must be the
+    engine's."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    src = open(os.path.join(root, "evosoro_amd", "csrc", "engine.hip")).read()
+    body = src[src.index("void Engine::set_option("):]
+    body = body[:body.index("\n}\n")]
+    keys = set(re.findall(r'key == "([a-z_]+)"', body))
+    assert {"tiled", "tile_small", "steps_per_launch", "fused"} <= keys          # (the parse found the function)
+    header = open(os.path.join(root, "include", "vxhip.h")).read()
+    doc = header[header.index("/* Options (all have working defaults):"):header.index("int  vxh_set_option(")]
+    missing = sorted(k for k in keys - {"dbg"} if '"%s"' % k not in doc)
+    assert not missing, "options accepted by the engine but not documented in include/vxhip.h: %s" % missing
+    default = re.search(r"int steps_per_launch_ = (\d+);", open(os.path.join(root, "evosoro_amd", "csrc", "engine.hpp")).read()).group(1)
+    assert re.search(r'"steps_per_launch".*\(default %s\)' % default, doc), "the header's default of steps_per_launch is not %s" % default
