@@ -67,3 +67,41 @@ def test_cli_over_a_device_list(golden_dir, tmp_path):
         fit = d / "golden_run" / "fitnessFiles"
         outs[devs] = {f: (fit / f).read_text() for f in sorted(os.listdir(fit))}
     assert len(outs["0"]) == 4 and outs["0"] == outs["0,0"]
+
+
+def test_more_engines_than_robots_and_reuse_of_the_handle(golden_dir):
+    """Edge cases of the several-devices handle: three engines for two robots (one engine holds nothing), an empty handle, and the
+    handle used again after vxh_reset and after vxh_clear -- every time the results of the one-device engine, bit for bit."""
+    from evosoro_amd import engine as eng_mod
+    paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in ("probe6", "rand6_col")]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as one:
+        one.set_option("tiled", 0)
+        for p in paths:
+            one.add_vxa_file(p)
+        one.run()
+        want = [one.result(i) for i in range(2)]
+        one.reset()
+        one.step(300)
+        want_300 = [one.state(i) for i in range(2)]
+    with eng_mod.Engine(eng_mod.VOXCAD, (0, 0, 0)) as many:
+        assert many.num_robots() == 0
+        many.run()                                        # nothing to do is not an error
+        for p in paths:
+            many.add_vxa_file(p)
+        many.run()
+        for i in range(2):
+            assert _same(many.result(i), want[i]), i
+        large, total = many.bond_modes()
+        assert 0 <= large <= total and total > 0
+        many.reset()                                      # same robots, from the start
+        many.step(300)
+        for i in range(2):
+            assert np.array_equal(many.state(i), want_300[i]), i
+        many.run()
+        for i in range(2):
+            assert _same(many.result(i), want[i]), i
+        many.clear()
+        assert many.num_robots() == 0
+        many.add_vxa_file(paths[1])                       # a different population afterwards
+        many.run()
+        assert _same(many.result(0), want[1])
