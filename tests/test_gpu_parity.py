@@ -758,6 +758,17 @@ def test_in_memory_hand_off_builds_the_same_robots(eng_mod, tmp_path):
         with pytest.raises(eng_mod.VxhError):
             bad.add_robots(texts[0], [(np.full((2, 2, 2), 9), OrderedDict(), None)])
         assert bad.num_robots() == 0
+        # all or nothing: a bad robot after good ones adds none of the call's robots, and the engine stays usable
+        good = (np.ones((2, 2, 2), dtype=int), OrderedDict(), None)
+        with pytest.raises(eng_mod.VxhError):
+            bad.add_robots(texts[0], [good, good, (np.full((2, 2, 2), 9), OrderedDict(), None)])
+        assert bad.num_robots() == 0
+        assert bad.add_robots(texts[0], [good, good]) == 0 and bad.num_robots() == 2
+        with pytest.raises(eng_mod.VxhError):
+            bad.add_robots(texts[0], [good, (np.ones((2, 2, 2), dtype=int), OrderedDict([("<VestigialLimbs>", np.zeros((2, 2, 2)))]), None)])
+        assert bad.num_robots() == 2
+        bad.step(10)
+        assert all(bad.result(i).steps == 10 for i in range(2))
 
 
 @pytest.mark.parametrize("in_memory", [False, True])
