@@ -40,6 +40,12 @@ struct DRobot {               // constant per robot
     double trace_dt;              // <TimeBetweenTraces>, 0 = no centre-of-mass trace
     int trace_begin, trace_cap;   // this robot's entries of DBatch::trace
     float temp_amplitude, temp_period;
+    long long col_begin;          // first entry of this robot's block of contact rows in DBatch::col_partner / col_a1 / col_code
+    int col_cap, pad1;            // partners a row can hold.  Default nsurf - 1: every other surface voxel, i.e. unbounded like the
+                                  // reference's lists (CreateColBond, VX_Sim.cpp:753-769); engine option col_cap sets a smaller one
+    // wide kernel (kernels_wide.hpp): the robot's combined bond list in DBatch::wlist and its length, the record number that stays zero (what the
+    // missing directions of a voxel point at), doubles of LDS its bond records / scratch take
+    int wl_begin, wnbond, wzidx, wregion;
 };
 
 struct DRobotState {          // mutable per robot
@@ -109,7 +115,7 @@ struct DResult {
     int touching, feet;           // voxels below the floor plane, and those of material 6 among them (GetNumTouchingFloor :2660-2712)
 };
 
-enum { VXH_MAXCOL = 64 };     // collision partners kept per surface voxel (overflow -> VXH_ROBOT_COL_OVERFLOW)
+// (collision partners per surface voxel: DRobot::col_cap; a row that would need more -> VXH_ROBOT_COL_OVERFLOW)
 
 // all device pointers of a batch; passed to kernels by value
 struct DBatch {
@@ -124,6 +130,10 @@ struct DBatch {
     const unsigned short* vclass;     // [nv] robot-local class id
     const short* bclass;              // [3*nv] axis-major, robot-local class id, -1 = no bond
     const int* nbr;                   // [6*nv] direction-major, global voxel slot or -1
+    const int* wlist;                 // wide kernel: per robot (DRobot::wl_begin) ALL its bonds in one list, axis after axis, entry = local
+                                      // negative-end voxel | local positive-end voxel << 9 | axis << 18 | bond class << 20
+    const int* wgather;               // [2][nv] wide kernel: the records of the voxel's six bonds (+X -X +Y -Y +Z -Z, 10 bits each, three
+                                      // per word; DRobot::wzidx where the voxel has no bond in that direction)
     const int* blist;                 // [3*nv] fused path: per robot and axis the COMPACTED list of its bonds, entry t of axis a at
                                       // [a*nv + vox_begin + t] = local negative-end voxel | local positive-end voxel << 10 |
                                       // bond class << 20, -1 past the end of the list
@@ -152,7 +162,7 @@ struct DBatch {
                                       // bit j of row i set when surface voxels i and j are within the hop horizon
     int* col_cnt;                     // [total surface voxels]
     int col_rows, pad2;               // total surface voxels of colliding robots
-    int* col_partner;                 // [VXH_MAXCOL][col_rows] (partner-major) global voxel slots
+    int* col_partner;                 // per robot a block [col_cap][nsurf] (partner-major; kernels.hpp col_at) of global voxel slots
     double* col_a1;                   // same shape: linear stiffness a1 of that collision bond
     // land_water fluid drag (LW/VX_Sim.cpp:1516-1597): deformable surface mesh of every fluid robot
     int total_mv, pad3;               // mesh vertices of all fluid robots

@@ -38,6 +38,7 @@ struct Engine::Device {
     // stream per group so that the groups fill the chip together
     struct Group {
         int block = 0, nacc = 0, fluid = 0, tabg = 0;   // template arguments of k_robot_steps
+        int wide = 0;                     // 1: k_robot_wide<block, fluid, tabg> (kernels_wide.hpp)
         int count = 0;
         const int* list = nullptr;
         size_t lds = 0;                   // dynamic LDS bytes
@@ -102,6 +103,15 @@ struct Engine::Device {
         HIP_OK(hipMalloc(&p, n * sizeof(T)));
         allocs.push_back(p);
         HIP_OK(hipMemset(p, 0, n * sizeof(T)));
+        return (T*)p;
+    }
+    template <class T>
+    T* alloc_raw(size_t n)
+    {
+        void* p = nullptr;
+        if (n == 0) n = 1;
+        HIP_OK(hipMalloc(&p, n * sizeof(T)));
+        allocs.push_back(p);
         return (T*)p;
     }
     void free_all()
@@ -397,10 +407,14 @@ void Engine::set_option(const std::string& key, double value)
     if (key == "fused") { fused_ = value != 0; drop_graph(); }
     else if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
     else if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); steps_per_launch_ = (int)value; }
-    else if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small") {
-        // the tiling is part of the uploaded batch: set before the first vxh_run / vxh_step, or follow with vxh_reset
-        if (prepared_) throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or call vxh_reset after it)");
-        if (key == "tiled") { if (value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2"); tiled_ = (int)value; }
+    else if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "col_cap") {
+        // which kernel steps a robot, its tiling and the size of its contact rows are part of the uploaded batch: set before the first
+        // vxh_run / vxh_step, or right after vxh_reset (no step taken yet: the batch is then assembled again at the next run)
+        if (prepared_ && rounds_done_ > 0) throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or right after vxh_reset)");
+        prepared_ = false;
+        if (key == "wide") { if (value != 0 && value != 1) throw std::invalid_argument("wide: 0 or 1"); wide_ = value != 0; }
+        else if (key == "col_cap") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("col_cap out of range"); col_cap_ = (int)value; }
+        else if (key == "tiled") { if (value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2"); tiled_ = (int)value; }
         else if (key == "tile_small") { if (value != 0 && value != 1) throw std::invalid_argument("tile_small: 0 or 1"); tile_small_ = value != 0; }
         else { if (!(value >= 0 && value <= 4096)) throw std::invalid_argument("tiles_per_robot out of range"); tiles_per_robot_ = (int)value; }
     }
@@ -433,6 +447,22 @@ void Engine::prepare()
     D.free_all();
     hs.mark("free");
     const int nr = (int)robots_.size();
+    // Wide kernel (kernels_wide.hpp; robots of up to WIDE_BLOCK voxels and 1023 bonds): its bond records share their LDS region with
+    // the scratch of the whole-robot passes (12 * BLOCK doubles, then the mesh vertices of a robot in a fluid); the record that stays
+    // zero lies behind both.  A function of the robot alone, like every kernel choice.
+    constexpr int WIDE_BLOCK = 512;
+    struct WideLayout { int zidx = 0, region = 0; };
+    auto wide_layout = [&](const RobotModel& M) {
+        WideLayout W;
+        const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
+        const int scratch = 12 * WIDE_BLOCK + (in_fluid ? 3 * M.nmv : 0);
+        W.zidx = std::max(M.nbond, (scratch + VXH_WIDE_REC - 1) / VXH_WIDE_REC);
+        W.region = (VXH_WIDE_REC * (W.zidx + 1) + 1) & ~1;
+        return W;
+    };
+    auto wide_listed = [&](const RobotModel& M) {
+        return wide_ && M.nvox > 0 && M.nvox <= WIDE_BLOCK && M.nbond <= 1023 && M.bond_classes.size() <= 4095 && wide_layout(M).zidx <= 1023;
+    };
     std::vector<DVoxClass> vtab;
     std::vector<DBondClass> btab;
     D.h_robot.assign(nr, DRobot{});
@@ -454,6 +484,7 @@ void Engine::prepare()
     if ((long long)nv * 36 >= (1LL << 32))
         throw std::invalid_argument("batch too large for one engine (" + std::to_string(nv) + " voxel slots; limit 119 million): split the population");
     D.total_surf = ns;
+    long long col_total = 0;
     // centre-of-mass traces (<TimeBetweenTraces>): one entry at most every trace_dt of simulated time after InitCmTime
     D.trace_begin.assign(nr, 0); D.trace_cap.assign(nr, 0); D.total_trace = 0;
     for (int r = 0; r < nr; ++r) {
@@ -473,6 +504,7 @@ void Engine::prepare()
     std::vector<unsigned short> vclass(nv, 0);
     std::vector<short> bclass((size_t)3 * nv, -1);
     std::vector<int> blist((size_t)3 * nv, -1);
+    std::vector<int> wgather((size_t)2 * nv, 0);
     std::vector<float> amp_damp(nv, 1.f);
     std::vector<double> act_sb(nv, 0.0), act_cb(nv, 1.0);
     bool any_dev = false;
@@ -500,15 +532,23 @@ void Engine::prepare()
     std::vector<DRobotState> rstate(nr);
 
     // offsets of the per-robot pieces of the shared tables, then the robots are assembled on the host cores (disjoint ranges)
-    std::vector<int> vtab_off(nr + 1, 0), btab_off(nr + 1, 0);
-    std::vector<long long> excl_off(nr + 1, 0);
+    std::vector<int> vtab_off(nr + 1, 0), btab_off(nr + 1, 0), wl_off(nr + 1, 0);
+    std::vector<long long> excl_off(nr + 1, 0), col_off(nr + 1, 0);
+    std::vector<int> col_cap(nr, 0);
     for (int r = 0; r < nr; ++r) {
         const RobotModel& M = robots_[r];
         if (M.vox_classes.size() > 32767 || M.bond_classes.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one robot");
         vtab_off[r + 1] = vtab_off[r] + (int)M.vox_classes.size();
         btab_off[r + 1] = btab_off[r] + (int)M.bond_classes.size();
         excl_off[r + 1] = excl_off[r] + (M.vxa.self_col_enabled ? (long long)M.nsurf * ((M.nsurf + 63) / 64) : 0);
+        // contact rows: as long as the physics makes them -- a surface voxel can list every other one (CreateColBond, VX_Sim.cpp:753-769,
+        // has no cap) -- unless the option col_cap bounds them; 12-16 bytes per entry, untouched beyond the partners a row really has
+        col_cap[r] = M.vxa.self_col_enabled ? std::max(1, col_cap_ > 0 ? std::min(col_cap_, M.nsurf - 1) : M.nsurf - 1) : 0;
+        col_off[r + 1] = col_off[r] + (long long)col_cap[r] * (M.vxa.self_col_enabled ? M.nsurf : 0);
+        wl_off[r + 1] = wl_off[r] + (wide_listed(M) ? M.nbond : 0);
     }
+    std::vector<int> wlist(std::max(wl_off[nr], 1), -1);
+    col_total = col_off[nr];
     vtab.resize(vtab_off[nr]);
     btab.resize(btab_off[nr]);
     excl.assign((size_t)excl_off[nr], 0ull);
@@ -564,6 +604,34 @@ void Engine::prepare()
                     if (c >= 0) blist[(size_t)a * nv + base + t++] = (int)((unsigned)v | ((unsigned)M.nbr[(size_t)v * 6 + 2 * a] << 10) | ((unsigned)c << 20));
                 }
             }
+        DRobot& R = D.h_robot[r];
+        R.wl_begin = wl_off[r]; R.wnbond = 0; R.wzidx = 0; R.wregion = 0;
+        if (wide_listed(M)) {
+            // wide kernel: all bonds in one list, axis after axis; a bond's place in it is the number of its record, and every voxel
+            // learns the records of its six directions (+A: the bond it is the negative end of; -A: that of its -A neighbour)
+            const WideLayout W = wide_layout(M);
+            std::vector<int> slot_of((size_t)M.nvox * 3, -1);
+            int t = 0;
+            for (int a = 0; a < 3; ++a)
+                for (int v = 0; v < M.nvox; ++v) {
+                    const int c = M.bond_class[(size_t)v * 3 + a];
+                    if (c < 0) continue;
+                    slot_of[(size_t)v * 3 + a] = t;
+                    wlist[wl_off[r] + t++] = (int)((unsigned)v | ((unsigned)M.nbr[(size_t)v * 6 + 2 * a] << 9) | ((unsigned)a << 18) | ((unsigned)c << 20));
+                }
+            for (int v = 0; v < M.nvox; ++v) {
+                int idx[6];
+                for (int a = 0; a < 3; ++a) {
+                    idx[2 * a] = slot_of[(size_t)v * 3 + a];
+                    const int n = M.nbr[(size_t)v * 6 + 2 * a + 1];
+                    idx[2 * a + 1] = n >= 0 ? slot_of[(size_t)n * 3 + a] : -1;
+                }
+                for (int d = 0; d < 6; ++d) if (idx[d] < 0) idx[d] = W.zidx;
+                wgather[base + v] = idx[0] | (idx[1] << 10) | (idx[2] << 20);
+                wgather[(size_t)nv + base + v] = idx[3] | (idx[4] << 10) | (idx[5] << 20);
+            }
+            R.wnbond = M.nbond; R.wzidx = W.zidx; R.wregion = W.region;
+        }
         if (X.self_col_enabled)
             for (int i = 0; i < M.nsurf; ++i) { surf[D.surf_begin[r] + i] = base + M.surf[i]; surf_ord[base + M.surf[i]] = i; }
         // CalcNearby exclusion lists as bit rows over surface ordinals
@@ -581,7 +649,7 @@ void Engine::prepare()
                 }
             }
         }
-        DRobot& R = D.h_robot[r];
+        R.col_begin = col_off[r]; R.col_cap = col_cap[r];
         R.vox_begin = base; R.nvox = M.nvox; R.surf_begin = D.surf_begin[r]; R.nsurf = X.self_col_enabled ? M.nsurf : 0;
         R.flags = (X.self_col_enabled ? RF_SELF_COL : 0) | (X.grav_enabled ? RF_GRAV : 0) | (X.floor_enabled ? RF_FLOOR : 0) |
                   (X.temp_enabled ? RF_TEMP : 0) | ((X.sticky_floor && variant_ == 0) ? RF_STICKY : 0) |
@@ -660,6 +728,8 @@ void Engine::prepare()
     B.bclass = D.upload(bclass);
     B.nbr = D.upload(nbr);
     B.blist = D.upload(blist);
+    B.wlist = D.upload(wlist);
+    B.wgather = D.upload(wgather);
     B.act_sb = D.upload(act_sb);
     B.act_cb = D.upload(act_cb);
     B.amp_damp = D.upload(amp_damp);
@@ -697,17 +767,35 @@ void Engine::prepare()
     B.trace = D.alloc_zero<double>((size_t)std::max(D.total_trace, 1) * 4);
     B.col_rows = std::max(ns, 1);
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
-    B.col_partner = D.alloc_zero<int>((size_t)std::max(ns, 1) * VXH_MAXCOL);
-    B.col_a1 = D.alloc_zero<double>((size_t)std::max(ns, 1) * VXH_MAXCOL);
+    B.col_partner = D.alloc_raw<int>((size_t)std::max<long long>(col_off[nr], 1));     // (entries beyond col_cnt are never read)
+    B.col_a1 = D.alloc_raw<double>((size_t)std::max<long long>(col_off[nr], 1));
     hs.mark("allocations + uploads");
     // Which kernel steps which robot.  Resident kernel (kernels_fused.hpp), one workgroup per robot: its variant is a function
     // of the robot alone (size, fluid, LDS need of its own tables), never of the batch.
-    struct FusedVariant { int block = 0, nacc = 0, fluid = 0, tabg = 0; size_t lds = 0; };
+    struct FusedVariant { int block = 0, nacc = 0, fluid = 0, tabg = 0, wide = 0; size_t lds = 0; };
     auto fused_variant = [&](const RobotModel& M) {
         FusedVariant fv;
         const size_t lds_max = 160 * 1024 - VXH_FUSED_STATIC_LDS;
         const int n = M.nvox;
         if (n == 0 || n > 1024 || M.bond_classes.size() > 4095) return fv;   // (12 class bits in a bond entry; a robot of 1024 voxels has at most 3072 bonds)
+        if (wide_listed(M)) {
+            // the wide kernel when its LDS layout fits (mirrors the top of k_robot_wide): pose tile, record region, class tables,
+            // the strain tile of a land_water robot, the mask + pool of the contact rows
+            const WideLayout W = wide_layout(M);
+            const int mesh = M.nmv > 0 ? 1 : 0;
+            auto wneed = [&](bool tables_in_lds) {
+                return (size_t)(8 * WIDE_BLOCK + W.region) * 8 +
+                       (tables_in_lds ? M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) : 0) +
+                       (mesh ? (size_t)48 * WIDE_BLOCK : 0) + (M.vxa.self_col_enabled ? (size_t)8 * WIDE_BLOCK : 0);
+            };
+            const int wtabg = wneed(true) > lds_max ? 1 : 0;
+            if (wneed(!wtabg) <= lds_max) {
+                fv.block = WIDE_BLOCK; fv.nacc = 0; fv.fluid = mesh; fv.tabg = wtabg; fv.wide = 1; fv.lds = wneed(!wtabg);
+                if (M.vxa.self_col_enabled && lds_max > fv.lds) fv.lds += std::min<size_t>(lds_max - fv.lds, (size_t)24 * 1024);
+                fv.lds &= ~(size_t)7;
+                return fv;
+            }
+        }
         const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
         const int fluid = M.nmv > 0 ? 1 : 0;      // (the MESH variants: every land_water robot carries the surface mesh)
         const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
@@ -847,7 +935,7 @@ void Engine::prepare()
             for (int k = 0; k < h_tiles[t].n_own; ++k) { const int g = tile_vox[h_tiles[t].vox_off + k]; tile_of[g] = (int)t; tile_lidx[g] = k; }
         B.tile_of = D.upload(tile_of);
         B.tile_lidx = D.upload(tile_lidx);
-        B.col_code = D.alloc_zero<int>(h_tiles.empty() ? 1 : (size_t)std::max(ns, 1) * VXH_MAXCOL);
+        B.col_code = D.alloc_raw<int>(h_tiles.empty() ? 1 : (size_t)std::max<long long>(col_total, 1));
         B.tile_xh = D.alloc_zero<int>(std::max<size_t>(1, h_tiles.size()) * VXH_TILE_XH);
         B.tile_xhn = D.alloc_zero<int>(std::max<size_t>(1, h_tiles.size()));
     }
@@ -868,8 +956,8 @@ void Engine::prepare()
             const FusedVariant fv = fused_variant(robots_[r]);
             if (fv.block == 0) continue;                              // streaming kernels
             Device::Group* g = nullptr;
-            for (auto& q : D.groups) if (q.block == fv.block && q.nacc == fv.nacc && q.fluid == fv.fluid && q.tabg == fv.tabg) g = &q;
-            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = fv.block; g->nacc = fv.nacc; g->fluid = fv.fluid; g->tabg = fv.tabg; }
+            for (auto& q : D.groups) if (q.block == fv.block && q.nacc == fv.nacc && q.fluid == fv.fluid && q.tabg == fv.tabg && q.wide == fv.wide) g = &q;
+            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = fv.block; g->nacc = fv.nacc; g->fluid = fv.fluid; g->tabg = fv.tabg; g->wide = fv.wide; }
             g->robots.push_back(r);
             g->lds = std::max(g->lds, fv.lds);
         }
@@ -965,8 +1053,21 @@ static void launch_sized(const DBatch& B, int block, const int* list, int count,
     else launch_variant<1024, 1, FLUID, TABG>(B, list, count, lds, s, cap, iters);
 }
 
-static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+template <int BLOCK, bool MESH, bool TABG>
+static void launch_wide(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
+    static size_t granted[64] = {};
+    grant_dynamic_lds((const void*)k_robot_wide<BLOCK, MESH, TABG>, granted, lds);
+    hipLaunchKernelGGL((k_robot_wide<BLOCK, MESH, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
+}
+
+static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool wide, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+{
+    if (wide) {
+        if (fluid) { if (tabg) launch_wide<512, true, true>(B, list, count, lds, s, cap, iters); else launch_wide<512, true, false>(B, list, count, lds, s, cap, iters); }
+        else { if (tabg) launch_wide<512, false, true>(B, list, count, lds, s, cap, iters); else launch_wide<512, false, false>(B, list, count, lds, s, cap, iters); }
+        return;
+    }
     if (fluid) { if (tabg) launch_sized<true, true>(B, block, list, count, lds, s, cap, iters); else launch_sized<true, false>(B, block, list, count, lds, s, cap, iters); }
     else { if (tabg) launch_sized<false, true>(B, block, list, count, lds, s, cap, iters); else launch_sized<false, false>(B, block, list, count, lds, s, cap, iters); }
 }
@@ -999,7 +1100,7 @@ void Engine::advance(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters) {
             for (size_t k = 0; k < D.groups.size(); ++k) {
                 const auto& g = D.groups[k];
-                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.list, g.count, g.lds, g.stream, cap, iters);
+                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.wide != 0, g.list, g.count, g.lds, g.stream, cap, iters);
                 ++launches; ++group_launches[k];
             }
         }
@@ -1101,7 +1202,7 @@ void Engine::advance(long long max_rounds)
         } else {
             float cms = 0;
             HIP_OK(hipEventElapsedTime(&cms, D.groups[best].t0, D.groups[best].t1));
-            counters_.dominant_block = D.groups[best].block; counters_.dominant_robots = D.groups[best].count;
+            counters_.dominant_block = D.groups[best].block + (D.groups[best].wide ? 1 : 0); counters_.dominant_robots = D.groups[best].count;
             counters_.dominant_launches = group_launches[best]; counters_.dominant_seconds = cms * 1e-3;
             counters_.dominant_alg_bytes = grp_ab[best]; counters_.dominant_voxel_steps = grp_vs[best];
         }

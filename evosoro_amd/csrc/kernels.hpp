@@ -241,6 +241,14 @@ __device__ __forceinline__ d3 to_rotvec(dq q, double slthresh)
     return mk3(2.0 * q.x * f, 2.0 * q.y * f, 2.0 * q.z * f);
 }
 
+// Contact rows (DBatch::col_partner / col_a1 / col_code): robot r owns the block [col_begin, col_begin + col_cap * nsurf), entry k of
+// the row of its surface voxel i at col_begin + k * nsurf + i (partner-major inside the block: coalesced across a wavefront).
+// `row` = the batch-wide row number surf_begin + i, as DBatch::col_cnt is indexed.
+__device__ __forceinline__ size_t col_at(const DRobot& R, int k, int row)
+{
+    return (size_t)R.col_begin + (size_t)k * (size_t)R.nsurf + (size_t)(row - R.surf_begin);
+}
+
 __device__ __forceinline__ int robot_of(const DBatch& B, int vslot)
 {
     return __builtin_amdgcn_readfirstlane(B.wave_robot[vslot >> 6]);
@@ -501,12 +509,15 @@ __device__ __forceinline__ DevParams load_dev(const DBatch& B, int v)
     return d;
 }
 
-// Everything of EulerStep after the internal-bond sums: collision bonds, gravity, floor, integration, actuation.
-// F/M arrive holding slow damping + internal bond forces / minus internal bond moments.  Returns |new velocity|^2.
+// Everything of EulerStep after the internal-bond sums, in two independent halves (a voxel's translation and its rotation + size
+// never read each other's results within a step): voxel_update_lin -- collision bonds, gravity, drag, floor, linear integration --
+// and voxel_update_ang -- angular integration, quaternion update, actuation -> new scale.  voxel_update runs one after the other on
+// one lane (resident, tiled and streaming kernels); the wide kernel (kernels_wide.hpp) gives the halves of a small robot's voxels
+// to different wavefronts.
+// F arrives holding slow damping + internal bond forces.  `scale`: the voxel's size at the start of the step.  Returns |new velocity|^2.
 template <class Fetch>
-__device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, const Fetch& fetch,
-                                               double t, double act_sin, double act_cos, double prenatal_c, d3 F, d3 M, d3 vel,
-                                               VoxState& S, int row, int ccnt, bool fluid, d3 drag, double ph_sin, double ph_cos, float amp_damp)
+__device__ __forceinline__ double voxel_update_lin(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, const Fetch& fetch,
+                                                   d3 F, d3 vel, d3& pos, d3& lm, double scale, int row, int ccnt, bool fluid, d3 drag)
 {
     // (v: global voxel slot = what the contact rows and `fetch` speak)
     const int flags = R.flags;
@@ -519,7 +530,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool on = k0 + j < ccnt;
-                const size_t at = (size_t)(k0 + j) * B.col_rows + row;   // partner-major: coalesced across the wave
+                const size_t at = col_at(R, k0 + j, row);                // partner-major: coalesced across the wave
                 o[j] = on ? B.col_partner[at] : -1;
                 a1[j] = on ? B.col_a1[at] : 0.0;
             }
@@ -528,7 +539,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (o[j] < 0) continue;
-                F = contact_force_add(F, S.pos, S.scale, qx[j], qy[j], qz[j], qs[j], a1[j]);
+                F = contact_force_add(F, pos, scale, qx[j], qy[j], qz[j], qs[j], a1[j]);
             }
         }
     }
@@ -536,7 +547,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
     if (fluid) F = F + drag;                  // LW/VXS_Voxel.cpp:372-373
 
     if ((flags & RF_FLOOR) && !fluid) {       // CalcFloorEffect, VXS_Voxel.cpp:708-758
-        const double pen = 0.5 * S.scale - S.pos.z;
+        const double pen = 0.5 * scale - pos.z;
         bool static_fric = false;
         if (pen > 0) {
             const double normal = C.k_floor * pen;
@@ -546,28 +557,39 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
             const double fric = C.u_dynamic * normal;
             double fx = 0, fy = 0;
             bool stopped = (vel.x == 0 && vel.y == 0);
-            if (flags & RF_STICKY) { S.lm.x = 0; S.lm.y = 0; static_fric = true; stopped = true; }
+            if (flags & RF_STICKY) { lm.x = 0; lm.y = 0; static_fric = true; stopped = true; }
             if (stopped) {
                 if (surf_force < C.u_static * normal) static_fric = true;
             } else if (fric * dt < C.mass * surf_vel) {
                 // -(cos, sin)(atan2(vy, vx)) * fric == -(vx, vy)/|v| * fric
                 const double inv = vdiv(fric, surf_vel);
                 fx = -vel.x * inv; fy = -vel.y * inv;
-            } else { static_fric = true; S.lm.x = 0; S.lm.y = 0; }
+            } else { static_fric = true; lm.x = 0; lm.y = 0; }
             F.x += fx; F.y += fy; F.z += fz;
         }
         if (static_fric) { F.x = 0; F.y = 0; }
     }
 
-    // EulerStep, VXS_Voxel.cpp:183-222
-    S.lm = S.lm + F * dt;
-    S.pos = S.pos + S.lm * (dt * C.mass_inv);
-    S.am = S.am + M * dt;
+    // EulerStep, VXS_Voxel.cpp:183-189
+    lm = lm + F * dt;
+    pos = pos + lm * (dt * C.mass_inv);
+    return len2(lm * C.mass_inv);
+}
+
+// M arrives holding minus the internal bond moments.  `scale` in: the size at the start of the step, out: the new one.
+__device__ __forceinline__ void voxel_update_ang(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, double t, double act_sin,
+                                                 double act_cos, double prenatal_c, d3 M, d3& am, dq& q, double& scale,
+                                                 double ph_sin, double ph_cos, float amp_damp)
+{
+    const int flags = R.flags;
+    const double dt = R.dt;
+    // EulerStep, VXS_Voxel.cpp:190-222
+    am = am + M * dt;
     const double amf = 1 - 10 * R.slow_z * C.inertia_inv * C.c_ang * dt;
-    S.am = S.am * amf;
-    d3 w = S.am * C.inertia_inv;
-    dq spin = qmul(mkq(0, w.x * 0.5, w.y * 0.5, w.z * 0.5), S.ang);
-    dq ang = mkq(S.ang.w + spin.w * dt, S.ang.x + spin.x * dt, S.ang.y + spin.y * dt, S.ang.z + spin.z * dt);
+    am = am * amf;
+    d3 w = am * C.inertia_inv;
+    dq spin = qmul(mkq(0, w.x * 0.5, w.y * 0.5, w.z * 0.5), q);
+    dq ang = mkq(q.w + spin.w * dt, q.x + spin.x * dt, q.y + spin.y * dt, q.z + spin.z * dt);
     {
         // NormalizeFast with the reference's own two roundings (sqrt, then 1 / l): the `w >= 1 -> identity` snap below
         // discards rotations smaller than ~1.5e-8 rad, and whether w lands on 1.0 depends on the last bit of 1 / l
@@ -576,7 +598,7 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
         if (l != 0) { const double li = vrcp(l); ang.w *= li; ang.x *= li; ang.y *= li; ang.z *= li; }
         if (ang.w >= 1.0) ang = mkq(1.0, 0, 0, 0);
     }
-    S.ang = ang;
+    q = ang;
 
     // thermal actuation -> new scale (VXS_Voxel.cpp:224-340 without development; LW/VXS_Voxel.cpp:211-235)
     // sin(2 pi' (t/T + phase)) of the reference = sin(a + b) with a = 2 pi' t/T, the same for every voxel (sincos once
@@ -614,8 +636,8 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
         }
         new_scale = ctrl * nom + (1 + prenatal) * (1 + dev_tf) * nom;
         const double max_scale = (1 + R.growth_amplitude) * nom, min_scale = R.min_temp_fact * nom;
-        if (new_scale < S.scale && new_scale < min_scale) new_scale = S.scale;
-        if (new_scale > S.scale && new_scale > max_scale) new_scale = S.scale;
+        if (new_scale < scale && new_scale < min_scale) new_scale = scale;
+        if (new_scale > scale && new_scale > max_scale) new_scale = scale;
     } else if (!(flags & RF_LW)) {
         const double prenatal = prenatal_c * (((float)C.nom_size / C.nom_size) - 1);
         double ctrl = 0;
@@ -623,8 +645,8 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
             ctrl = (double)amp_damp * ((double)R.temp_amplitude * act) * C.cte;
         new_scale = ctrl * C.nom_size + (1 + prenatal) * C.nom_size;
         const double max_scale = (1 + R.growth_amplitude) * C.nom_size, min_scale = R.min_temp_fact * C.nom_size;
-        if (new_scale < S.scale && new_scale < min_scale) new_scale = S.scale;
-        if (new_scale > S.scale && new_scale > max_scale) new_scale = S.scale;
+        if (new_scale < scale && new_scale < min_scale) new_scale = scale;
+        if (new_scale > scale && new_scale > max_scale) new_scale = scale;
     } else {
         double tf = 1.0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)
@@ -632,8 +654,17 @@ __device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R,
         if (tf < 0.1) tf = 0.1;
         new_scale = tf * C.nom_size;
     }
-    S.scale = new_scale;
-    return len2(S.lm * C.mass_inv);
+    scale = new_scale;
+}
+
+template <class Fetch>
+__device__ __forceinline__ double voxel_update(const DBatch& B, const DRobot& R, const DVoxClass& C, int v, const Fetch& fetch,
+                                               double t, double act_sin, double act_cos, double prenatal_c, d3 F, d3 M, d3 vel,
+                                               VoxState& S, int row, int ccnt, bool fluid, d3 drag, double ph_sin, double ph_cos, float amp_damp)
+{
+    const double vel2 = voxel_update_lin(B, R, C, v, fetch, F, vel, S.pos, S.lm, S.scale, row, ccnt, fluid, drag);
+    voxel_update_ang(B, R, C, v, t, act_sin, act_cos, prenatal_c, M, S.am, S.ang, S.scale, ph_sin, ph_cos, amp_damp);
+    return vel2;
 }
 
 // uniform per-step factors of the actuation, evaluated once per robot and step instead of once per voxel
@@ -864,11 +895,11 @@ __device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, D
                 const double s1 = (j > i) ? si : sh[3 * CH + k];   // scale of Vox1 = the earlier one, used twice (:2382)
                 const double act = H * (s1 + s1) * 0.5;
                 if (d2 < act * act) {
-                    if (cnt < VXH_MAXCOL) {
+                    if (cnt < R.col_cap) {
                         const int vj = shv[k];
                         const DVoxClass& Ci = B.vclass_tab[R.vtab_begin + B.vclass[vi]];
                         const DVoxClass& Cj = B.vclass_tab[R.vtab_begin + B.vclass[vj]];
-                        const size_t at = (size_t)cnt * B.col_rows + (R.surf_begin + i);
+                        const size_t at = col_at(R, cnt, R.surf_begin + i);
                         B.col_partner[at] = vj;
                         B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
                     }
@@ -879,7 +910,7 @@ __device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, D
         __syncthreads();
     }
     if (mine) {
-        if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
+        if (cnt > R.col_cap) { cnt = R.col_cap; atomicOr(&rs.col_overflow, 1); }
         B.col_cnt[R.surf_begin + i] = cnt;
     }
 }
@@ -1073,4 +1104,5 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
 }  // namespace vxh
 
 #include "kernels_fused.hpp"
+#include "kernels_wide.hpp"
 #include "kernels_tiled.hpp"

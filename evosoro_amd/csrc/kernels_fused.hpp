@@ -143,9 +143,9 @@ __device__ __forceinline__ void fused_rebuild_plain(const DBatch& B, const DRobo
                 const double s1 = (j > i) ? si : qs[u];           // scale of Vox1 = the earlier one, used twice (:2382)
                 const double act = H * (s1 + s1) * 0.5;
                 if (d2 < act * act) {
-                    if (cnt < VXH_MAXCOL) {
+                    if (cnt < R.col_cap) {
                         const DVoxClass& Cj = vct[other[u] >> 10];
-                        const size_t at = (size_t)cnt * B.col_rows + (R.surf_begin + i);
+                        const size_t at = col_at(R, cnt, R.surf_begin + i);
                         B.col_partner[at] = R.vox_begin + (other[u] & 1023);
                         B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
                     }
@@ -154,7 +154,7 @@ __device__ __forceinline__ void fused_rebuild_plain(const DBatch& B, const DRobo
             }
         }
         VXH_RB_MARK(2101)      // (wave 0's own scan: lanes of one wavefront finish together)
-        if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
+        if (cnt > R.col_cap) { cnt = R.col_cap; atomicOr(&rs.col_overflow, 1); }
         B.col_cnt[R.surf_begin + i] = cnt;
     }
     __syncthreads();
@@ -220,10 +220,10 @@ __device__ __forceinline__ void fused_rebuild_staged(const DBatch& B, const DRob
                 const double s1 = (j > i) ? si : stg[3 * BLOCK + j];   // scale of Vox1 = the earlier one, used twice (:2382)
                 const double act = H * (s1 + s1) * 0.5;
                 if (d2 < act * act) {
-                    if (cnt < VXH_MAXCOL) {
+                    if (cnt < R.col_cap) {
                         const int other = shi[j];
                         const DVoxClass& Cj = vct[other >> 10];
-                        const size_t at = (size_t)cnt * B.col_rows + (R.surf_begin + i);
+                        const size_t at = col_at(R, cnt, R.surf_begin + i);
                         B.col_partner[at] = R.vox_begin + (other & 1023);
                         B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
                     }
@@ -231,17 +231,139 @@ __device__ __forceinline__ void fused_rebuild_staged(const DBatch& B, const DRob
                 }
             }
         }
-        if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
+        if (cnt > R.col_cap) { cnt = R.col_cap; atomicOr(&rs.col_overflow, 1); }
         B.col_cnt[R.surf_begin + i] = cnt;
     }
     __syncthreads();
 }
 
-template <int BLOCK>
-__device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, int* shi, const DVoxClass* vct)
+// lane `lane` (a compile-time constant after unrolling) of `old` := the uniform value `sval` (v_writelane_b32: one VALU instruction, no compare / select)
+// (the lane number must be a literal: gfx9 allows one scalar register per VALU instruction, and `sval` is it)
+__device__ __forceinline__ unsigned writelane_u32(unsigned old, unsigned sval, int lane)
 {
-    if constexpr (BLOCK == 1024) fused_rebuild_staged<BLOCK>(B, R, rs, ps, shi, vct);
-    else fused_rebuild_plain<BLOCK>(B, R, rs, ps, shi, vct);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(lane));
+    return old;
+}
+
+// CalcL1Bonds (VX_Sim.cpp:2357-2413) as a BIT MATRIX built from 64 x 64 blocks of surface-voxel pairs, every unordered pair tested
+// once.  The plain scan above lets thread i walk all ns candidates (ns^2 tests, wavefront w busy for as long as its rows need, the
+// SIMD with three wavefronts three times as long as the one with two); here
+//   1. positions are staged by surface ordinal (`stg`: x y z planes of NS = 64 * nb doubles; slots past ns hold +infinity-like
+//      values that fail every test), so a candidate's address is uniform -- a broadcast LDS read, no index indirection;
+//   2. the nb (nb + 1) / 2 block pairs (I <= J) are dealt round-robin to the wavefronts.  In a pair lane l holds row i = 64 I + l
+//      and walks the 64 candidates j = 64 J + u: d2 < thr_i with thr_i = min(FilterDist^2, ActDist_i^2) -- the reference's two
+//      tests `Dist2 < FilterDist2` and `Dist2 < ActDist * ActDist` (:2378-2383) are both `d2 <`, so one compare against the smaller
+//      bound decides both, exactly; ActDist uses the scale of the EARLIER voxel (:2382), which is the row's in every pair with
+//      I < J and in the upper triangle of a diagonal block.  The compare's lane mask IS row j's word for block I (the test is
+//      symmetric in everything but that scale, and the earlier voxel is the same seen from either side): it is kept by lane u
+//      (v_writelane); the lane's own bit is shifted into row i's word for block J with one add-with-carry;
+//   3. both go to the matrix `mat` [nb][NS] (word-major: conflict-free), one writer per word; a diagonal block contributes the
+//      upper triangle of the rows' own words and the lower triangle of the masks;
+//   4. after a barrier thread i walks its row's nb words in ascending order -- the creation order of the reference's collision bonds,
+//      hence the order CalcContactForce sums them in -- drops the pairs within the hop horizon (`excl` bit rows = !IsNearbyVox, :2380)
+//      and writes partner and pair stiffness of the rest.
+// Same arithmetic per pair as the plain scan, hence the same rows (developer build, what-if switch 16: both run, rows compared).
+// Measured: DESIGN.md "Broad-phase".  `mat`: nb * NS words; `stg`: 3 * NS doubles.
+template <int BLOCK>
+__device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, unsigned long long* mat,
+                                                  double* stg, const DVoxClass* vct)
+{
+    const int tid = opaque_tid<BLOCK>(), ns = R.nsurf;
+    const int nb = (ns + 63) >> 6, NS = nb << 6;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = BLOCK / 64;
+    for (int k = tid; k < NS; k += BLOCK) {
+        double x = 1.0e150, y = 1.0e150, z = 1.0e150;          // (a slot past the list: farther than any bound from every voxel; rows past the list accept nothing, thr < 0)
+        if (k < ns) { const int l = B.surf[R.surf_begin + k] - R.vox_begin; x = ps[l]; y = ps[BLOCK + l]; z = ps[2 * BLOCK + l]; }
+        stg[k] = x; stg[NS + k] = y; stg[2 * NS + k] = z;
+    }
+    __syncthreads();
+    const double H = R.col_horizon, filter2 = R.filter_dist2;
+    const int npairs = nb * (nb + 1) / 2;
+    for (int p = wave; p < npairs; p += NW) {
+        int I = 0, rem = p;
+        while (rem >= nb - I) { rem -= nb - I; ++I; }
+        const int J = I + rem;
+        const int i = (I << 6) + lane;
+        const d3 pi = mk3(stg[i], stg[NS + i], stg[2 * NS + i]);
+        double thr = -1.0;                                      // (rows past the list accept nothing)
+        if (i < ns) {
+            const double si = ps[3 * BLOCK + (B.surf[R.surf_begin + i] - R.vox_begin)];
+            const double act = H * (si + si) * 0.5;             // the row is Vox1 = the earlier voxel of every pair this block pair keeps
+            const double act2 = act * act;
+            thr = act2 < filter2 ? act2 : filter2;
+        }
+        unsigned own_lo = 0, own_hi = 0, col_lo = 0, col_hi = 0;
+        const double* q = stg + (J << 6);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const d3 d = pi - mk3(q[u], q[NS + u], q[2 * NS + u]);
+            const bool in = len2(d) < thr;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+            own_lo |= in ? (1u << u) : 0u;
+            col_lo = writelane_u32(col_lo, (unsigned)m, u);
+            col_hi = writelane_u32(col_hi, (unsigned)(m >> 32), u);
+        }
+#pragma unroll
+        for (int u = 32; u < 64; ++u) {
+            const d3 d = pi - mk3(q[u], q[NS + u], q[2 * NS + u]);
+            const bool in = len2(d) < thr;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+            own_hi |= in ? (1u << (u - 32)) : 0u;
+            col_lo = writelane_u32(col_lo, (unsigned)m, u);
+            col_hi = writelane_u32(col_hi, (unsigned)(m >> 32), u);
+        }
+        const unsigned long long own = ((unsigned long long)own_hi << 32) | own_lo, col = ((unsigned long long)col_hi << 32) | col_lo;
+        if (I == J) {
+            const unsigned long long below = (1ull << lane) - 1ull;          // partners before me / after me inside the block
+            mat[(size_t)I * NS + i] = (own & ~(below | (1ull << lane))) | (col & below);
+        } else {
+            mat[(size_t)J * NS + i] = own;                                   // row i, partners of block J
+            mat[(size_t)I * NS + (J << 6) + lane] = col;                     // row 64 J + lane, partners of block I
+        }
+    }
+    __syncthreads();
+    if (tid < ns) {
+        const int i = tid;
+        const int gi = B.surf[R.surf_begin + i];
+        const DVoxClass& Ci = vct[B.vclass[gi]];
+        const unsigned long long* row = B.excl + R.excl_begin + (long long)i * R.excl_wpr;
+        int cnt = 0;
+        for (int w = 0; w < nb; ++w) {
+            unsigned long long word = mat[(size_t)w * NS + i] & ~row[w];     // !pV1->IsNearbyVox(SIndex2)
+            while (word) {
+                const int u = __builtin_ctzll(word);
+                word &= word - 1;
+                const int j = (w << 6) + u;
+                if (cnt < R.col_cap) {
+                    const int gj = B.surf[R.surf_begin + j];
+                    const DVoxClass& Cj = vct[B.vclass[gj]];
+                    const size_t at = col_at(R, cnt, R.surf_begin + i);
+                    B.col_partner[at] = gj;
+                    B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
+                }
+                ++cnt;
+            }
+        }
+        if (cnt > R.col_cap) { cnt = R.col_cap; atomicOr(&rs.col_overflow, 1); }
+        B.col_cnt[R.surf_begin + i] = cnt;
+    }
+    __syncthreads();
+}
+
+// The broad-phase of a resident robot: the bit-matrix scan when its matrix (nb * NS words) fits the scratch tile and the staged
+// positions (3 * NS doubles) fit behind it or in the contact-row pool (`pool`, dead during a run: rows_to_lds refills it afterwards);
+// else the staged / plain scans.  `scratch` is left dirty: the caller re-zeroes what it needs zero.
+template <int BLOCK>
+__device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, double* scratch, int scratch_doubles,
+                                              double* pool, int pool_doubles, const DVoxClass* vct)
+{
+    const int nb = (R.nsurf + 63) >> 6, NS = nb << 6;
+    const int need_mat = nb * NS, need_stg = 3 * NS;
+    if (need_mat + need_stg <= scratch_doubles) fused_rebuild_sym<BLOCK>(B, R, rs, ps, (unsigned long long*)scratch, scratch + need_mat, vct);
+    else if (need_mat <= scratch_doubles && need_stg <= pool_doubles) fused_rebuild_sym<BLOCK>(B, R, rs, ps, (unsigned long long*)scratch, pool, vct);
+    else if constexpr (BLOCK == 1024) fused_rebuild_staged<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
+    else fused_rebuild_plain<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
 }
 
 // land_water fluid drag (LW/VX_Sim.cpp:1516-1597) inside the resident kernel; the per-corner and per-facet arithmetic is
@@ -518,7 +640,9 @@ __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, co
 //           arithmetic), a bit in the owner's mask for the pairs in reach;
 //   pass 2  every lane adds the forces of its pairs in reach, in list order (the order the reference adds its collision bonds).
 // A pair: partner | owner << 10 | place in the owner's row << 20 (rc_code), pair stiffness (rc_a1).  `rowd`: partner count |
-// (start of my row in the copy + 1) << 7; a wavefront whose rows did not fit (nseg < 0) reads them from memory.
+// (start of my row in the copy + 1) << VXH_ROWD_BITS; a wavefront whose rows did not fit (nseg < 0) reads them from memory, and so does
+// a row of more than 64 partners (the mask of the pairs in reach has 64 bits; rows are as long as the physics makes them, DRobot::col_cap).
+enum { VXH_ROWD_BITS = 11, VXH_ROWD_MASK = (1 << VXH_ROWD_BITS) - 1 };
 template <int BLOCK>
 __device__ __forceinline__ void fused_contact_reach(const double* ps, int seg, int nseg, unsigned long long* mask, const int* rc_code)
 {
@@ -538,11 +662,11 @@ template <int BLOCK>
 __device__ __forceinline__ d3 fused_contact_forces(const DBatch& B, const DRobot& R, const double* ps, d3 F, d3 pos, double scale, int self, int v, int rowd,
                                                    unsigned long long* mask, const int* rc_code, const double* rc_a1)
 {
-    if ((rowd >> 7) != 0) {                    // my row is in the LDS copy
+    if ((rowd >> VXH_ROWD_BITS) != 0) {         // my row is in the LDS copy
         unsigned long long m = mask[self];
         if (m) {
             mask[self] = 0;
-            const int roff = (rowd >> 7) - 1;
+            const int roff = (rowd >> VXH_ROWD_BITS) - 1;
             do {
                 const int k = __builtin_ctzll(m);
                 m &= m - 1;
@@ -552,14 +676,14 @@ __device__ __forceinline__ d3 fused_contact_forces(const DBatch& B, const DRobot
         }
         return F;
     }
-    const int ccnt = rowd & 127;
+    const int ccnt = rowd & VXH_ROWD_MASK;
     const int row = R.surf_begin + B.surf_ord[v];
     for (int k0 = 0; k0 < ccnt; k0 += 2) {
         int l[2]; double a1[2], qx[2], qy[2], qz[2], qs[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool on = k0 + j < ccnt;
-            const size_t at = (size_t)(k0 + j) * B.col_rows + row;   // partner-major: coalesced across the wave
+            const size_t at = col_at(R, k0 + j, row);   // partner-major: coalesced across the wave
             l[j] = on ? B.col_partner[at] - R.vox_begin : -1;
             a1[j] = on ? B.col_a1[at] : 0.0;
         }
@@ -690,7 +814,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     const FetchLds<BLOCK> fetch{ps, base};
     DragCache<BLOCK> dcache;
     if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) dcache.load(B, R, tid); }
-    // my contact row: partner count | (start of the workgroup's LDS copy of it + 1) << 7; s_seg: where the rows of each wavefront's
+    // my contact row: partner count | (start of the workgroup's LDS copy of it + 1) << VXH_ROWD_BITS; s_seg: where the rows of each wavefront's
     // lanes start in the copy and how many pairs they hold (-1: they did not fit, that wavefront reads its rows from memory).
     // Refreshed after every broad-phase run.  (every thread calls: barriers inside)
     int rowd = 0;
@@ -714,7 +838,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         if (pool_cap > 0) cmask[tid_r] = 0;
         __syncthreads();
         VXH_R2L_MARK(2114)     // surface ordinal -> row count (two dependent loads), first barrier
-        int incl = ccnt;                      // places in the copy: prefix sum within the wavefront, one atomic per wavefront
+        const int ccnt_l = ccnt <= 64 ? ccnt : 0;     // (a longer row stays in memory: 64 mask bits per voxel)
+        int incl = ccnt_l;                    // places in the copy: prefix sum within the wavefront, one atomic per wavefront
         const int lane = tid_r & 63;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
@@ -732,12 +857,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // (the developer build used to count wavefront copies and overflows here with global atomics from every wavefront: contended, and the
         // barrier below waits for them -- this function took 52 k cycles per call with them and takes 13.5 k without, and the difference
         // was for a while mistaken for a cost of copying the rows; removed)
-        const int off = wave_base + incl - ccnt;
+        const int off = wave_base + incl - ccnt_l;
         rowd = ccnt;
-        if (fits && ccnt > 0) {
-            rowd = ccnt | ((off + 1) << 7);
+        if (fits && ccnt_l > 0) {
+            rowd = ccnt | ((off + 1) << VXH_ROWD_BITS);
             for (int k = 0; k < ccnt; ++k) {
-                const size_t at = (size_t)k * B.col_rows + row;
+                const size_t at = col_at(R, k, row);
                 rc_code[off + k] = (B.col_partner[at] - base) | (tid_r << 10) | (k << 20);
                 rc_a1[off + k] = B.col_a1[at];
             }
@@ -782,21 +907,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #ifdef VXH_PHASE_TIMING
         const unsigned long long t_reb0 = __builtin_readcyclecounter();
 #endif
-        if (k_rebuild) {
-            fused_rebuild<BLOCK>(B, R, rs, ps, (int*)acc, vct);
+        if (__builtin_expect(k_rebuild, 0)) {
+            fused_rebuild<BLOCK>(B, R, rs, ps, acc, NACC * 6 * BLOCK, (double*)cmask, max(0, lds_doubles - (int)((double*)cmask - lds)), vct);
 #ifdef VXH_PHASE_TIMING
-            if (VXH_DBG(16) && B.prof) {     // cross-check: the scan it replaces must leave the same rows (count, partners, stiffness bits)
+            if (VXH_DBG(16) && B.prof) {     // cross-check: the plain scan must leave the same rows (count, partners, stiffness bits)
                 int my_row = -1, n_new = 0; unsigned long long sum_new = 0;
                 if (tid < R.nsurf) {
                     my_row = R.surf_begin + tid; n_new = B.col_cnt[my_row];
-                    for (int k = 0; k < n_new; ++k) { const size_t at = (size_t)k * B.col_rows + my_row; sum_new += (unsigned long long)(k + 1) * ((unsigned long long)B.col_partner[at] * 1000003ull + (unsigned long long)__double_as_longlong(B.col_a1[at])); }
+                    for (int k = 0; k < n_new; ++k) { const size_t at = col_at(R, k, my_row); sum_new += (unsigned long long)(k + 1) * ((unsigned long long)B.col_partner[at] * 1000003ull + (unsigned long long)__double_as_longlong(B.col_a1[at])); }
                 }
                 __syncthreads();
-                if constexpr (BLOCK == 1024) fused_rebuild_plain<BLOCK>(B, R, rs, ps, (int*)acc, vct);     // (the other scan)
-                else fused_rebuild_staged<BLOCK>(B, R, rs, ps, (int*)acc, vct);
+                fused_rebuild_plain<BLOCK>(B, R, rs, ps, (int*)acc, vct);
                 if (tid < R.nsurf) {
                     const int n_old = B.col_cnt[my_row]; unsigned long long sum_old = 0;
-                    for (int k = 0; k < n_old; ++k) { const size_t at = (size_t)k * B.col_rows + my_row; sum_old += (unsigned long long)(k + 1) * ((unsigned long long)B.col_partner[at] * 1000003ull + (unsigned long long)__double_as_longlong(B.col_a1[at])); }
+                    for (int k = 0; k < n_old; ++k) { const size_t at = col_at(R, k, my_row); sum_old += (unsigned long long)(k + 1) * ((unsigned long long)B.col_partner[at] * 1000003ull + (unsigned long long)__double_as_longlong(B.col_a1[at])); }
                     atomicAdd(&B.prof[2104], 1ull);
                     if (n_old != n_new || sum_old != sum_new) atomicAdd(&B.prof[2105], 1ull);
                 }
@@ -804,10 +928,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             }
 #endif
             rows_to_lds();
-            if (BLOCK == 1024 || VXH_DBG(16)) {                            // the staged planes of the broad-phase (plane 0: below)
 #pragma unroll
-                for (int k = 1; k < 5; ++k) acc[k * BLOCK + tid] = 0.0;
-            }
+            for (int k = 1; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;      // the scratch of the broad-phase (plane 0: below)
             scratch_used = true;
         }
 #ifdef VXH_PHASE_TIMING
@@ -862,33 +984,33 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             F = F + (vel * (-R.slow_z)) * C.c_lin;
 #ifdef VXH_PHASE_TIMING
             const d3 F_before = F;
-            const unsigned long long mask_seen = ((rowd >> 7) != 0) ? cmask[tid] : 0ull;     // what pass 2 is about to consume
+            const unsigned long long mask_seen = ((rowd >> VXH_ROWD_BITS) != 0) ? cmask[tid] : 0ull;     // what pass 2 is about to consume
 #endif
             if (rowd != 0) F = fused_contact_forces<BLOCK>(B, R, ps, F, S.pos, S.scale, tid, vv, rowd, cmask, rc_code, rc_a1);
 #ifdef VXH_PHASE_TIMING
-            if (VXH_DBG(8) && B.prof && (rowd >> 7) != 0) {     // the same sum through the rows in memory: must give the same bits
-                const d3 G = fused_contact_forces<BLOCK>(B, R, ps, F_before, S.pos, S.scale, tid, vv, rowd & 127, cmask, rc_code, rc_a1);
+            if (VXH_DBG(8) && B.prof && (rowd >> VXH_ROWD_BITS) != 0) {     // the same sum through the rows in memory: must give the same bits
+                const d3 G = fused_contact_forces<BLOCK>(B, R, ps, F_before, S.pos, S.scale, tid, vv, rowd & VXH_ROWD_MASK, cmask, rc_code, rc_a1);
                 atomicAdd(&B.prof[2115], 1ull);
                 if (!(G.x == F.x && G.y == F.y && G.z == F.z)) {
                     atomicAdd(&B.prof[2116], 1ull);
                     // pairs of my row in reach by CalcContactForce's own test, against the bits pass 1 set for me
                     int reach = 0;
                     const int crow0 = R.surf_begin + B.surf_ord[vv];
-                    for (int k = 0; k < (rowd & 127); ++k) {
-                        const int q = B.col_partner[(size_t)k * B.col_rows + crow0] - base;
+                    for (int k = 0; k < (rowd & VXH_ROWD_MASK); ++k) {
+                        const int q = B.col_partner[col_at(R, k, crow0)] - base;
                         if (contact_in_reach(ps[q] - S.pos.x, ps[BLOCK + q] - S.pos.y, ps[2 * BLOCK + q] - S.pos.z, (ps[3 * BLOCK + q] + S.scale) * 0.75)) ++reach;
                     }
                     const int bits = __builtin_popcountll(mask_seen);
                     atomicAdd(&B.prof[bits < reach ? 2118 : (bits > reach ? 2119 : 2111)], 1ull);
                 }
                 // is the LDS copy of my row what memory holds now?  (partner and stiffness of every entry, bit for bit)
-                const int crow = R.surf_begin + B.surf_ord[vv], coff = (rowd >> 7) - 1;
+                const int crow = R.surf_begin + B.surf_ord[vv], coff = (rowd >> VXH_ROWD_BITS) - 1;
                 bool same = true;
-                for (int k = 0; k < (rowd & 127); ++k) {
-                    const size_t at = (size_t)k * B.col_rows + crow;
+                for (int k = 0; k < (rowd & VXH_ROWD_MASK); ++k) {
+                    const size_t at = col_at(R, k, crow);
                     same = same && (rc_code[coff + k] & 1023) == B.col_partner[at] - base && rc_a1[coff + k] == B.col_a1[at];
                 }
-                if (B.col_cnt[crow] != (rowd & 127)) same = false;
+                if (B.col_cnt[crow] != (rowd & VXH_ROWD_MASK)) same = false;
                 if (!same) atomicAdd(&B.prof[2117], 1ull);
             }
 #endif

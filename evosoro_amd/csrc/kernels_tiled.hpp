@@ -113,7 +113,7 @@ struct FetchTile {
 // its contact row in LDS (codes + stiffnesses at rc_code / rc_a1 [roff ..), every partner in LDS too), or, for a row that does
 // not fit or has a partner the tile does not mirror, from the rows in memory like the other kernels (the memory requests of a
 // round issued together, and only by wavefronts that have any).
-__device__ __forceinline__ d3 tile_contacts(const DBatch& B, const FetchTile& fetch, d3 F, const VoxState& S, int v, int row, int ccnt, int roff,
+__device__ __forceinline__ d3 tile_contacts(const DBatch& B, const DRobot& R, const FetchTile& fetch, d3 F, const VoxState& S, int v, int row, int ccnt, int roff,
                                             const int* rc_code, const double* rc_a1)
 {
     if (ccnt <= 0) return F;
@@ -134,7 +134,7 @@ __device__ __forceinline__ d3 tile_contacts(const DBatch& B, const FetchTile& fe
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool on = k0 + j < ccnt;
-            const size_t at = (size_t)(k0 + j) * B.col_rows + row;
+            const size_t at = col_at(R, k0 + j, row);
             o[j] = on ? B.col_partner[at] : -1;
             a1[j] = on ? B.col_a1[at] : 0.0;
             code[j] = on ? B.col_code[at] : -2;
@@ -238,11 +238,11 @@ __device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DR
                     const double s1 = (j > i) ? si : qs[u];                          // scale of Vox1 = the earlier one, used twice (:2382)
                     const double act = H * (s1 + s1) * 0.5;
                     if (d2[u] < act * act) {
-                        if (cnt < VXH_MAXCOL) {
+                        if (cnt < R.col_cap) {
                             const int vj = shv[k];
                             const DVoxClass& Ci = B.vclass_tab[R.vtab_begin + B.vclass[vi]];
                             const DVoxClass& Cj = B.vclass_tab[R.vtab_begin + B.vclass[vj]];
-                            const size_t at = (size_t)cnt * B.col_rows + row;
+                            const size_t at = col_at(R, cnt, row);
                             B.col_partner[at] = vj;
                             B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
                             if (B.tile_of[vj] != ti) {                               // into the set of partners to mirror (linear probing)
@@ -261,7 +261,7 @@ __device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DR
         __syncthreads();
     }
     if (mine) {
-        if (cnt > VXH_MAXCOL) { cnt = VXH_MAXCOL; atomicOr(&rs.col_overflow, 1); }
+        if (cnt > R.col_cap) { cnt = R.col_cap; atomicOr(&rs.col_overflow, 1); }
         B.col_cnt[row] = cnt;
     }
     for (int h = tid; h < VXH_TILE_HASH; h += NT) {               // number the distinct partners to mirror
@@ -272,7 +272,7 @@ __device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DR
     __syncthreads();
     if (mine) {                                                    // second pass: the codes of my row
         for (int k = 0; k < cnt; ++k) {
-            const size_t at = (size_t)k * B.col_rows + row;
+            const size_t at = col_at(R, k, row);
             const int vj = B.col_partner[at];
             int code = -1;
             if (B.tile_of[vj] == ti) code = B.tile_lidx[vj];
@@ -420,12 +420,12 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         roff = -1;
         if (valid && codes_live && ccnt > 0) {
             bool all_local = true;
-            for (int k = 0; k < ccnt; ++k) all_local = all_local && B.col_code[(size_t)k * B.col_rows + row] != -1;
+            for (int k = 0; k < ccnt; ++k) all_local = all_local && B.col_code[col_at(R, k, row)] != -1;
             if (all_local) {
                 const int off = atomicAdd(&s_pool, ccnt);
                 if (off + ccnt <= VXH_TILE_ROWPOOL) {
                     roff = off;
-                    for (int k = 0; k < ccnt; ++k) { const size_t at = (size_t)k * B.col_rows + row; rc_code[off + k] = B.col_code[at]; rc_a1[off + k] = B.col_a1[at]; }
+                    for (int k = 0; k < ccnt; ++k) { const size_t at = col_at(R, k, row); rc_code[off + k] = B.col_code[at]; rc_a1[off + k] = B.col_a1[at]; }
                 }
             }
         }
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                     const d3 vel = S.lm * C.mass_inv;
                     F = F + (vel * (-R.slow_z)) * C.c_lin;
                     const FetchTile fetch{ps, px, np, tid, codes_live, pose};
-                    F = tile_contacts(B, fetch, F, S, gv, row, ccnt, roff, rc_code, rc_a1);
+                    F = tile_contacts(B, R, fetch, F, S, gv, row, ccnt, roff, rc_code, rc_a1);
                     vel2 = voxel_update(B, R, C, gv, pose, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, row, 0, false, mk3(0, 0, 0),
                                         pht[tid], pht[no + tid], amp_damp);
                 }

@@ -1,0 +1,310 @@
+// Wide path of the batched Voxelyze stepper: k_robot_wide<BLOCK, MESH, TABG>, one workgroup per robot, the robot resident in its CU
+// for a whole launch like k_robot_steps (kernels_fused.hpp) -- but laid out for the LATENCY of a step instead of its instruction
+// count: a small robot (up to BLOCK voxels, up to 2 * BLOCK bonds) gets more threads than it has voxels, so that
+//   * every bond has a lane of its own and ALL THREE AXES are evaluated in one round (the resident kernel runs three rounds, one
+//     per axis, a barrier between them: three dependent ~650-instruction FP64 chains per step on wavefronts that have a SIMD to
+//     themselves and issue a dependent FP64 instruction only every ~7 cycles, scripts/ubench/fp64_issue.hip).  The combined bond list
+//     (DBatch::wlist) carries the axis per entry (bond_compute_rt); thread t takes entries t and t + BLOCK;
+//   * a bond's outputs go to a RECORD of its own in LDS (Force1, -Moment1, Force2, -Moment2: one writer, no accumulation, no
+//     barrier between bonds), and a voxel adds up the records of its six directions in the reference's own order
+//     +X -X +Y -Y +Z -Z after the slow-damping term (CalcTotalForce / CalcTotalMoment, VXS_Voxel.cpp:496-501, 659-665) -- the
+//     resident kernel sums per bond end instead (DESIGN.md "Numerics");
+//   * when the robot has at most BLOCK / 2 voxels the two independent halves of a voxel's update run on DIFFERENT wavefronts
+//     (voxel_update_lin on thread v, voxel_update_ang on thread BLOCK / 2 + v: translation with contacts, floor and friction
+//     here, rotation + actuation there), each keeping its own momentum in registers.
+// Everything else -- control thread, IniCM latch, broad-phase, contact rows in LDS, fluid drag -- is the resident kernel's code.
+// Measured (round 3, 64 robots = a quarter of the CUs busy): DESIGN.md "Wide kernel".
+// Dynamic LDS (doubles):
+//   ps   [8][BLOCK]   pose tile, as in the resident kernel
+//   rec  [region]     bond records, VXH_WIDE_REC doubles each (13: twelve values + one of padding, 26 dwords -- a wavefront's
+//                     64-bit accesses at that stride are conflict-free); record DRobot::wzidx stays zero: what the missing
+//                     directions of a voxel point at.  Between steps the same memory is the scratch of latch / broad-phase /
+//                     drag (12 * BLOCK doubles, then the mesh vertices of a robot in a fluid), all below the zero record.
+//   tabs              class tables (not TABG)
+//   st   [6][BLOCK]   MESH: directional strains
+//   cmask, rc_a1, rc_code   contact rows of colliding robots (rows_to_lds)
+#pragma once
+
+namespace vxh {
+
+enum { VXH_WIDE_REC = 13, VXH_WIDE_STATIC_LDS = 448 };
+
+// bond `entry` of the combined list: poses from the pose tile, history from / to HBM (L2), outputs into record `slot`
+template <int BLOCK, bool MESH>
+__device__ __forceinline__ bool wide_bond(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, double* rec, int entry, int slot,
+                                          unsigned& modebits, int shift, bool damp_on, double* st)
+{
+    unsigned nv = B.nv;
+    asm volatile("" : "+s"(nv));              // (plane addresses rebuilt per bond by the scalar unit, see fused_bond)
+    const int l1 = entry & 511, l2 = (entry >> 9) & 511, axis = (entry >> 18) & 3;
+    const unsigned voff = ((unsigned)axis * nv + (unsigned)(R.vox_begin + l1)) * 8u;     // canonical slot axis * nv + negative-end voxel
+    BondHist H;
+    H.p0 = ld_plane(B.hist, 0, nv, voff); H.p1 = ld_plane(B.hist, 3, nv, voff); H.p2 = ld_plane(B.hist, 6, nv, voff);
+    H.g0 = ld_plane(B.hist, 9, nv, voff); H.g1 = ld_plane(B.hist, 12, nv, voff); H.g2 = ld_plane(B.hist, 15, nv, voff);
+    H.flags = (modebits >> shift) & 3u;
+    H.store_hist = false;
+    const d3 p1 = mk3(ps[l1], ps[BLOCK + l1], ps[2 * BLOCK + l1]);
+    const double s1 = ps[3 * BLOCK + l1];
+    const dq q1 = mkq(ps[4 * BLOCK + l1], ps[5 * BLOCK + l1], ps[6 * BLOCK + l1], ps[7 * BLOCK + l1]);
+    const d3 p2 = mk3(ps[l2], ps[BLOCK + l2], ps[2 * BLOCK + l2]);
+    const double s2 = ps[3 * BLOCK + l2];
+    const dq q2 = mkq(ps[4 * BLOCK + l2], ps[5 * BLOCK + l2], ps[6 * BLOCK + l2], ps[7 * BLOCK + l2]);
+    const BondOut o = bond_compute_rt(axis, B, bct[(unsigned)entry >> 20], H, p1, q1, s1, p2, q2, s2, damp_on);
+    if (H.store_hist) {
+        st_plane(B.hist, 0, nv, voff, H.p0); st_plane(B.hist, 3, nv, voff, H.p1); st_plane(B.hist, 6, nv, voff, H.p2);
+        st_plane(B.hist, 9, nv, voff, H.g0); st_plane(B.hist, 12, nv, voff, H.g1); st_plane(B.hist, 15, nv, voff, H.g2);
+    }
+    modebits = (modebits & ~(3u << shift)) | (H.flags << shift);
+    if constexpr (MESH) {                     // SetStrainDir (VXS_BondInternal.cpp:300-304): +A side of voxel 1, -A side of voxel 2
+        st[axis * BLOCK + l1] = o.strain1;
+        st[(3 + axis) * BLOCK + l2] = o.strain2;
+    }
+    double* e = rec + slot * VXH_WIDE_REC;
+    e[0] = o.f1.x; e[1] = o.f1.y; e[2] = o.f1.z; e[3] = -o.m1.x; e[4] = -o.m1.y; e[5] = -o.m1.z;
+    e[6] = o.f2.x; e[7] = o.f2.y; e[8] = o.f2.z; e[9] = -o.m2.x; e[10] = -o.m2.y; e[11] = -o.m2.z;
+    return o.diverged;
+}
+
+// acc += the three values at offset `off` of the records of the voxel's six directions (+X -X +Y -Y +Z -Z: the negative end of the
+// bond in a + direction takes its Force1 / Moment1, offsets 0 / 3; the positive end of the bond in a - direction Force2 / Moment2,
+// offsets 6 / 9).  g0: +X | -X << 10 | +Y << 20, g1: -Y | +Z << 10 | -Z << 20.  A missing direction reads the zero record.
+__device__ __forceinline__ d3 wide_gather(const double* rec, int g0, int g1, int off, d3 acc)
+{
+    const int idx[6] = {g0 & 1023, (g0 >> 10) & 1023, (g0 >> 20) & 1023, g1 & 1023, (g1 >> 10) & 1023, (g1 >> 20) & 1023};
+    double v[6][3];
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        const double* e = rec + idx[d] * VXH_WIDE_REC + off + ((d & 1) ? 6 : 0);
+        v[d][0] = e[0]; v[d][1] = e[1]; v[d][2] = e[2];
+    }
+#pragma unroll
+    for (int d = 0; d < 6; ++d) acc = acc + mk3(v[d][0], v[d][1], v[d][2]);
+    return acc;
+}
+
+template <int BLOCK, bool MESH, bool TABG>
+__global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, const DRobot* __restrict__ robots,
+                                                                   const int* __restrict__ robot_list, long long step_cap, int iters,
+                                                                   int lds_doubles)
+{
+    extern __shared__ __align__(16) double lds[];
+    double* const ps = lds;
+    double* const rec = lds + 8 * BLOCK;
+    __shared__ DRobotState rs;
+    __shared__ FusedCtl s_ctl[2];
+    __shared__ int s_div, s_seg[2 * (BLOCK / 64)];
+    static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + 2 * sizeof(int) + 2 * 16 * sizeof(int) + 16 <= VXH_WIDE_STATIC_LDS, "static LDS bound");
+
+    const int tid = threadIdx.x;
+    const int r = __builtin_amdgcn_readfirstlane(robot_list[blockIdx.x]);
+    const DRobot& R = robots[r];
+    const unsigned nv = B.nv;
+    const int base = R.vox_begin, nvox = R.nvox;
+    // roles of this thread: the translation of voxel `tid` (valid), the rotation + size of voxel `la` (angr); the same voxel unless the
+    // robot is small enough to give the two halves to different wavefronts
+    const bool split = 2 * nvox <= BLOCK;
+    const int la = tid - (split ? BLOCK / 2 : 0);
+    const bool valid = tid < nvox, angr = la >= 0 && la < nvox;
+    const int v = base + tid, va = base + la;
+    if (tid == 0) rs = B.rstate[r];
+    double* const tabs = rec + R.wregion;
+    const int nbd = TABG ? 0 : R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = TABG ? 0 : R.n_vclass * (int)(sizeof(DVoxClass) / 8);
+    const DBondClass* bct;
+    const DVoxClass* vct;
+    if constexpr (TABG) {
+        bct = B.bclass_tab + R.btab_begin;
+        vct = B.vclass_tab + R.vtab_begin;
+    } else {
+        for (int k = tid; k < nbd; k += BLOCK) tabs[k] = ((const double*)(B.bclass_tab + R.btab_begin))[k];
+        for (int k = tid; k < nvd; k += BLOCK) tabs[nbd + k] = ((const double*)(B.vclass_tab + R.vtab_begin))[k];
+        bct = (const DBondClass*)tabs;
+        vct = (const DVoxClass*)(tabs + nbd);
+    }
+    double* const st = tabs + nbd + nvd;                       // MESH: [6][BLOCK]
+    double* const mesh = rec + 12 * BLOCK;                     // mesh vertices of a robot in a fluid: inside the record region, behind the scratch
+    unsigned long long* const cmask = (unsigned long long*)(st + (MESH ? 6 * BLOCK : 0));
+    double* const rc_a1 = (double*)cmask + BLOCK;
+    const int pool_cap = (R.flags & RF_SELF_COL) ? max(0, (int)((lds_doubles - (int)(rc_a1 - lds)) * 2 / 3) - 1) : 0;
+    int* const rc_code = (int*)(rc_a1 + pool_cap);
+    if constexpr (MESH) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) st[k * BLOCK + tid] = valid ? B.strain[(unsigned)k * nv + (unsigned)v] : 0.0;
+    }
+    for (int k = tid; k < VXH_WIDE_REC; k += BLOCK) rec[R.wzidx * VXH_WIDE_REC + k] = 0.0;     // the zero record
+    __syncthreads();
+
+    // ---- this thread's roles: momenta -> registers, pose -> LDS; its bonds
+    const DVoxClass& Cl = vct[valid ? B.vclass[v] : 0];
+    const DVoxClass& Ca = vct[angr ? B.vclass[va] : 0];
+    const int nb = R.wnbond;
+    int e0 = tid < nb ? B.wlist[R.wl_begin + tid] : -1, e1 = tid + BLOCK < nb ? B.wlist[R.wl_begin + BLOCK + tid] : -1;
+    unsigned modebits = 0;                    // 2 bits per bond: SmallAngle, history layout (DBatch::hist)
+    if (e0 != -1) modebits |= (unsigned)(B.small_angle[(unsigned)((e0 >> 18) & 3) * nv + (base + (e0 & 511))] & 3);
+    if (e1 != -1) modebits |= (unsigned)(B.small_angle[(unsigned)((e1 >> 18) & 3) * nv + (base + (e1 & 511))] & 3) << 2;
+    int gl0 = 0, gl1 = 0, ga0 = 0, ga1 = 0;   // records of my voxel's six bonds (wide_gather), per role
+    float amp_damp = 1.f;
+    double ph_sin = 0, ph_cos = 1;
+    d3 lm = mk3(0, 0, 0), am = mk3(0, 0, 0);
+    {
+        const int b0 = rs.steps & 1;
+        if (valid) {
+            gl0 = B.wgather[v]; gl1 = B.wgather[nv + v];
+            lm = mk3(LINMOM(0, v), LINMOM(1, v), LINMOM(2, v));
+            ps[tid] = POS(b0, 0, v); ps[BLOCK + tid] = POS(b0, 1, v); ps[2 * BLOCK + tid] = POS(b0, 2, v);
+        }
+        if (angr) {
+            ga0 = B.wgather[va]; ga1 = B.wgather[nv + va];
+            amp_damp = B.amp_damp[va]; ph_sin = B.act_sb[va]; ph_cos = B.act_cb[va];
+            am = mk3(ANGMOM(0, va), ANGMOM(1, va), ANGMOM(2, va));
+            ps[3 * BLOCK + la] = SCALE(b0, va);
+            ps[4 * BLOCK + la] = QUAT(0, va); ps[5 * BLOCK + la] = QUAT(1, va); ps[6 * BLOCK + la] = QUAT(2, va); ps[7 * BLOCK + la] = QUAT(3, va);
+        }
+    }
+    const FetchLds<BLOCK> fetch{ps, base};
+    DragCache<BLOCK> dcache;
+    if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) dcache.load(B, R, tid); }
+    // my contact row (see k_robot_steps): partner count | (start of the LDS copy + 1) << VXH_ROWD_BITS
+    int rowd = 0;
+    auto rows_to_lds = [&]() {
+        rowd = 0;
+        if (!(R.flags & RF_SELF_COL)) return;
+        const int tid_r = opaque_tid<BLOCK>();
+        int row = -1;
+        if (valid) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
+        const int ccnt = row >= 0 ? B.col_cnt[row] : 0;
+        if (pool_cap > 0) cmask[tid_r] = 0;
+        __syncthreads();
+        const int ccnt_l = ccnt <= 64 ? ccnt : 0;     // (a longer row stays in memory: 64 mask bits per voxel)
+        int incl = ccnt_l;
+        const int lane = tid_r & 63;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const int wave_total = __shfl(incl, 63);
+        if (lane == 0) s_seg[2 * (tid_r >> 6) + 1] = wave_total;
+        __syncthreads();
+        int wave_base = 0;
+        for (int w = 0; w < (tid_r >> 6); ++w) wave_base += s_seg[2 * w + 1];
+        __syncthreads();                      // (s_seg is rewritten below)
+        const bool fits = wave_base + wave_total <= pool_cap;
+        if (lane == 0) { s_seg[2 * (tid_r >> 6)] = wave_base; s_seg[2 * (tid_r >> 6) + 1] = fits ? wave_total : -1; }
+        const int off = wave_base + incl - ccnt_l;
+        rowd = ccnt;
+        if (fits && ccnt_l > 0) {
+            rowd = ccnt | ((off + 1) << VXH_ROWD_BITS);
+            for (int k = 0; k < ccnt; ++k) {
+                const size_t at = col_at(R, k, row);
+                rc_code[off + k] = (B.col_partner[at] - base) | (tid_r << 10) | (k << 20);
+                rc_a1[off + k] = B.col_a1[at];
+            }
+        }
+        __syncthreads();
+    };
+
+    const bool ctl_thread = tid == BLOCK - 64;
+    if (ctl_thread) { fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]); fused_control_horizon(R, rs, s_ctl[0]); s_div = 0; }
+    rows_to_lds();
+    __syncthreads();                           // control of the first step + every voxel's pose visible
+    VXH_T_DECL
+    for (int it = 0;; ++it) {
+        const FusedCtl& K = s_ctl[it & 1];
+        FusedCtl& Knext = s_ctl[(it + 1) & 1];
+        const int kf = __builtin_amdgcn_readfirstlane(K.flags);
+        const bool k_go = kf & 1, k_latch = kf & 2, k_eol = kf & 4, k_rebuild = kf & 8, k_trace = kf & 16;
+        if (!k_go && !k_trace) break;
+        int vv = v, vva = va;                  // opaque per-step copies (see k_robot_steps)
+        asm volatile("" : "+v"(vv));
+        asm volatile("" : "+v"(vva));
+        if (k_latch || k_eol || k_trace)
+            fused_latch_cm<BLOCK>(R, rs, ps, rec, valid, Cl, k_latch, k_eol, k_trace, B.trace + (size_t)(R.trace_begin + K.trace_index) * 4);
+        if (!k_go) break;
+        if (__builtin_expect(k_rebuild, 0)) {
+            fused_rebuild<BLOCK>(B, R, rs, ps, rec, 12 * BLOCK, (double*)cmask, max(0, lds_doubles - (int)((double*)cmask - lds)), vct);
+            rows_to_lds();
+        }
+        d3 drag = mk3(0, 0, 0);
+        const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
+        if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK, 12 * BLOCK>(B, R, ps, st, (unsigned)BLOCK, mesh, rec, valid, vv, lm, Cl.mass_inv, dcache); }
+        const bool damp_on = (kf & 32) != 0;
+        VXH_T_MARK(1)
+
+        // ---- bond phase: every bond of the robot, all axes, one round (two for the threads that hold a second entry)
+        bool div = false;
+        if (e0 != -1) div = wide_bond<BLOCK, MESH>(B, R, bct, ps, rec, e0, tid, modebits, 0, damp_on, st);
+        if (e1 != -1) div = wide_bond<BLOCK, MESH>(B, R, bct, ps, rec, e1, tid + BLOCK, modebits, 2, damp_on, st) || div;
+        if (div) s_div = 1;
+        VXH_T_MARK(2)
+        __syncthreads();                       // (B)
+        VXH_T_MARK(3)
+        if (s_div) {                           // Integrate() returns before the voxel loop (VX_Sim.cpp:1777)
+            __syncthreads();
+            if (ctl_thread) { rs.diverged = 1; fused_control_begin(R, rs, step_cap, 0, Knext); s_div = 0; }
+            __syncthreads();
+            continue;
+        }
+        // ---- voxel phase, translation: damping + bond forces in the reference's order, contacts, floor, integration
+        double vel2 = 0;
+        d3 pos = mk3(0, 0, 0);
+        if (R.flags & RF_SELF_COL) {
+            const int nseg = s_seg[2 * (tid >> 6) + 1];
+            if (nseg > 0) fused_contact_reach<BLOCK>(ps, s_seg[2 * (tid >> 6)], nseg, cmask, rc_code);
+        }
+        if (valid) {
+            const d3 vel = lm * Cl.mass_inv;
+            d3 F = wide_gather(rec, gl0, gl1, 0, (vel * (-R.slow_z)) * Cl.c_lin);
+            pos = mk3(ps[tid], ps[BLOCK + tid], ps[2 * BLOCK + tid]);
+            const double scale = ps[3 * BLOCK + tid];
+            if (rowd != 0) F = fused_contact_forces<BLOCK>(B, R, ps, F, pos, scale, tid, vv, rowd, cmask, rc_code, rc_a1);
+            vel2 = voxel_update_lin(B, R, Cl, vv, fetch, F, vel, pos, lm, scale, -1, 0, fluid, drag);
+        }
+        // ---- voxel phase, rotation and size
+        dq ang = mkq(1, 0, 0, 0);
+        double scale_a = 0;
+        if (angr) {
+            const d3 M = wide_gather(rec, ga0, ga1, 3, mk3(0, 0, 0));
+            scale_a = ps[3 * BLOCK + la];
+            ang = mkq(ps[4 * BLOCK + la], ps[5 * BLOCK + la], ps[6 * BLOCK + la], ps[7 * BLOCK + la]);
+            voxel_update_ang(B, R, Ca, vva, K.time, K.act_sin, K.act_cos, K.prenatal_c, M, am, ang, scale_a, ph_sin, ph_cos, amp_damp);
+        }
+        if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
+        if (R.flags & RF_SELF_COL) {             // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
+            vel2 = wave_max_nonneg(vel2);
+            if ((tid & 63) == 0) atomicMax(&rs.maxvel2_bits, (unsigned long long)__double_as_longlong(vel2));
+        }
+        VXH_T_MARK(4)
+        __syncthreads();                       // (C) every read of the old poses is done
+        if (valid) { ps[tid] = pos.x; ps[BLOCK + tid] = pos.y; ps[2 * BLOCK + tid] = pos.z; }
+        if (angr) {
+            ps[3 * BLOCK + la] = scale_a;
+            ps[4 * BLOCK + la] = ang.w; ps[5 * BLOCK + la] = ang.x; ps[6 * BLOCK + la] = ang.y; ps[7 * BLOCK + la] = ang.z;
+        }
+        VXH_T_MARK(5)
+        if (ctl_thread) { fused_control_horizon(R, rs, Knext); s_div = 0; }
+        __syncthreads();                       // (A) control + every voxel's published pose visible
+        VXH_T_MARK(0)
+    }
+    VXH_T_FLUSH
+    // ---- back to HBM
+    {
+        const int b1 = rs.steps & 1;
+        if (valid) {
+            POS(b1, 0, v) = ps[tid]; POS(b1, 1, v) = ps[BLOCK + tid]; POS(b1, 2, v) = ps[2 * BLOCK + tid];
+            LINMOM(0, v) = lm.x; LINMOM(1, v) = lm.y; LINMOM(2, v) = lm.z;
+        }
+        if (angr) {
+            SCALE(b1, va) = ps[3 * BLOCK + la];
+            QUAT(0, va) = ps[4 * BLOCK + la]; QUAT(1, va) = ps[5 * BLOCK + la]; QUAT(2, va) = ps[6 * BLOCK + la]; QUAT(3, va) = ps[7 * BLOCK + la];
+            ANGMOM(0, va) = am.x; ANGMOM(1, va) = am.y; ANGMOM(2, va) = am.z;
+        }
+    }
+    if constexpr (MESH) {
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) B.strain[(unsigned)k * nv + (unsigned)v] = st[k * BLOCK + tid];
+        }
+    }
+    if (e0 != -1) B.small_angle[(unsigned)((e0 >> 18) & 3) * nv + (base + (e0 & 511))] = (unsigned char)(modebits & 3u);
+    if (e1 != -1) B.small_angle[(unsigned)((e1 >> 18) & 3) * nv + (base + (e1 & 511))] = (unsigned char)((modebits >> 2) & 3u);
+    if (tid == 0) B.rstate[r] = rs;
+}
+
+}  // namespace vxh

@@ -178,9 +178,16 @@ int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long 
  *                       6-14 % faster there (64 or fewer robots of 10x10x10 per GPU), at the price that such a robot's last bits then
  *                       depend on the population it is evaluated in (the two kernels agree to 1e-12 voxel, not to the bit).  Default 0.
  *   "tiles_per_robot"   > 0 requests a tile count (tests).
- *                       These three belong to the uploaded batch: set them before the first vxh_run / vxh_step (VXH_ERR_STATE
- *                       afterwards, until vxh_reset).  The tiles of a robot wait for each other on the device: an engine that tiles
- *                       must own its GPU (with another process on the same GPU set "tiled" to 0).
+ *   "wide"              1 (default) = robots of up to 512 voxels and 1023 bonds are stepped by the wide kernel (one lane per bond, all
+ *                       three axes at once, forces summed in the reference's order); 0 = by the resident kernel with its three bond
+ *                       rounds (cross-checks).  Like "tiled" a function of the robot alone.
+ *   "col_cap"           partners a collision row can hold.  0 (default) = every other surface voxel of the robot, i.e. unbounded like
+ *                       the reference's lists (CVX_Sim::CreateColBond has no cap); memory: 12-16 bytes x nsurf^2 per colliding robot
+ *                       (5 MB for a 10x10x10 robot), touched only as far as rows really grow.  n > 0 bounds the rows at n partners
+ *                       (less memory); a robot one of whose rows would need more ends with VXH_ROBOT_COL_OVERFLOW.
+ *                       These five belong to the uploaded batch: set them before the first vxh_run / vxh_step or right after
+ *                       vxh_reset (VXH_ERR_STATE once a step has been taken).  The tiles of a robot wait for each other on the
+ *                       device: an engine that tiles must own its GPU (with another process on the same GPU set "tiled" to 0).
  *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 1024).  A launch of a self-colliding population
  *                       carries ~0.27 ms of fixed cost, so vxh_step(e, n) with a small n is paid for: 20 steps at a time run at
  *                       ~47 us per step where 1000 at a time run at ~31.5 (512 robots of 10x10x10).

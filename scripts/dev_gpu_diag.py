@@ -587,3 +587,22 @@ if __name__ == "__main__" and "launchlen" in sys.argv[1:]:
             c = eng.counters()
             print("steps per launch %5d: %3d launches, kernel %.4f s = %.2f us per step, vxh_run wall %.4f s; all finished: %s" % (
                 L, c.launches, c.kernel_seconds, 1e6 * c.kernel_seconds / c.max_steps, wall, all(eng.result(i).status == 1 for i in range(len(paths)))), flush=True)
+
+
+if __name__ == "__main__" and "smallphases" in sys.argv[1:]:
+    # round 3: where a step of the latency-bound configs goes (resident kernel; developer library), and their plain timings
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    if "prof" in sys.argv[1:]:
+        engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+        engine._lib = None
+    ph = "prof" in sys.argv[1:]
+    print("64 x 6^3 walkers", flush=True)
+    timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.05, Env(), {}, phases=ph)
+    print("64 x 8^3 swimmers", flush=True)
+    timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.05, env_w, {}, per_voxel_phase=True, phases=ph)
+    print("64 x 8^3 walkers", flush=True)
+    timing_cfg(engine.VOXCAD, 64, (8, 8, 8), 0.05, Env(), {}, phases=ph)
+    print("64 x 10^3 walkers", flush=True)
+    timing_cfg(engine.VOXCAD, 64, (10, 10, 10), 0.03, Env(), {}, phases=ph)

@@ -25,10 +25,12 @@ def manifest():
         return json.load(handle)
 
 
-# Every GPU test runs once per kernel path: "auto" (the engine's own choice: small test batches go to the multi-workgroup
-# kernel with one bond per lane), "resident" (tiled = 0: one workgroup per robot / streaming kernels, the round-1 paths) and
-# "tiles3" (every robot cut into about three tiles whatever its size).  A test that sets the options itself overrides this.
-KERNEL_PATHS = {"auto": "", "resident": "tiled=0", "tiles3": "tiled=2,tiles_per_robot=3"}
+# Every GPU test runs once per kernel path, three DIFFERENT kernels for the small robots most tests use: "auto" (the engine's own
+# choice: robots of up to 512 voxels go to the wide kernel, kernels_wide.hpp; larger ones to the resident kernel, lattices above
+# 1024 voxels to the tiled one), "narrow" (wide = 0, tiled = 0: the resident kernel k_robot_steps with its three bond rounds /
+# the streaming kernels: the round-1 paths) and "tiles3" (every robot cut into about three tiles whatever its size:
+# k_tile_steps).  A test that sets the options itself overrides this.
+KERNEL_PATHS = {"auto": "", "narrow": "tiled=0,wide=0", "tiles3": "tiled=2,tiles_per_robot=3"}
 
 
 def pytest_generate_tests(metafunc):

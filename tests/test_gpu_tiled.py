@@ -31,7 +31,7 @@ def test_tiling_does_not_change_the_trajectory(golden_dir):
     from evosoro_amd import engine as eng_mod
     paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in LAND]
     checkpoints = (1, 7, 300, 900)            # 900 steps: past InitCmTime for most robots, launches of 256 steps chained
-    ref = _states(eng_mod, paths, {"tiled": 0}, checkpoints)
+    ref = _states(eng_mod, paths, {"tiled": 0, "wide": 0}, checkpoints)      # (the resident kernel: the tiled one sums in ITS order)
     bitwise = {}
     for k in (1, 2, 5):
         got = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": k}, checkpoints)
@@ -94,6 +94,7 @@ def test_kernel_choice_follows_the_robot_alone_unless_tile_small(golden_dir):
         with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
             eng.set_option("tiled", 1)                                 # the automatic policy, whatever kernel the test matrix forces
             eng.set_option("tiles_per_robot", 0)                       # (conftest.py: VXH_ENGINE_OPTIONS)
+            eng.set_option("wide", 1)
             for key, val in options.items():
                 eng.set_option(key, val)
             eng.add_vxa_file(path)
@@ -106,6 +107,8 @@ def test_kernel_choice_follows_the_robot_alone_unless_tile_small(golden_dir):
     assert blk == 1                                                    # ... tiled on request
     assert np.abs(big_small[:, :8] - big_default[:, :8]).max() < 1e-12
     small_default, blk = run(small, {})
-    assert blk == 256
+    assert blk == 513                                                  # (the wide kernel, k_robot_wide<512>: reported as its workgroup size + 1)
     small_small, blk = run(small, {"tile_small": 1})
-    assert blk == 256 and np.array_equal(small_small, small_default)  # small robots are never worth tiling: unchanged
+    assert blk == 513 and np.array_equal(small_small, small_default)  # small robots are never worth tiling: unchanged
+    small_narrow, blk = run(small, {"wide": 0})
+    assert blk == 256 and np.abs(small_narrow[:, :8] - small_default[:, :8]).max() < 1e-11   # resident on request: other summation order
