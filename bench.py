@@ -167,7 +167,48 @@ def measured_traffic(robots_per_gpu, lattice):
 
 
 def kernel_name(block):
-    return "k_tile_steps" if block == 1 else (("k_robot_steps<%d,...>" % block) if block else "k_bonds+k_voxels")
+    """vxh_counters.dominant_block -> kernel: 0 streaming, 1 tiled, workgroup size of the resident kernel, workgroup size + 1 of the wide one"""
+    if block == 1:
+        return "k_tile_steps"
+    if block > 1 and block % 64 == 1:
+        return "k_robot_wide<%d,...>" % (block - 1)
+    return ("k_robot_steps<%d,...>" % block) if block else "k_bonds+k_voxels"
+
+
+def measured_compute(kernel):
+    """What the SQ counters say binds the dominant kernel (newest profiles/r*_compute.json, written by scripts/profile_sum.py from
+    separate rocprofv3 --pmc passes over this command): share of the SIMD cycles in which a vector instruction was executing,
+    share of wavefront time spent waiting, LDS bank-conflict ratio, and the FP64 rate those instructions amount to against the
+    vector-FP64 peak.  Counters cannot be read from inside this process: reported only when the profile is of this kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_compute.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        c = json.load(f)
+    if kernel.split("<")[0] not in c.get("kernel", "") or kernel.split("<")[-1].split(",")[0] not in c.get("kernel", ""):
+        return None
+    c["source"] = os.path.relpath(files[-1], REPO)
+    return c
+
+
+def relaunch_under_launcher(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this same command under
+    torch.distributed.run and pass its exit code on -- instead of silently measuring one GPU."""
+    import socket
+    import torch
+    share = os.environ.get("VXH_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not share and have < n_gpus:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible (VXH_BENCH_SHARE_GPU=1 walks the N-rank path on one device)\n" % (n_gpus, have))
+        raise SystemExit(2)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    entry = os.environ.get("VXH_BENCH_ENTRY", os.path.abspath(__file__))      # (tests launch a wrapper that stubs the engine)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), entry] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
 
 
 def timed_steps(eng, steps, barrier=None):
@@ -239,12 +280,17 @@ def main():
     from evosoro_amd import engine, parallel
     from evosoro_amd.base import Env
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_launcher(args.gpus)       # (does not return)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1 or os.environ.get("VXH_FORCE_DIST") == "1"   # (the latter: 1-rank RCCL smoke test)
-    if args.gpus != world and distributed:
-        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE %d\n" % (args.gpus, world))
+        raise SystemExit(2)
     # VXH_BENCH_SHARE_GPU=1: every rank on device 0 and gloo instead of RCCL -- only to walk the N > 1 code path on a 1-GPU box
     share_gpu = os.environ.get("VXH_BENCH_SHARE_GPU") == "1"
     if share_gpu:
@@ -321,6 +367,30 @@ def main():
                       "kernel": kernel_name(sc1.dominant_block)}
             seng.close()
 
+        handle = None
+        if world > 1:
+            # the other N-GPU route: ONE process, one handle over the N devices (vxh_create_multi: the C ABI partitions the population
+            # by cost, one host thread per device, results stay in host memory -- no collective).  Rank 0 steps N x 512 robots through
+            # it while the other ranks wait at the barrier below; same timing protocol.
+            if rank == 0:
+                hp = []
+                for k in range(world):
+                    hp += make_population(os.path.join(tmp, "handle%d" % k), n_local, k * n_local, shape, sim_time, INIT_CM_TIME)
+                devices = [0] * world if share_gpu else list(range(world))
+                heng = engine.Engine(engine.VOXCAD, devices)
+                heng.add_vxa_files(hp)
+                hd = [heng.dims(i) for i in range(len(hp))]
+                h_nvox = sum(d["nvox"] for d in hd)
+                heng.step((int(max(INIT_CM_TIME / d["dt"] for d in hd)) + 32) + max(args.warmup, 1))
+                h0 = heng.counters()
+                h_elapsed = timed_steps(heng, args.steps)
+                h1 = heng.counters()
+                assert abs((h1.voxel_steps - h0.voxel_steps) - float(h_nvox) * args.steps) < 0.5
+                handle = {"scaling": "weak", "route": "one process, vxh_create_multi over devices %s" % devices, "value": h_nvox * args.steps / h_elapsed,
+                          "unit": "voxel-timesteps/s", "ms_per_step": h_elapsed / args.steps * 1e3, "robots": len(hp)}
+                heng.close()
+            dist.barrier()
+
         if rank == 0:
             dom_seconds = c1.dominant_seconds
             roof_bw = (c1.dominant_alg_bytes / dom_seconds / 1e9) if dom_seconds > 0 else 0.0
@@ -362,6 +432,13 @@ def main():
             out["roofline"].update(measured_traffic(n_local, args.lattice))
             if strong:
                 out["strong"] = strong
+            if handle:
+                out["multi_handle"] = handle
+            comp = measured_compute(kernel_name(c1.dominant_block)) if (n_local == 512 and args.lattice == 10) else None
+            if comp:
+                # the bound that binds, next to the contract's algorithmic-HBM fraction
+                out["roofline"]["compute"] = comp
+                out["roofline"]["bound"] = comp.get("bound", "hbm")
             if world == 1 and not args.no_other_configs:
                 env_w = Env()
                 env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")

@@ -1,4 +1,5 @@
 // C ABI of libvxhip (include/vxhip.h): exception -> status code translation around vxh::Engine.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -89,6 +90,43 @@ int vxh_plan_tiles_buffer(const char* xml, size_t len, int variant, int k_reques
             if (capacity < m.nvox) return fail(VXH_ERR_ARG, "tile_of buffer too small");
             for (int v = 0; v < m.nvox; ++v) tile_of_out[v] = plan.tile_of[v];
         }
+        return VXH_OK;
+    } catch (const std::exception& ex) {
+        return fail(VXH_ERR_PARSE, ex.what());
+    }
+}
+
+int vxh_inspect_constants(const char* xml, size_t len, int variant, double* vox12n, int vox_capacity, double* bond23n, int bond_capacity,
+                          char* errbuf, size_t errcap)
+{
+    if (!xml || !vox12n || !bond23n || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;
+    auto fail = [&](int code, const char* what) {
+        if (errbuf && errcap) { std::strncpy(errbuf, what, errcap - 1); errbuf[errcap - 1] = 0; }
+        return code;
+    };
+    try {
+        vxh::VxaModel vxa = vxh::read_vxa(xml, len, variant);
+        if (!vxa.unsupported.empty()) return fail(VXH_ERR_UNSUPPORTED, vxa.unsupported.front().c_str());
+        const vxh::RobotModel m = vxh::build_robot(vxa);
+        if (vox_capacity < m.nvox || bond_capacity < m.nbond) return fail(VXH_ERR_ARG, "constant buffers too small");
+        for (int v = 0; v < m.nvox; ++v) {
+            const vxh::VoxClass& c = m.vox_classes[m.vox_class[v]];
+            double* o = vox12n + (size_t)12 * v;
+            o[0] = c.mass; o[1] = c.mass_inv; o[2] = c.inertia; o[3] = c.inertia_inv; o[4] = c.first_moment; o[5] = c.c_lin; o[6] = c.c_ang;
+            o[7] = c.E; o[8] = c.nom_size; o[9] = c.u_static; o[10] = c.u_dynamic; o[11] = c.cte;
+        }
+        int k = 0;                               // bonds in the reference's creation order: per voxel, +X +Y +Z (VX_Sim.cpp:620-645)
+        for (int v = 0; v < m.nvox; ++v)
+            for (int a = 0; a < 3; ++a) {
+                const int cls = m.bond_class[(size_t)v * 3 + a];
+                if (cls < 0) continue;
+                const vxh::BondClass& b = m.bond_classes[cls];
+                double* o = bond23n + (size_t)23 * k++;
+                o[0] = v; o[1] = m.nbr[(size_t)v * 6 + 2 * a]; o[2] = a; o[3] = b.homogeneous; o[4] = b.L; o[5] = b.a1; o[6] = b.a2;
+                o[7] = b.b1; o[8] = b.b2; o[9] = b.b3; o[10] = b.b1; o[11] = b.b2; o[12] = b.b3;      // (cubic voxels: the y and z sets coincide)
+                o[13] = b.sq_a1m1; o[14] = b.sq_a1m2; o[15] = b.sq_a2i1; o[16] = b.sq_a2i2;
+                o[17] = b.sq_b1m1; o[18] = b.sq_b1m2; o[19] = b.sq_b2fm1; o[20] = b.sq_b2fm2; o[21] = b.sq_b3i1; o[22] = b.sq_b3i2;
+            }
         return VXH_OK;
     } catch (const std::exception& ex) {
         return fail(VXH_ERR_PARSE, ex.what());
@@ -219,7 +257,51 @@ int vxh_write_result_xml(const vxh_engine* ce, int robot, const char* path_or_nu
     const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
     std::fclose(f);
     if (!ok) { e->last_error = "short write to " + path; return VXH_ERR_IO; }
+    // land_water: the final mesh's per-vertex angle excesses into <CurvaturesTmpFile>, tab-separated with the stream's six
+    // significant digits, as CVX_MeshUtil::computeShapeComplexity leaves them for curvatureEntropy.py (LW/VX_MeshUtil.cpp:1016-1031;
+    // the reference then runs that script -- absent from its repository -- and removes the file; here the file stays)
+    if (m.vxa.variant == 1 && !m.vxa.curvatures_tmp_file.empty() && m.nmv > 0) {
+        std::vector<double> ex;
+        rc = guarded(e, [&] { ex = e->impl->angle_excess(robot, true); });
+        if (rc != VXH_OK) return rc;
+        if (std::FILE* c = std::fopen(m.vxa.curvatures_tmp_file.c_str(), "wb")) {      // (an unwritable path: skipped, like the reference's `return -1`)
+            for (double v : ex) std::fprintf(c, "%g\t", v);
+            std::fclose(c);
+        }
+    }
     return VXH_OK;
+}
+
+int vxh_get_angle_excess(const vxh_engine* ce, int robot, int at_end, double* out, int capacity, int* count_out)
+{
+    vxh_engine* e = const_cast<vxh_engine*>(ce);
+    if (bad_robot(e, robot) || !count_out || (capacity > 0 && !out)) return VXH_ERR_ARG;
+    return guarded(e, [&] {
+        const std::vector<double> ex = e->impl->angle_excess(robot, at_end != 0);
+        *count_out = (int)ex.size();
+        for (int k = 0; k < std::min((int)ex.size(), capacity); ++k) out[k] = ex[k];
+    });
+}
+
+int vxh_inspect_angle_excess(const char* xml, size_t len, int variant, double* out, int capacity, int* count_out, char* errbuf, size_t errcap)
+{
+    if (!xml || !count_out || (capacity > 0 && !out) || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;
+    auto fail = [&](int code, const char* what) {
+        if (errbuf && errcap) { std::strncpy(errbuf, what, errcap - 1); errbuf[errcap - 1] = 0; }
+        return code;
+    };
+    try {
+        vxh::VxaModel vxa = vxh::read_vxa(xml, len, variant);
+        if (!vxa.unsupported.empty()) return fail(VXH_ERR_UNSUPPORTED, vxa.unsupported.front().c_str());
+        const vxh::RobotModel m = vxh::build_robot(vxa);
+        std::vector<double> ex;
+        vxh::mesh_angle_excess(m, nullptr, nullptr, nullptr, ex);
+        *count_out = (int)ex.size();
+        for (int k = 0; k < std::min((int)ex.size(), capacity); ++k) out[k] = ex[k];
+        return VXH_OK;
+    } catch (const std::exception& ex) {
+        return fail(VXH_ERR_PARSE, ex.what());
+    }
 }
 
 int vxh_get_state(const vxh_engine* ce, int robot, double* out14n, int capacity)
@@ -272,6 +354,8 @@ const char* vxh_strerror(int status)
 }
 
 const char* vxh_last_error(const vxh_engine* e) { return e ? e->last_error.c_str() : ""; }
-const char* vxh_version(void) { return "vxhip 0.1.0 (gfx950)"; }
+const char* vxh_version(void) { return "vxhip 0.3.0 (gfx950)"; }
+
+int vxh_device_count(void) { return vxh::hip_device_count(); }
 
 }  // extern "C"

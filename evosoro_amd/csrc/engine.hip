@@ -31,6 +31,12 @@ void hip_check(hipError_t e, const char* what)
 
 }  // namespace
 
+int hip_device_count()
+{
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
 struct Engine::Device {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -171,7 +177,18 @@ Engine::~Engine()
     }
 }
 
-int Engine::add_vxa(const char* data, size_t len)
+// The add_* calls are build_* (parse + model building: may throw, touch nothing) followed by append(): a refused call leaves the
+// engine -- and, behind a handle over several devices, the distribution of the robots -- as it was.
+int Engine::append(std::vector<RobotModel>&& built)
+{
+    const int first = (int)robots_.size();
+    for (auto& m : built) robots_.push_back(std::move(m));
+    prepared_ = false;
+    state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
+    return first;
+}
+
+std::vector<RobotModel> Engine::build_vxa(const char* data, size_t len) const
 {
     VxaModel vxa = read_vxa(data, len, variant_);
     if (!vxa.unsupported.empty()) {
@@ -179,17 +196,20 @@ int Engine::add_vxa(const char* data, size_t len)
         for (const auto& u : vxa.unsupported) msg += " [" + u + "]";
         throw std::invalid_argument(msg);
     }
-    robots_.push_back(build_robot(vxa));
-    prepared_ = false;
-    state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
-    return (int)robots_.size() - 1;
+    std::vector<RobotModel> out;
+    out.push_back(build_robot(vxa));
+    return out;
 }
+int Engine::add_vxa(const char* data, size_t len) { return append(build_vxa(data, len)); }
+int Engine::add_vxa_files(const std::vector<std::string>& paths) { return append(build_vxa_files(paths)); }
+int Engine::add_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* in, int n, bool round_like_text)
+{ return append(build_arrays(template_vxa, len, in, n, round_like_text)); }
 
 // A generation arrives as hundreds of .vxa files; reading, XML parsing and model building (hop-distance lists, bond
 // classes, drag mesh) are independent per robot and take longer than the GPU needs to simulate them, so they are
 // spread over the host cores.  Robots are appended in the order of `paths`; the first failure (in that order) is
 // rethrown and nothing is appended.
-int Engine::add_vxa_files(const std::vector<std::string>& paths)
+std::vector<RobotModel> Engine::build_vxa_files(const std::vector<std::string>& paths) const
 {
     const int n = (int)paths.size();
     std::vector<RobotModel> built(n);
@@ -222,17 +242,13 @@ int Engine::add_vxa_files(const std::vector<std::string>& paths)
     worker();
     for (auto& t : pool) t.join();
     for (int i = 0; i < n; ++i) if (errors[i]) std::rethrow_exception(errors[i]);
-    const int first = (int)robots_.size();
-    for (int i = 0; i < n; ++i) robots_.push_back(std::move(built[i]));
-    prepared_ = false;
-    state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
-    return first;
+    return built;
 }
 
 // A generation handed over as arrays (vxh_add_robots): one parsed template + per-robot lattice and layers.  The VxaModel of a robot
 // is exactly what read_vxa builds from the file the writer would have produced: material digits as they are, layer values taken by
 // occupied-voxel counter in file order (VX_Object.cpp:1879-1900), optionally through the writer's decimal text.
-int Engine::add_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* in, int n, bool round_like_text)
+std::vector<RobotModel> Engine::build_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* in, int n, bool round_like_text) const
 {
     VxaModel base = read_vxa(template_vxa, len, variant_);
     if (!base.unsupported.empty()) {
@@ -262,6 +278,8 @@ int Engine::add_arrays(const char* template_vxa, size_t len, const vxh_robot_arr
             try {
                 const vxh_robot_arrays& A = in[i];
                 if (A.nx < 1 || A.ny < 1 || A.nz < 1 || (long long)A.nx * A.ny * A.nz > (1LL << 26) || !A.material) throw std::invalid_argument("bad lattice");
+                if (A.n_layers < 0 || (A.n_layers > 0 && (!A.layer_tags || !A.layers))) throw std::invalid_argument("bad layer arrays");
+                for (int l = 0; l < A.n_layers; ++l) if (!A.layer_tags[l] || !A.layers[l]) throw std::invalid_argument("null layer tag or layer");
                 VxaModel m = base;
                 m.nx = A.nx; m.ny = A.ny; m.nz = A.nz;
                 const size_t cells = (size_t)A.nx * A.ny * A.nz;
@@ -296,11 +314,7 @@ int Engine::add_arrays(const char* template_vxa, size_t len, const vxh_robot_arr
     worker();
     for (auto& t : pool) t.join();
     for (int i = 0; i < n; ++i) if (errors[i]) std::rethrow_exception(errors[i]);
-    const int first = (int)robots_.size();
-    for (int i = 0; i < n; ++i) robots_.push_back(std::move(built[i]));
-    prepared_ = false;
-    state_downloaded_ = control_downloaded_ = reduced_downloaded_ = false;
-    return first;
+    return built;
 }
 
 std::vector<RobotModel> Engine::take_robots()
@@ -359,10 +373,11 @@ void Engine::clear()
                             h[2112], h[2113], h[2114] ? (double)h[2114] * 12.0 / (double)h[2112] : 0.0, h[2115], h[2116], h[2117], h[2118], h[2119], h[2111]);
         if (h[2108]) fprintf(stderr, "broad-phase runs (resident kernel, with the copy of the rows): %llu, %.0f cycles each on average; workgroup-launches with at least one: %llu; "
                             "most cycles one workgroup spent in them in one launch (maximum over ALL launches): %llu\n", h[2108], (double)h[2109] / (double)h[2108], h[2107], h[2110]);
-        if (h[2108] && h[2100]) fprintf(stderr, "   of a broad-phase run, cycles on average (first wavefront): staging the surface list %.0f | its own scan %.0f | count write + wait for the "
-                                      "slowest wavefront %.0f | the rest (copy of the rows to LDS) %.0f\n", (double)h[2100] / h[2108], (double)h[2101] / h[2108], (double)h[2102] / h[2108],
-                                      ((double)h[2109] - (double)h[2100] - (double)h[2101] - (double)h[2102]) / h[2108]);
-        if (h[2104]) fprintf(stderr, "   broad-phase cross-check (dbg 16): %llu rows built by both scans, %llu differ\n", h[2104], h[2105]);
+        if (h[2108] && h[2100]) fprintf(stderr, "   of a broad-phase run, cycles on average (first wavefront): staging the surface list %.0f | its own scan / block pairs %.0f | wait for the "
+                                      "slowest wavefront %.0f | bit matrix -> rows %.0f | the rest (copy of the rows to LDS) %.0f\n", (double)h[2100] / h[2108], (double)h[2101] / h[2108], (double)h[2102] / h[2108],
+                                      (double)h[2126] / h[2108], ((double)h[2109] - (double)h[2100] - (double)h[2101] - (double)h[2102] - (double)h[2126]) / h[2108]);
+        if (h[2104]) fprintf(stderr, "   broad-phase cross-check (dbg 16): %llu rows built by both scans, %llu differ (%llu longer, %llu shorter than the plain scan's; longest row %llu against %llu; partners in all %llu against %llu)\n",
+                             h[2104], h[2105], h[2120], h[2121], h[2122], h[2123], h[2124], h[2125]);
         if (h[2103]) fprintf(stderr, "   prologue of the resident kernel, cycle sums of the first thread over all workgroup-launches: tables + first barrier %.3e | state load, zeroing, "
                              "first control %.3e | rows_to_lds %.3e  = (its parts, incl. the calls after broad-phase runs) ordinal -> count loads + barrier %.3e | scan + allotment %.3e | copy + barrier %.3e\n",
                              (double)h[2103], (double)h[2106], (double)h[2113], (double)h[2114], (double)h[2115], (double)h[2116]);
@@ -398,28 +413,48 @@ void Engine::drop_graph()
     if (dev_->graph) { hipGraphDestroy(dev_->graph); dev_->graph = nullptr; }
 }
 
-void Engine::set_option(const std::string& key, double value)
+// throws what set_option would throw for this key / value in the engine's present state, and changes nothing: a handle over several
+// devices applies an option to all of its engines or to none
+void Engine::check_option(const std::string& key, double value) const
 {
 #ifdef VXH_PHASE_TIMING
-    if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; drop_graph(); }    // physics-skipping what-if switches: developer library only
-    else
+    if (key == "dbg") return;                 // physics-skipping what-if switches: developer library only
 #endif
-    if (key == "fused") { fused_ = value != 0; drop_graph(); }
-    else if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
-    else if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); steps_per_launch_ = (int)value; }
-    else if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "col_cap") {
+    if (key == "fused" || key == "host_results") return;
+    if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); return; }
+    if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); return; }
+    if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "col_cap") {
         // which kernel steps a robot, its tiling and the size of its contact rows are part of the uploaded batch: set before the first
         // vxh_run / vxh_step, or right after vxh_reset (no step taken yet: the batch is then assembled again at the next run)
         if (prepared_ && rounds_done_ > 0) throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or right after vxh_reset)");
-        prepared_ = false;
-        if (key == "wide") { if (value != 0 && value != 1) throw std::invalid_argument("wide: 0 or 1"); wide_ = value != 0; }
-        else if (key == "col_cap") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("col_cap out of range"); col_cap_ = (int)value; }
-        else if (key == "tiled") { if (value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2"); tiled_ = (int)value; }
-        else if (key == "tile_small") { if (value != 0 && value != 1) throw std::invalid_argument("tile_small: 0 or 1"); tile_small_ = value != 0; }
-        else { if (!(value >= 0 && value <= 4096)) throw std::invalid_argument("tiles_per_robot out of range"); tiles_per_robot_ = (int)value; }
+        if (key == "wide" && value != 0 && value != 1) throw std::invalid_argument("wide: 0 or 1");
+        if (key == "col_cap" && !(value >= 0 && value <= 1e6)) throw std::invalid_argument("col_cap out of range");
+        if (key == "tiled" && value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2");
+        if (key == "tile_small" && value != 0 && value != 1) throw std::invalid_argument("tile_small: 0 or 1");
+        if (key == "tiles_per_robot" && !(value >= 0 && value <= 4096)) throw std::invalid_argument("tiles_per_robot out of range");
+        return;
     }
-    else if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); graph_steps_ = (int)value; drop_graph(); }
-    else throw std::invalid_argument("unknown option " + key);
+    throw std::invalid_argument("unknown option " + key);
+}
+
+void Engine::set_option(const std::string& key, double value)
+{
+    check_option(key, value);
+#ifdef VXH_PHASE_TIMING
+    if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; drop_graph(); return; }
+#endif
+    if (key == "fused") { fused_ = value != 0; drop_graph(); }
+    else if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
+    else if (key == "steps_per_launch") steps_per_launch_ = (int)value;
+    else if (key == "graph_steps") { graph_steps_ = (int)value; drop_graph(); }
+    else {
+        prepared_ = false;                    // (the batch is assembled again at the next run)
+        if (key == "wide") wide_ = value != 0;
+        else if (key == "col_cap") col_cap_ = (int)value;
+        else if (key == "tiled") tiled_ = (int)value;
+        else if (key == "tile_small") tile_small_ = value != 0;
+        else tiles_per_robot_ = (int)value;
+    }
 }
 
 // where the host-side time of a run goes (VXH_PROF_HOST=1: one line per prepare() / advance() on stderr)
@@ -1110,8 +1145,12 @@ void Engine::advance(long long max_rounds)
     if (tiled) {
         // every tiled launch on the one tile stream: the tiles of a robot wait for each other, so two such launches must never
         // compete for the CUs
+        // ... nor with anything else: the launches are sized for an empty chip (capacity() in prepare()), and the tiles of a robot that
+        // are already placed spin -- holding their CUs -- until the missing ones arrive.  In a mixed batch the tiled launches therefore
+        // run AFTER the launch groups of the resident robots, and the streaming kernels after them.
         const int iters = std::max(1, steps_per_launch_);
         HIP_OK(hipStreamWaitEvent(D.tile_stream, D.ev0, 0));
+        if (fused) for (auto& g : D.groups) HIP_OK(hipStreamWaitEvent(D.tile_stream, g.t1, 0));
         HIP_OK(hipEventRecord(D.tile_t0, D.tile_stream));
         for (long long done = 0; done < todo || done == 0; done += iters)
             for (const auto& L : D.tile_launches) {
@@ -1123,6 +1162,7 @@ void Engine::advance(long long max_rounds)
         HIP_OK(hipEventRecord(D.tile_t1, D.tile_stream));
     }
     if (streaming) {
+        if (tiled) HIP_OK(hipStreamWaitEvent(D.stream, D.tile_t1, 0));
         const int nb_b = (3 * B.nv + 255) / 256, nb_v = (B.nv + 255) / 256;
         auto round = [&](long long c) {
             hipLaunchKernelGGL(k_step_begin, dim3(B.n_robots), dim3(256), 0, D.stream, B, c, 1);
@@ -1314,6 +1354,19 @@ int Engine::cm_trace(int robot, double* out4n, int capacity)
     const int n = (int)(t.size() / 4);
     for (int k = 0; k < std::min(n, capacity) * 4; ++k) out4n[k] = t[k];
     return n;
+}
+
+std::vector<double> Engine::angle_excess(int robot, bool at_end)
+{
+    const RobotModel& M = robots_[robot];
+    std::vector<double> out;
+    if (!at_end) { mesh_angle_excess(M, nullptr, nullptr, nullptr, out); return out; }
+    if (!prepared_) throw std::logic_error("angle excesses of the final state requested before vxh_run/vxh_step");
+    if (!state_downloaded_) download();
+    const HostState& H = host_[robot];
+    if (H.steps == 0 || (int)H.strain.size() != 6 * M.nvox) mesh_angle_excess(M, nullptr, nullptr, nullptr, out);
+    else mesh_angle_excess(M, H.pos.data(), H.quat.data(), H.strain.data(), out);
+    return out;
 }
 
 void Engine::bond_modes(long long* large_angle, long long* total)

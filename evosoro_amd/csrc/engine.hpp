@@ -30,6 +30,11 @@ public:
     int add_vxa(const char* data, size_t len);              // returns robot index; throws
     int add_vxa_files(const std::vector<std::string>& paths);   // parse + build on all host cores, append in order; returns first index
     int add_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text);   // returns first index
+    // the same in two steps: parse + build (throws, changes nothing), then append
+    std::vector<RobotModel> build_vxa(const char* data, size_t len) const;
+    std::vector<RobotModel> build_vxa_files(const std::vector<std::string>& paths) const;
+    std::vector<RobotModel> build_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text) const;
+    int append(std::vector<RobotModel>&& built);             // returns first index
     int num_robots() const { return (int)robots_.size(); }
     const RobotModel& robot(int i) const { return robots_[i]; }
     void run();                                // to completion
@@ -41,8 +46,10 @@ public:
     void state14(int robot, double* out, int capacity);
     void counters(vxh_counters* out) const { *out = counters_; }
     int cm_trace(int robot, double* out4n, int capacity);      // returns the number of points recorded
+    std::vector<double> angle_excess(int robot, bool at_end);  // land_water: discrete curvature of every mesh vertex, rest state / current state
     void bond_modes(long long* large_angle, long long* total);   // SmallAngle flags of every bond, downloaded
     void set_option(const std::string& key, double value);
+    void check_option(const std::string& key, double value) const;   // throws what set_option would throw, changes nothing
     int variant() const { return variant_; }
     int device() const { return device_id_; }
     // EngineSet moves robots between the engines of a handle (host-side models only; the batch is rebuilt on the next run)
@@ -104,6 +111,7 @@ public:
     void set_option(const std::string& key, double value);
     int cm_trace(int robot, double* out4n, int capacity);
     const std::vector<double>& trace_of(int robot);
+    std::vector<double> angle_excess(int robot, bool at_end);
     void bond_modes(long long* large_angle, long long* total);
     int n_devices() const { return (int)engines_.size(); }
 
@@ -116,10 +124,14 @@ private:
     bool distributed_ = false;
 };
 
+int hip_device_count();      // engine.hip: HIP devices this process can use (0 when the runtime reports none)
+
 // results.cpp: the numbers of CVX_SimGA::WriteResultFile from a final state, and the XML text
 void compute_result(const RobotModel& model, const HostState& st, vxh_result* out);
 std::string result_xml(const RobotModel& model, const vxh_result& res, const std::vector<double>& cm_trace);
 const std::vector<double>& empty_trace();
 double convex_hull_volume(const std::vector<double>& xyz);   // results.cpp: what stands in for the reference's external qhull
+// results.cpp: per-vertex angle excess of the surface mesh (LW/VX_MeshUtil.cpp:956-1014); pos / quat / strain null = the rest state
+void mesh_angle_excess(const RobotModel& model, const double* pos, const double* quat, const double* strain, std::vector<double>& out);
 
 }  // namespace vxh

@@ -74,10 +74,14 @@ void EngineSet::each(const std::function<void(Engine&)>& body)
     for (auto& e : errors) if (e) std::rethrow_exception(e);
 }
 
-int EngineSet::add_vxa(const char* data, size_t len) { gather(); return engines_[0]->add_vxa(data, len); }
-int EngineSet::add_vxa_files(const std::vector<std::string>& paths) { gather(); return engines_[0]->add_vxa_files(paths); }
+// additions: parse and build first -- a refused call (bad file, unsupported feature) leaves the robots where they are, with the
+// results of earlier runs readable -- then bring every robot back to engine 0 and append
+int EngineSet::add_vxa(const char* data, size_t len)
+{ std::vector<RobotModel> m = engines_[0]->build_vxa(data, len); gather(); return engines_[0]->append(std::move(m)); }
+int EngineSet::add_vxa_files(const std::vector<std::string>& paths)
+{ std::vector<RobotModel> m = engines_[0]->build_vxa_files(paths); gather(); return engines_[0]->append(std::move(m)); }
 int EngineSet::add_arrays(const char* t, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text)
-{ gather(); return engines_[0]->add_arrays(t, len, robots, n, round_like_text); }
+{ std::vector<RobotModel> m = engines_[0]->build_arrays(t, len, robots, n, round_like_text); gather(); return engines_[0]->append(std::move(m)); }
 
 int EngineSet::num_robots() const { return distributed_ ? (int)where_.size() : engines_[0]->num_robots(); }
 const RobotModel& EngineSet::robot(int i) const
@@ -85,12 +89,13 @@ const RobotModel& EngineSet::robot(int i) const
 
 void EngineSet::run() { distribute(); each([](Engine& e) { e.run(); }); }
 void EngineSet::step(long long n) { distribute(); each([n](Engine& e) { e.step(n); }); }
-void EngineSet::reset() { each([](Engine& e) { e.reset(); }); }
+void EngineSet::reset() { distribute(); each([](Engine& e) { e.reset(); }); }      // (distribute first: not the whole population on device 0)
 void EngineSet::clear() { for (auto& e : engines_) e->clear(); where_.clear(); distributed_ = false; }
 
+// (readers distribute first, like run(): after an addition, or a reset, the engine that holds the robot says what is missing)
 void EngineSet::result(int robot, vxh_result* out)
 {
-    if (!distributed_) throw std::logic_error("results requested before vxh_run/vxh_step");
+    distribute();
     engines_[where_[robot].first]->result(where_[robot].second, out);
 }
 void EngineSet::state14(int robot, double* out, int capacity)
@@ -100,17 +105,22 @@ void EngineSet::state14(int robot, double* out, int capacity)
 }
 int EngineSet::cm_trace(int robot, double* out4n, int capacity)
 {
-    if (!distributed_) throw std::logic_error("trace requested before vxh_run/vxh_step");
+    distribute();
     return engines_[where_[robot].first]->cm_trace(where_[robot].second, out4n, capacity);
 }
 const std::vector<double>& EngineSet::trace_of(int robot)
 {
-    if (!distributed_) throw std::logic_error("trace requested before vxh_run/vxh_step");
+    distribute();
     return engines_[where_[robot].first]->trace_of(where_[robot].second);
+}
+std::vector<double> EngineSet::angle_excess(int robot, bool at_end)
+{
+    distribute();
+    return engines_[where_[robot].first]->angle_excess(where_[robot].second, at_end);
 }
 void EngineSet::bond_modes(long long* large_angle, long long* total)
 {
-    if (!distributed_) throw std::logic_error("bond modes requested before vxh_run/vxh_step");
+    distribute();
     *large_angle = *total = 0;
     for (auto& e : engines_) { if (e->num_robots() == 0) continue; long long l = 0, t = 0; e->bond_modes(&l, &t); *large_angle += l; *total += t; }
 }
@@ -135,6 +145,11 @@ void EngineSet::counters(vxh_counters* out) const
     }
 }
 
-void EngineSet::set_option(const std::string& key, double value) { for (auto& e : engines_) e->set_option(key, value); }
+// to every engine or to none: an engine without robots would accept what one that has stepped refuses
+void EngineSet::set_option(const std::string& key, double value)
+{
+    for (auto& e : engines_) e->check_option(key, value);
+    for (auto& e : engines_) e->set_option(key, value);
+}
 
 }  // namespace vxh

@@ -99,6 +99,11 @@ __device__ __forceinline__ void fused_latch_cm(const DRobot& R, DRobotState& rs,
 // CalcL1Bonds (VX_Sim.cpp:2357-2413) from the pose tile; thread i owns surface voxel i (see rebuild_rows in kernels.hpp).  This scan
 // (every lane reads every candidate's index and pose from LDS) is what the 256-, 512- and 768-thread variants run; the 1024-thread
 // variant runs fused_rebuild_staged below.  The developer build runs both (what-if switch 16) and compares the rows.
+#ifdef VXH_PHASE_TIMING
+#define VXH_RB_MARK(slot) { const unsigned long long t_now = __builtin_readcyclecounter(); if (B.prof && tid == 0) atomicAdd(&B.prof[slot], t_now - t_rb); t_rb = t_now; }
+#else
+#define VXH_RB_MARK(slot)
+#endif
 template <int BLOCK>
 __device__ __forceinline__ void fused_rebuild_plain(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, int* shi,
                                               const DVoxClass* vct)
@@ -106,9 +111,6 @@ __device__ __forceinline__ void fused_rebuild_plain(const DBatch& B, const DRobo
     const int tid = opaque_tid<BLOCK>(), ns = R.nsurf;
 #ifdef VXH_PHASE_TIMING
     unsigned long long t_rb = __builtin_readcyclecounter();
-#define VXH_RB_MARK(slot) { const unsigned long long t_now = __builtin_readcyclecounter(); if (B.prof && tid == 0) atomicAdd(&B.prof[slot], t_now - t_rb); t_rb = t_now; }
-#else
-#define VXH_RB_MARK(slot)
 #endif
     for (int k = tid; k < ns; k += BLOCK) {      // local voxel index | class of every surface voxel
         const int g = B.surf[R.surf_begin + k];
@@ -237,12 +239,14 @@ __device__ __forceinline__ void fused_rebuild_staged(const DBatch& B, const DRob
     __syncthreads();
 }
 
-// lane `lane` (a compile-time constant after unrolling) of `old` := the uniform value `sval` (v_writelane_b32: one VALU instruction, no compare / select)
-// (the lane number must be a literal: gfx9 allows one scalar register per VALU instruction, and `sval` is it)
+// lane `lane` (a compile-time constant after unrolling) of `old` := the uniform value `sval`.  Written as compare + select on purpose:
+// v_writelane_b32 through inline assembly does it in one instruction, and with it in this rarely executed function the STEP of a
+// colliding population ran twice as slow (61.9 against 30.4 us per population step, same box, same source otherwise: round 3,
+// scripts/ab_lib.py lc2) while a population without collisions was unaffected -- the compiler's handling of the hot loop changes
+// with an asm statement anywhere in the kernel; not investigated further.
 __device__ __forceinline__ unsigned writelane_u32(unsigned old, unsigned sval, int lane)
 {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(lane));
-    return old;
+    return ((int)(threadIdx.x & 63) == lane) ? sval : old;
 }
 
 // CalcL1Bonds (VX_Sim.cpp:2357-2413) as a BIT MATRIX built from 64 x 64 blocks of surface-voxel pairs, every unordered pair tested
@@ -272,12 +276,16 @@ __device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot&
     const int nb = (ns + 63) >> 6, NS = nb << 6;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NW = BLOCK / 64;
+#ifdef VXH_PHASE_TIMING
+    unsigned long long t_rb = __builtin_readcyclecounter();
+#endif
     for (int k = tid; k < NS; k += BLOCK) {
         double x = 1.0e150, y = 1.0e150, z = 1.0e150;          // (a slot past the list: farther than any bound from every voxel; rows past the list accept nothing, thr < 0)
         if (k < ns) { const int l = B.surf[R.surf_begin + k] - R.vox_begin; x = ps[l]; y = ps[BLOCK + l]; z = ps[2 * BLOCK + l]; }
         stg[k] = x; stg[NS + k] = y; stg[2 * NS + k] = z;
     }
     __syncthreads();
+    VXH_RB_MARK(2100)      // staging
     const double H = R.col_horizon, filter2 = R.filter_dist2;
     const int npairs = nb * (nb + 1) / 2;
     for (int p = wave; p < npairs; p += NW) {
@@ -293,26 +301,27 @@ __device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot&
             const double act2 = act * act;
             thr = act2 < filter2 ? act2 : filter2;
         }
-        unsigned own_lo = 0, own_hi = 0, col_lo = 0, col_hi = 0;
+        unsigned own_w[2] = {0, 0}, col_lo = 0, col_hi = 0;
         const double* q = stg + (J << 6);
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const d3 d = pi - mk3(q[u], q[NS + u], q[2 * NS + u]);
-            const bool in = len2(d) < thr;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
-            own_lo |= in ? (1u << u) : 0u;
-            col_lo = writelane_u32(col_lo, (unsigned)m, u);
-            col_hi = writelane_u32(col_hi, (unsigned)(m >> 32), u);
-        }
+        for (int half = 0; half < 2; ++half) {
+            unsigned own = 0;
+#pragma unroll 1
+            for (int u0 = 0; u0 < 32; u0 += 8) {           // (eight candidates in flight: unrolled further the compiler keeps all 64 lane masks alive and spills them)
 #pragma unroll
-        for (int u = 32; u < 64; ++u) {
-            const d3 d = pi - mk3(q[u], q[NS + u], q[2 * NS + u]);
-            const bool in = len2(d) < thr;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
-            own_hi |= in ? (1u << (u - 32)) : 0u;
-            col_lo = writelane_u32(col_lo, (unsigned)m, u);
-            col_hi = writelane_u32(col_hi, (unsigned)(m >> 32), u);
+                for (int k = 0; k < 8; ++k) {
+                    const int u = 32 * half + u0 + k;
+                    const d3 d = pi - mk3(q[u], q[NS + u], q[2 * NS + u]);
+                    const bool in = len2(d) < thr;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                    own |= in ? (1u << (u0 + k)) : 0u;
+                    col_lo = writelane_u32(col_lo, (unsigned)m, u);
+                    col_hi = writelane_u32(col_hi, (unsigned)(m >> 32), u);
+                }
+            }
+            own_w[half] = own;
         }
+        const unsigned own_lo = own_w[0], own_hi = own_w[1];
         const unsigned long long own = ((unsigned long long)own_hi << 32) | own_lo, col = ((unsigned long long)col_hi << 32) | col_lo;
         if (I == J) {
             const unsigned long long below = (1ull << lane) - 1ull;          // partners before me / after me inside the block
@@ -322,7 +331,9 @@ __device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot&
             mat[(size_t)I * NS + (J << 6) + lane] = col;                     // row 64 J + lane, partners of block I
         }
     }
+    VXH_RB_MARK(2101)      // wave 0's block pairs
     __syncthreads();
+    VXH_RB_MARK(2102)      // waiting for the slowest wavefront
     if (tid < ns) {
         const int i = tid;
         const int gi = B.surf[R.surf_begin + i];
@@ -349,6 +360,7 @@ __device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot&
         B.col_cnt[R.surf_begin + i] = cnt;
     }
     __syncthreads();
+    VXH_RB_MARK(2126)      // rows written
 }
 
 // The broad-phase of a resident robot: the bit-matrix scan when its matrix (nb * NS words) fits the scratch tile and the staged
@@ -358,12 +370,21 @@ template <int BLOCK>
 __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, double* scratch, int scratch_doubles,
                                               double* pool, int pool_doubles, const DVoxClass* vct)
 {
-    const int nb = (R.nsurf + 63) >> 6, NS = nb << 6;
-    const int need_mat = nb * NS, need_stg = 3 * NS;
-    if (need_mat + need_stg <= scratch_doubles) fused_rebuild_sym<BLOCK>(B, R, rs, ps, (unsigned long long*)scratch, scratch + need_mat, vct);
-    else if (need_mat <= scratch_doubles && need_stg <= pool_doubles) fused_rebuild_sym<BLOCK>(B, R, rs, ps, (unsigned long long*)scratch, pool, vct);
-    else if constexpr (BLOCK == 1024) fused_rebuild_staged<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
-    else fused_rebuild_plain<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
+    if constexpr (BLOCK == 1024) {
+        // (the 1024-thread variant has one accumulator tile, 6 * BLOCK doubles: the matrix of a robot of more than 768 voxels rarely
+        // fits, and the extra code costs this variant, which is short of registers, scratch in its hot phases: 180 -> 252 bytes)
+        fused_rebuild_staged<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
+    } else {
+        const int nb = (R.nsurf + 63) >> 6, NS = nb << 6;
+        const int need_mat = nb * NS, need_stg = 3 * NS;
+#ifdef VXH_NO_SYM          // (developer what-if: the scan of round 2)
+        if (true) fused_rebuild_plain<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
+        else
+#endif
+        if (need_mat + need_stg <= scratch_doubles) fused_rebuild_sym<BLOCK>(B, R, rs, ps, (unsigned long long*)scratch, scratch + need_mat, vct);
+        else if (need_mat <= scratch_doubles && need_stg <= pool_doubles) fused_rebuild_sym<BLOCK>(B, R, rs, ps, (unsigned long long*)scratch, pool, vct);
+        else fused_rebuild_plain<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
+    }
 }
 
 // land_water fluid drag (LW/VX_Sim.cpp:1516-1597) inside the resident kernel; the per-corner and per-facet arithmetic is
@@ -923,6 +944,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
                     for (int k = 0; k < n_old; ++k) { const size_t at = col_at(R, k, my_row); sum_old += (unsigned long long)(k + 1) * ((unsigned long long)B.col_partner[at] * 1000003ull + (unsigned long long)__double_as_longlong(B.col_a1[at])); }
                     atomicAdd(&B.prof[2104], 1ull);
                     if (n_old != n_new || sum_old != sum_new) atomicAdd(&B.prof[2105], 1ull);
+                    if (n_new > n_old) atomicAdd(&B.prof[2120], 1ull);
+                    if (n_new < n_old) atomicAdd(&B.prof[2121], 1ull);
+                    atomicMax(&B.prof[2122], (unsigned long long)n_new);
+                    atomicMax(&B.prof[2123], (unsigned long long)n_old);
+                    atomicAdd(&B.prof[2124], (unsigned long long)n_new);
+                    atomicAdd(&B.prof[2125], (unsigned long long)n_old);
                 }
                 __syncthreads();
             }

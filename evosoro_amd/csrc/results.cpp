@@ -193,6 +193,38 @@ double convex_hull_volume(const std::vector<double>& pts)
     return std::fabs(volume);
 }
 
+// Angle excess 2 pi - (sum of the facet angles meeting in the vertex) of every vertex of the deformable surface mesh: the discrete
+// curvatures CVX_MeshUtil::computeShapeComplexity (LW/VX_MeshUtil.cpp:956-1014) writes to <CurvaturesTmpFile> for the entropy script
+// (which the reference repository does not contain).  Same operation order: a vertex adds the angles of its facets in facet order
+// (the reference loops vertex-major and scans all facets per vertex -- O(V F); here one pass over the facets adds each facet's three
+// angles to its three vertices, which visits a vertex's facets in the same order); edge vectors normalised with Vec3D::Normalize
+// (sqrt, three divisions), angle = acos of their dot product, PI = 3.14159265358979 (Vec3D.h).
+void mesh_angle_excess(const RobotModel& M, const double* pos, const double* quat, const double* strain, std::vector<double>& out)
+{
+    out.assign((size_t)M.nmv, 0.0);
+    if (M.nmv == 0) return;
+    std::vector<double> vert;
+    mesh_vertices(M, pos, quat, strain, vert);
+    std::vector<double> sum((size_t)M.nmv, 0.0);
+    const size_t nf = M.facet_vox.size();
+    auto angle_at = [&](int at, int p, int q) {
+        double v1[3], v2[3];
+        for (int k = 0; k < 3; ++k) { v1[k] = vert[(size_t)3 * p + k] - vert[(size_t)3 * at + k]; v2[k] = vert[(size_t)3 * q + k] - vert[(size_t)3 * at + k]; }
+        const double l1 = std::sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]), l2 = std::sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]);
+        if (l1 > 0) { v1[0] /= l1; v1[1] /= l1; v1[2] /= l1; }
+        if (l2 > 0) { v2[0] /= l2; v2[1] /= l2; v2[2] /= l2; }
+        return std::acos(v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]);
+    };
+    for (size_t f = 0; f < nf; ++f) {
+        const int a = M.facet_vert[3 * f], b = M.facet_vert[3 * f + 1], c = M.facet_vert[3 * f + 2];
+        // (`if V == a ... else if V == b ... else if V == c`: a vertex listed twice by a facet is counted once, as its first role)
+        sum[a] += angle_at(a, b, c);
+        if (b != a) sum[b] += angle_at(b, a, c);
+        if (c != a && c != b) sum[c] += angle_at(c, a, b);
+    }
+    for (int i = 0; i < M.nmv; ++i) out[i] = (2.0 * 3.14159265358979) - sum[i];
+}
+
 // <ConvexHullVolumeStart/End> of a land_water robot: the hull of its surface-mesh vertices as the reference hands them to qhull,
 // i.e. printed with the stream's 6 significant digits (LW/VX_MeshUtil.cpp:806)
 double robot_hull_volume(const RobotModel& M, const double* pos, const double* quat, const double* strain)

@@ -229,8 +229,10 @@ VxaModel read_vxa(const char* data, size_t len, int variant)
     if (const XmlNode* eq = sim ? sim->child("EquilibriumMode") : nullptr)
         if (flag(eq, "EquilibriumModeEnabled", false)) m.unsupported.push_back("EquilibriumModeEnabled");
     m.min_temp_fact = num(sim, "MinTempFact", 0.1);
-    if (const XmlNode* ga = sim ? sim->child("GA") : nullptr)
+    if (const XmlNode* ga = sim ? sim->child("GA") : nullptr) {
         if (const XmlNode* f = ga->child("FitnessFileName")) m.fitness_file_name = f->text;
+        if (const XmlNode* f = ga->child("CurvaturesTmpFile")) m.curvatures_tmp_file = f->text;
+    }
     if (!(m.stop_type >= 0 && m.stop_type <= 3)) m.unsupported.push_back("StopConditionType>3");
 
     // ---- Environment (VX_Environment.cpp:123-234; LW/VX_Environment.cpp:190-191)

@@ -39,6 +39,7 @@ struct VxaModel {
     double stop_value = 0, afterlife_time = 0, midlife_freeze_time = 0, init_cm_time = 0;
     double min_temp_fact = 0.1;
     std::string fitness_file_name;
+    std::string curvatures_tmp_file;       // <CurvaturesTmpFile> (land_water GA section): where the per-vertex angle excesses go
     // Environment
     bool grav_enabled = false, floor_enabled = false, temp_enabled = false, vary_temp_enabled = false;
     double grav_acc = -9.81, temp_amplitude = 0, temp_base = 25, temp_period = 0.1;

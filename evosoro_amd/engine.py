@@ -16,10 +16,10 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_create_multi", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_inspect_constants", "vxh_inspect_angle_excess", "vxh_get_angle_excess", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_create_multi", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_cm_trace", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
-           "vxh_last_error", "vxh_version"]
+           "vxh_last_error", "vxh_version", "vxh_device_count"]
 
 
 class VxhResult(ctypes.Structure):
@@ -108,6 +108,10 @@ def load_library():
                                            ctypes.c_char_p, ctypes.c_size_t]
     lib.vxh_plan_tiles_buffer.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, I, ctypes.POINTER(VxhTilingInfo),
                                           ctypes.POINTER(I), I, ctypes.c_char_p, ctypes.c_size_t]
+    if hasattr(lib, "vxh_inspect_constants"):     # (absent from libraries of earlier rounds, which scripts/ab_lib.py loads for same-box comparisons)
+        lib.vxh_inspect_constants.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, P, I, P, I, ctypes.c_char_p, ctypes.c_size_t]
+        lib.vxh_inspect_angle_excess.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, P, I, ctypes.POINTER(I), ctypes.c_char_p, ctypes.c_size_t]
+        lib.vxh_get_angle_excess.argtypes = [P, I, I, P, I, ctypes.POINTER(I)]
     lib.vxh_convex_hull_volume.argtypes = [ctypes.POINTER(ctypes.c_double), I]
     lib.vxh_convex_hull_volume.restype = D
     lib.vxh_create.argtypes = [ctypes.POINTER(P), I, I]
@@ -141,6 +145,11 @@ def load_library():
     return lib
 
 
+def device_count():
+    """HIP devices the library can use (0 without a GPU)"""
+    return int(load_library().vxh_device_count())
+
+
 def inspect_vxa(text_or_path, variant=VOXCAD):
     """Host-only model summary of a .vxa (works without a GPU): counts, dt, planned step count."""
     lib = load_library()
@@ -154,6 +163,40 @@ def inspect_vxa(text_or_path, variant=VOXCAD):
     if rc != 0:
         raise VxhError(rc, "%s (%s)" % (lib.vxh_strerror(rc).decode(), err.value.decode()))
     return info
+
+
+def inspect_constants(text_or_path, variant=VOXCAD):
+    """Host-only: ([nvox, 12], [nbond, 23]) constants of every voxel and bond as the import computes them (include/vxhip.h)."""
+    lib = load_library()
+    if os.path.exists(text_or_path):
+        with open(text_or_path, "rb") as handle:
+            raw = handle.read()
+    else:
+        raw = text_or_path.encode("latin-1") if isinstance(text_or_path, str) else text_or_path
+    info = inspect_vxa(raw, variant)
+    vox, bond = np.zeros((max(info.nvox, 1), 12)), np.zeros((max(info.nbond, 1), 23))
+    err = ctypes.create_string_buffer(512)
+    rc = lib.vxh_inspect_constants(raw, len(raw), variant, vox.ctypes.data, info.nvox, bond.ctypes.data, info.nbond, err, len(err))
+    if rc != 0:
+        raise VxhError(rc, "%s (%s)" % (lib.vxh_strerror(rc).decode(), err.value.decode()))
+    return vox[:info.nvox], bond[:info.nbond]
+
+
+def inspect_angle_excess(text_or_path, variant=VOXCAD_LAND_WATER):
+    """Host-only: per-vertex angle excess of the rest-state surface mesh of a land_water .vxa (include/vxhip.h)."""
+    lib = load_library()
+    if os.path.exists(text_or_path):
+        with open(text_or_path, "rb") as handle:
+            raw = handle.read()
+    else:
+        raw = text_or_path.encode("latin-1") if isinstance(text_or_path, str) else text_or_path
+    count, err = ctypes.c_int(), ctypes.create_string_buffer(512)
+    rc = lib.vxh_inspect_angle_excess(raw, len(raw), variant, None, 0, ctypes.byref(count), err, len(err))
+    if rc != 0:
+        raise VxhError(rc, "%s (%s)" % (lib.vxh_strerror(rc).decode(), err.value.decode()))
+    out = np.zeros(max(count.value, 1))
+    lib.vxh_inspect_angle_excess(raw, len(raw), variant, out.ctypes.data, count.value, ctypes.byref(count), err, len(err))
+    return out[:count.value]
 
 
 def convex_hull_volume(points):
@@ -307,6 +350,14 @@ class Engine(object):
         self._check(self._lib.vxh_get_cm_trace(self._h, robot, None, 0, ctypes.byref(count)))
         out = np.zeros((max(count.value, 1), 4), dtype=np.float64)
         self._check(self._lib.vxh_get_cm_trace(self._h, robot, out.ctypes.data, count.value, ctypes.byref(count)))
+        return out[:count.value]
+
+    def angle_excess(self, robot, at_end=True):
+        """per-vertex angle excess of a land_water robot's surface mesh: rest state (at_end False) or current state"""
+        count = ctypes.c_int()
+        self._check(self._lib.vxh_get_angle_excess(self._h, robot, 1 if at_end else 0, None, 0, ctypes.byref(count)))
+        out = np.zeros(max(count.value, 1))
+        self._check(self._lib.vxh_get_angle_excess(self._h, robot, 1 if at_end else 0, out.ctypes.data, count.value, ctypes.byref(count)))
         return out[:count.value]
 
     def bond_modes(self):

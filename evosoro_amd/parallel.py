@@ -74,8 +74,11 @@ def barrier():
         dist.barrier()
 
 
-def gather_records(local_records, local_indices, total, device=None):
-    """All ranks receive the full [total, RECORD_LEN] table.  Single all_gather of a padded per-rank block.
+def gather_records(local_records, local_indices, total, device=None, per_rank=None):
+    """All ranks receive the full [total, RECORD_LEN] table.  ONE all_gather of a padded per-rank block: row 0 of a rank's block
+    carries its record count, rows 1.. carry (robot index, record).  `per_rank`: rows every rank reserves for its records -- all
+    ranks must pass the same value; callers that know the partition pass its largest shard (run_population), the default is `total`
+    (always enough: 288 B per robot and rank, a few hundred KB for an evosoro population).
 
     Without an initialised process group (single GPU) this is a plain scatter into the table.
     """
@@ -87,21 +90,24 @@ def gather_records(local_records, local_indices, total, device=None):
         return table
     import torch
     world = dist.get_world_size()
-    per_rank = (total + world - 1) // world + 1          # LPT shards may be uneven: allow slack, verified below
-    counts = torch.zeros(world, dtype=torch.int64, device=device)
-    mine = torch.tensor([len(local_indices)], dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(counts, mine)
-    per_rank = int(max(per_rank, int(counts.max().item())))
-    block = torch.zeros((per_rank, RECORD_LEN + 1), dtype=torch.float64, device=device)
-    if len(local_indices):
-        block[:len(local_indices), 0] = torch.tensor(list(local_indices), dtype=torch.float64, device=device)
-        block[:len(local_indices), 1:] = torch.from_numpy(local_records).to(block.device)
-    gathered = torch.zeros((world * per_rank, RECORD_LEN + 1), dtype=torch.float64, device=device)
-    dist.all_gather_into_tensor(gathered, block)
-    gathered = gathered.cpu().numpy().reshape(world, per_rank, RECORD_LEN + 1)
-    counts = counts.cpu().numpy()
+    per_rank = int(total if per_rank is None else per_rank)
+    n_mine = len(local_indices)
+    if n_mine > per_rank:
+        raise ValueError("gather_records: %d records on this rank, %d rows reserved per rank" % (n_mine, per_rank))
+    block = np.zeros((per_rank + 1, RECORD_LEN + 1), dtype=np.float64)
+    block[0, 0] = n_mine
+    if n_mine:
+        block[1:n_mine + 1, 0] = list(local_indices)
+        block[1:n_mine + 1, 1:] = local_records
+    mine = torch.from_numpy(block)
+    if device is not None:
+        mine = mine.to(device)
+    gathered = torch.zeros((world * (per_rank + 1), RECORD_LEN + 1), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(gathered, mine)
+    gathered = gathered.cpu().numpy().reshape(world, per_rank + 1, RECORD_LEN + 1)
     for r in range(world):
-        for k in range(int(counts[r])):
+        n = int(gathered[r, 0, 0])
+        for k in range(1, n + 1):
             table[int(gathered[r, k, 0])] = gathered[r, k, 1:]
     return table
 
@@ -144,19 +150,24 @@ def run_population(engine_module, paths, variant=0, costs=None, options=None, wr
         world, rank = dist.get_world_size(), dist.get_rank()
         shards = shard_by_cost(costs, world) if costs is not None else shard_round_robin(len(paths), world)
         mine = shards[rank]
+        largest = max(len(sh) for sh in shards)
     else:
         mine = list(range(len(paths)))
+        largest = len(paths)
     torch = sys.modules.get("torch")
     cuda_ready = torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized()
     if device is None:
         if dist and "LOCAL_RANK" in os.environ and not (cuda_ready and torch.cuda.current_device() != 0):
             # one process per GPU: a launcher (torch.distributed.run) exports LOCAL_RANK; honour it unless the caller has
             # selected a device itself, instead of piling every rank onto device 0
-            n_dev = torch.cuda.device_count() if (torch is not None and torch.cuda.is_available()) else 0
+            # (the device count from the engine's own library: a CPU-only torch with gloo on a multi-GPU node reports none)
+            n_dev = engine_module.device_count() if hasattr(engine_module, "device_count") else 0
+            if n_dev <= 0:
+                n_dev = torch.cuda.device_count() if (torch is not None and torch.cuda.is_available()) else 0
             device = int(os.environ["LOCAL_RANK"]) % n_dev if n_dev > 0 else 0
         else:
             device = torch.cuda.current_device() if cuda_ready else 0
     records, _ = run_shard(engine_module, [paths[i] for i in mine], variant, device, options, write_xml,
                            make_loader(mine) if make_loader else None)
     gather_device = torch.device("cuda", device) if (dist and dist.get_backend() == "nccl") else None
-    return gather_records(records, mine, len(paths), gather_device)
+    return gather_records(records, mine, len(paths), gather_device, per_rank=largest)

@@ -71,6 +71,16 @@ typedef struct vxh_result {
                                                       reference gets from an external qhull (LW/VX_MeshUtil.cpp:775-900); the
                                                       <ShapeComplexity*> tags are printed as -1 (their script is not in the reference) */
 } vxh_result;
+/* land_water shape descriptor, per vertex of the deformable surface mesh: the angle excess 2 pi - sum of the angles of the facets
+ * meeting in the vertex, exactly as CVX_MeshUtil::computeShapeComplexity forms it (LW/VX_MeshUtil.cpp:956-1014) before handing the
+ * vector to curvatureEntropy.py through <CurvaturesTmpFile> (:1016-1036).  That script is not in the reference repository, so the
+ * <ShapeComplexityStart/End> tags stay -1; the vector is what can be computed and pinned: at_end = 0 the rest state (what
+ * computeInitialShapeComplexity sees, voxelyzeMain/main.cpp:65), 1 the state after the last step (computeFinalShapeComplexity, :117).
+ * `count_out` receives the number of mesh vertices (0 for a _voxcad robot); at most `capacity` values are written.
+ * vxh_write_result_xml also writes the final vector to the robot's <CurvaturesTmpFile>, tab-separated, six significant digits. */
+int  vxh_get_angle_excess(const vxh_engine* e, int robot, int at_end, double* out, int capacity, int* count_out);
+/* ... of the rest state straight from a .vxa text, host-only (no GPU needed) */
+int  vxh_inspect_angle_excess(const char* xml, size_t len, int variant, double* out, int capacity, int* count_out, char* errbuf, size_t errcap);
 /* volume of the convex hull of n points (x, y, z per point): the computation behind hull_volume_*, exposed for testing */
 double vxh_convex_hull_volume(const double* xyz, int n);
 
@@ -113,6 +123,14 @@ typedef struct vxh_tiling_info {
     int max_bonds;           /* most bonds evaluated by a tile (bonds crossing a tile boundary count on both sides) */
     int total_bonds;         /* sum over tiles */
 } vxh_tiling_info;
+/* Host-only: the constants the import leaves on every voxel (12 doubles each: mass, 1/mass, inertia, 1/inertia, first moment,
+ * _2xSqMxExS, _2xSqIxExSxSxS, Vox_E, nominal size, uStatic, uDynamic, CTE -- CVX_Voxel::SetMaterial, VX_Voxel.cpp:94-128) and on
+ * every internal bond in the reference's creation order (23 doubles each: voxel 1, voxel 2, axis 0..2, homogeneous, L, a1, a2,
+ * b1y b2y b3y, b1z b2z b3z, _2xSqA1xM1/2, _2xSqA2xI1/2, _2xSqB1YxM1/2, _2xSqB2YxFM1/2, _2xSqB3YxI1/2 -- CVX_Bond::UpdateConstants,
+ * VX_Bond.cpp:95-173).  For the bit-for-bit comparison with the oracle (tests/test_capi.py); the kernels read tables derived
+ * from these per class. */
+int  vxh_inspect_constants(const char* xml, size_t len, int variant, double* vox12n, int vox_capacity, double* bond23n, int bond_capacity,
+                           char* errbuf, size_t errcap);
 int  vxh_plan_tiles_buffer(const char* xml, size_t len, int variant, int k_request, vxh_tiling_info* out, int* tile_of_out, int capacity,
                            char* errbuf, size_t errcap);
 
@@ -200,6 +218,9 @@ int  vxh_set_option(vxh_engine* e, const char* key, double value);
 const char* vxh_strerror(int status);
 const char* vxh_last_error(const vxh_engine* e);
 const char* vxh_version(void);
+/* HIP devices this process can use (0 without a GPU): what a one-process-per-GPU launcher takes LOCAL_RANK modulo
+ * (evosoro_amd/parallel.py), independent of whether the caller's torch build sees the GPUs */
+int  vxh_device_count(void);
 
 #ifdef __cplusplus
 }

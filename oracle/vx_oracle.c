@@ -920,6 +920,24 @@ void vxo_get_bond_table(const vxo_sim* s, int* v1, int* v2, int* axis)
     for (int i = 0; i < s->nbond; i++) { v1[i] = s->bond[i].v1; v2[i] = s->bond[i].v2; axis[i] = s->bond[i].axis; }
 }
 
+/* the constants Import leaves on every voxel (SetMaterial, VX_Voxel.cpp:94-128) and bond (UpdateConstants, VX_Bond.cpp:95-173), for the
+ * bit-for-bit comparison with the product's host model (tests/test_capi.py): 12 doubles per voxel, 23 per bond */
+void vxo_get_constants(const vxo_sim* s, double* vox12n, double* bond23n)
+{
+    for (int i = 0; i < s->nvox; i++) {
+        const voxel* v = &s->vox[i]; double* o = vox12n + 12 * i;
+        o[0] = v->mass; o[1] = v->mass_inv; o[2] = v->inertia; o[3] = v->inertia_inv; o[4] = v->first_moment; o[5] = v->c_lin; o[6] = v->c_ang;
+        o[7] = v->E; o[8] = v->nom_size; o[9] = v->u_static; o[10] = v->u_dynamic; o[11] = v->cte;
+    }
+    for (int i = 0; i < s->nbond; i++) {
+        const ibond* b = &s->bond[i]; double* o = bond23n + 23 * i;
+        o[0] = b->v1; o[1] = b->v2; o[2] = b->axis - 1; o[3] = b->homogeneous; o[4] = b->L; o[5] = b->a1; o[6] = b->a2;
+        o[7] = b->b1y; o[8] = b->b2y; o[9] = b->b3y; o[10] = b->b1z; o[11] = b->b2z; o[12] = b->b3z;
+        o[13] = b->sq_a1m1; o[14] = b->sq_a1m2; o[15] = b->sq_a2i1; o[16] = b->sq_a2i2;
+        o[17] = b->sq_b1ym1; o[18] = b->sq_b1ym2; o[19] = b->sq_b2yfm1; o[20] = b->sq_b2yfm2; o[21] = b->sq_b3yi1; o[22] = b->sq_b3yi2;
+    }
+}
+
 int vxo_get_cm_trace(const vxo_sim* s, double* out4n, int capacity)
 {
     for (int i = 0; i < s->ntrace && i < capacity; i++) memcpy(out4n + 4 * i, s->trace + 4 * i, 4 * sizeof(double));

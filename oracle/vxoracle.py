@@ -93,6 +93,7 @@ def lib():
         _lib.vxo_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(VxoInfo)]
         _lib.vxo_get_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_bond_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.vxo_get_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_result.argtypes = [ctypes.c_void_p, ctypes.POINTER(VxoResult)]
         _lib.vxo_get_cm_trace.restype = ctypes.c_int
         _lib.vxo_get_cm_trace.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
@@ -316,6 +317,13 @@ class OracleSim(object):
         v1, v2, ax = (np.zeros(n, dtype=np.int32) for _ in range(3))
         lib().vxo_get_bond_table(self._h, v1.ctypes.data, v2.ctypes.data, ax.ctypes.data)
         return v1, v2, ax
+
+    def constants(self):
+        """([nvox, 12], [nbond, 23]): the constants Import leaves on voxels and bonds (vx_oracle.c vxo_get_constants)"""
+        info = self.info()
+        vox, bond = np.zeros((info.nvox, 12)), np.zeros((max(info.nbond, 1), 23))
+        lib().vxo_get_constants(self._h, vox.ctypes.data, bond.ctypes.data)
+        return vox, bond[:info.nbond]
 
     def result(self):
         out = VxoResult()

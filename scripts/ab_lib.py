@@ -8,5 +8,5 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, ".."))
 from evosoro_amd import engine
 engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), sys.argv[1])
-sys.argv = ["dev_gpu_diag.py", sys.argv[2]]
+sys.argv = ["dev_gpu_diag.py"] + sys.argv[2:]
 runpy.run_path(os.path.join(HERE, "dev_gpu_diag.py"), run_name="__main__")

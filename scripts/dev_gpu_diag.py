@@ -528,7 +528,7 @@ if __name__ == "__main__" and "launchcost" in sys.argv[1:]:
 
 if __name__ == "__main__" and "proepi" in sys.argv[1:]:
     # developer library: cycles a wavefront of the resident kernel spends before the step loop and after it, per launch, colliding vs not
-    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), os.environ.get("VXH_PROF_LIB", "libvxhip_prof.so"))
     tmp = tempfile.mkdtemp()
     os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
     for col in (True, False):
@@ -606,3 +606,33 @@ if __name__ == "__main__" and "smallphases" in sys.argv[1:]:
     timing_cfg(engine.VOXCAD, 64, (8, 8, 8), 0.05, Env(), {}, phases=ph)
     print("64 x 10^3 walkers", flush=True)
     timing_cfg(engine.VOXCAD, 64, (10, 10, 10), 0.03, Env(), {}, phases=ph)
+
+
+if __name__ == "__main__" and "lc2" in sys.argv[1:]:
+    # round 3: the bench population (512 random 10^3 robots) with self-collision in launches of 250 and of 20 steps (fixed cost of a
+    # launch from the two), and without self-collision (the step alone).  Run through scripts/ab_lib.py to compare two libraries.
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    for col in ((True,) if "colonly" in sys.argv[1:] else (True, False)):
+        sim = Sim(self_collisions_enabled=col, dt_frac=0.9, simulation_time=2.0, fitness_eval_init_time=0.4)
+        paths = []
+        for ind in workloads.population(512, (10, 10, 10)):
+            write_voxelyze_file(sim, Env(), ind, tmp, "c%d" % col)
+            paths.append(os.path.join(tmp, "voxelyzeFiles", "c%d--id_%05i.vxa" % (col, ind.id)))
+        rows = []
+        for L in ((250, 20) if col else (250,)):
+            with engine.Engine(engine.VOXCAD, 0) as eng:
+                eng.set_option("tiled", 0)
+                eng.set_option("steps_per_launch", L)
+                eng.add_vxa_files(paths)
+                eng.step(900)
+                c0 = eng.counters()
+                eng.step(1000)
+                c1 = eng.counters()
+                ks, nl = c1.kernel_seconds - c0.kernel_seconds, c1.launches - c0.launches
+                rows.append((L, nl, ks))
+                print("%s col=%d  %3d steps per launch: %4d launches, %.2f us per step" % (os.path.basename(engine.LIB_PATH), col, L, nl, 1e3 * ks), flush=True)
+        if col:
+            (La, na, ka), (Lb, nb, kb) = rows
+            fixed = (kb - ka) / (nb - na)
+            print("%s col=1  -> fixed cost per launch %.0f us, per step without it %.2f us" % (os.path.basename(engine.LIB_PATH), 1e6 * fixed, 1e6 * (ka - na * fixed) / 1000), flush=True)

@@ -25,9 +25,61 @@ class _Result(object):
         self.hull_volume_start = self.hull_volume_end = -1.0
 
 
+class _Counters(object):
+    """the fields of vxh_counters that bench.py reads"""
+    def __init__(self):
+        self.voxel_steps = self.kernel_seconds = self.dominant_seconds = self.dominant_alg_bytes = self.dominant_voxel_steps = 0.0
+        self.launches = self.dominant_launches = self.dominant_block = 0
+
+
+_real = None          # the real evosoro_amd.engine, for its host-only calls (bench_stub_runner.py sets it before putting this module in its place)
+
+
+def inspect_vxa(path, variant=VOXCAD):
+    global _real
+    if _real is None:
+        from evosoro_amd import engine as _real_engine
+        _real = _real_engine
+    return _real.inspect_vxa(path, variant)
+
+
 class Engine(object):
     def __init__(self, variant=VOXCAD, device=0):
-        self.variant, self.models, self.sims = variant, [], []
+        self.variant, self.models, self.sims, self.paths = variant, [], [], []
+        self._c = _Counters()
+
+    def add_vxa_files(self, paths):
+        first = len(self.sims)
+        for p in paths:
+            self.add_vxa_file(p)
+        return first
+
+    def dims(self, i):
+        d = inspect_vxa(self.paths[i], self.variant)
+        return {"nvox": d.nvox, "nbond": d.nbond, "dt": d.dt, "planned_steps": d.planned_steps}
+
+    def step(self, n):
+        import time
+        t0 = time.perf_counter()
+        for sim in self.sims:
+            before = sim.info().steps
+            sim.step(n)
+            info = sim.info()
+            self._c.voxel_steps += float(info.nvox) * (info.steps - before)
+            self._c.dominant_alg_bytes += (224.0 * info.nvox + 144.0 * info.nbond) * (info.steps - before)
+        self._c.dominant_voxel_steps = self._c.voxel_steps
+        self._c.kernel_seconds += time.perf_counter() - t0
+        self._c.dominant_seconds = self._c.kernel_seconds
+        self._c.launches += 1
+        self._c.dominant_launches = 1
+
+    def counters(self):
+        import copy
+        return copy.copy(self._c)
+
+    def bond_modes(self):
+        total = sum(sim.info().nbond for sim in self.sims)
+        return total - sum(sim.info().n_small_angle for sim in self.sims), total
 
     def __enter__(self):
         return self
@@ -44,6 +96,7 @@ class Engine(object):
     def add_vxa_file(self, path):
         self.models.append(vo.parse_vxa(path, self.variant))
         self.sims.append(vo.OracleSim(self.models[-1]))
+        self.paths.append(path)
         return len(self.sims) - 1
 
     def add_robots(self, template_text, robots, round_like_text=True):
@@ -92,5 +145,3 @@ class Engine(object):
                 f.write("        <%s>%g</%s>\n" % (tag, getattr(res, field), tag))
             f.write("    </Fitness>\n</Voxelyze_Sim_Result>\n")
 
-    def counters(self):
-        return None

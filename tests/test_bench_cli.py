@@ -1,0 +1,63 @@
+"""bench.py's command line: `--gpus N` must either run N ranks or fail loudly -- never print a one-GPU number under an N-GPU label."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "6", "--warmup", "2", "--robots-per-gpu", "3", "--lattice", "4", "--no-cpu-baseline", "--no-other-configs"]
+
+
+def _run(cmd, env_extra, timeout=600):
+    env = dict(os.environ, PYTHONPATH=REPO, **env_extra)
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(key, None)
+    return subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
+def _line(proc):
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (proc.stdout.decode()[-2000:], proc.stderr.decode()[-3000:])
+    return json.loads(lines[0])
+
+
+def test_gpus_2_without_a_launcher_starts_two_ranks_on_the_stub():
+    """plain `python bench.py --gpus 2`: bench.py re-launches itself under torch.distributed.run (here: the stub wrapper, gloo,
+    every rank on 'device 0') and the line says n_gpus 2, with the strong run and the one-handle route beside the weak one"""
+    proc = _run([sys.executable, os.path.join(REPO, "tests", "bench_stub_runner.py"), "--gpus", "2"] + SMALL,
+                {"VXH_BENCH_SHARE_GPU": "1"})
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    out = _line(proc)
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak"
+    assert out["config"]["robots_per_gpu"] == 3 and out["value"] > 0
+    assert out["strong"]["scaling"] == "strong" and out["strong"]["value"] > 0
+    assert out["multi_handle"]["robots"] == 6 and out["multi_handle"]["value"] > 0
+
+
+def test_gpus_more_than_visible_fails_loudly():
+    proc = _run([sys.executable, os.path.join(REPO, "tests", "bench_stub_runner.py"), "--gpus", "4"] + SMALL, {"VXH_STUB_GPUS": "1"})
+    assert proc.returncode != 0
+    assert "--gpus 4 but 1 GPU(s) visible" in proc.stderr.decode()
+    assert not [ln for ln in proc.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_world_size_mismatch_fails_loudly():
+    proc = _run([sys.executable, os.path.join(REPO, "tests", "bench_stub_runner.py"), "--gpus", "1"] + SMALL, {})
+    assert proc.returncode == 0 and _line(proc)["n_gpus"] == 1
+    env = dict(os.environ, PYTHONPATH=REPO, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "tests", "bench_stub_runner.py"), "--gpus", "1"] + SMALL, env=env, cwd=REPO,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert proc.returncode != 0 and "WORLD_SIZE 2" in proc.stderr.decode()
+
+
+@pytest.mark.gpu
+def test_gpus_2_on_one_device_with_the_real_engine():
+    """the same on the GPU box: two ranks sharing device 0 (gloo), the real library"""
+    proc = _run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--robots-per-gpu", "16",
+                 "--lattice", "6", "--no-cpu-baseline", "--no-other-configs"], {"VXH_BENCH_SHARE_GPU": "1"})
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    out = _line(proc)
+    assert out["n_gpus"] == 2 and out["config"]["robots_per_gpu"] == 16 and out["value"] > 0
+    assert out["strong"]["value"] > 0 and out["multi_handle"]["robots"] == 32

@@ -69,6 +69,21 @@ def test_host_model_matches_oracle_and_reference(golden_dir, name):
     assert info.alg_bytes_per_step == 224.0 * info.nvox + 144.0 * info.nbond
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_import_constants_equal_the_oracles_bit_for_bit(golden_dir, name):
+    """every constant the import leaves on a voxel (SetMaterial) and on a bond (UpdateConstants:
+    stiffnesses a1 a2 b1 b2 b3 and the 2 sqrt(k m) damping terms), compared with the oracle's -- which is pinned on the reference --
+    as bit patterns, bond by bond in the reference's creation order.  (The kernels read per-class tables derived from these.)"""
+    import numpy as np
+    path = os.path.join(golden_dir, "vxa", name + ".vxa")
+    variant = 1 if name.startswith("lw_") else 0
+    vox, bond = engine.inspect_constants(path, variant)
+    ovox, obond = vo.OracleSim.from_vxa(path, variant).constants()
+    assert vox.shape == ovox.shape and bond.shape == obond.shape
+    assert np.array_equal(vox.view(np.int64), ovox.view(np.int64)), np.argwhere(vox != ovox)[:5]
+    assert np.array_equal(bond.view(np.int64), obond.view(np.int64)), np.argwhere(bond != obond)[:5]
+
+
 def test_reader_rejects_bad_input():
     with pytest.raises(engine.VxhError) as err:
         engine.inspect_vxa("<VXA><Simulator></Simulator>")
@@ -113,7 +128,7 @@ def test_every_engine_option_is_documented_in_the_header():
     import re
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     src = open(os.path.join(root, "evosoro_amd", "csrc", "engine.hip")).read()
-    body = src[src.index("void Engine::set_option("):]
+    body = src[src.index("void Engine::check_option("):]          # (set_option validates through it: every key appears there)
     body = body[:body.index("\n}\n")]
     keys = set(re.findall(r'key == "([a-z_]+)"', body))
     assert {"tiled", "tile_small", "steps_per_launch", "fused"} <= keys          # (the parse found the function)
