@@ -157,6 +157,7 @@ struct DBatch {
     double* bout;
     // collisions
     const int* surf;                  // global voxel slots of surface voxels, per robot contiguous
+    const int* surf_code;             // same shape as surf: robot-local voxel index | voxel class << 10 (what the broad-phase stages per ordinal)
     const int* surf_ord;              // [nv] ordinal in the robot's surface list or -1
     const unsigned long long* excl;   // CalcNearby exclusion as bit rows: per robot nsurf rows of excl_wpr 64-bit words,
                                       // bit j of row i set when surface voxels i and j are within the hop horizon

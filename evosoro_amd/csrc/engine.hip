@@ -534,7 +534,7 @@ void Engine::prepare()
         }
     }
 
-    std::vector<int> wave_robot(nv / 64, -1), nbr((size_t)6 * nv, -1), surf(std::max(ns, 1), 0), surf_ord(nv, -1);
+    std::vector<int> wave_robot(nv / 64, -1), nbr((size_t)6 * nv, -1), surf(std::max(ns, 1), 0), surf_code(std::max(ns, 1), 0), surf_ord(nv, -1);
     std::vector<unsigned long long> excl;
     std::vector<unsigned short> vclass(nv, 0);
     std::vector<short> bclass((size_t)3 * nv, -1);
@@ -668,7 +668,10 @@ void Engine::prepare()
             R.wnbond = M.nbond; R.wzidx = W.zidx; R.wregion = W.region;
         }
         if (X.self_col_enabled)
-            for (int i = 0; i < M.nsurf; ++i) { surf[D.surf_begin[r] + i] = base + M.surf[i]; surf_ord[base + M.surf[i]] = i; }
+            for (int i = 0; i < M.nsurf; ++i) {
+                surf[D.surf_begin[r] + i] = base + M.surf[i]; surf_ord[base + M.surf[i]] = i;
+                surf_code[D.surf_begin[r] + i] = (int)((unsigned)M.surf[i] | ((unsigned)M.vox_class[M.surf[i]] << 10));     // (robots the resident kernels take: < 1024 voxels)
+            }
         // CalcNearby exclusion lists as bit rows over surface ordinals
         const long long excl_begin = excl_off[r];
         int wpr = 0;
@@ -781,6 +784,7 @@ void Engine::prepare()
     B.small_angle = D.upload(small);
     B.bout = D.alloc_zero<double>((size_t)12 * 3 * nv);
     B.surf = D.upload(surf);
+    B.surf_code = D.upload(surf_code);
     B.surf_ord = D.upload(surf_ord);
     B.excl = D.upload(excl);
     B.total_mv = std::max(total_mv, 1);

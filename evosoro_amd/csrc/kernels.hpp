@@ -198,6 +198,31 @@ __device__ __forceinline__ double wave_max_nonneg(double v)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// min / max of any doubles over the 64 lanes of a (fully active) wavefront, returned in every lane (a lane without a source keeps its
+// own value, so no sign convention is needed)
+template <int CTRL, int ROW_MASK, bool MAX>
+__device__ __forceinline__ double dpp_minmax_stage(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    const double o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    return MAX ? (o > v ? o : v) : (o < v ? o : v);
+}
+template <bool MAX>
+__device__ __forceinline__ double wave_minmax(double v)
+{
+    v = dpp_minmax_stage<0x111, 0xf, MAX>(v);
+    v = dpp_minmax_stage<0x112, 0xf, MAX>(v);
+    v = dpp_minmax_stage<0x114, 0xf, MAX>(v);
+    v = dpp_minmax_stage<0x118, 0xf, MAX>(v);
+    v = dpp_minmax_stage<0x142, 0xa, MAX>(v);
+    v = dpp_minmax_stage<0x143, 0xc, MAX>(v);
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 #define VXH_PI 3.14159265358979
 #define VXH_DISCARD_ANGLE_RAD 1e-7
 #define VXH_SMALL_ANGLE_RAD 1.732e-2
@@ -229,9 +254,17 @@ __device__ __forceinline__ dq from_angle_to_pos_x(d3 from)
     return mkq(c, 0, n.z * h, -n.y * h);
 }
 // CQuat::ToRotationVector, Vec3D.h:270-285
+// 1 - w * w with the product rounded on its own, as the reference's FMA-less build forms it.  For a small rotation (w within 1e-4
+// of 1) the rounding of w * w is a relative error of 1e-12 in the difference; contracted into one fused multiply-add the engine's
+// value was the more accurate one -- and 1e-12 away from the reference's, which showed as a jump of the error against the oracle
+// from 1e-14 to 6e-12 (relative, angular velocity) on the step the first bonds of a violently starting robot turn large-angle
+// (tests/golden/vxa/lw_hexapus.vxa, step 4; scripts/dev_gpu_diag.py drift3, round 3).
+#pragma clang fp contract(off)
+__device__ __forceinline__ double one_minus_square(double w) { const double ww = w * w; return 1.0 - ww; }
+#pragma clang fp contract(fast)
 __device__ __forceinline__ d3 to_rotvec(dq q, double slthresh)
 {
-    double sl = 1.0 - q.w * q.w;
+    double sl = one_minus_square(q.w);
     if (sl <= 0) return mk3(0, 0, 0);
     double wc = q.w > 1 ? 1 : q.w;
     // sqrt((2 - 2w) / sl) = (2 - 2w) * rsqrt((2 - 2w) * sl)  and  acos(w) / sqrt(sl) = acos(w) * rsqrt(sl): one refined v_rsq_f64

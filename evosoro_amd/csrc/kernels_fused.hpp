@@ -112,10 +112,7 @@ __device__ __forceinline__ void fused_rebuild_plain(const DBatch& B, const DRobo
 #ifdef VXH_PHASE_TIMING
     unsigned long long t_rb = __builtin_readcyclecounter();
 #endif
-    for (int k = tid; k < ns; k += BLOCK) {      // local voxel index | class of every surface voxel
-        const int g = B.surf[R.surf_begin + k];
-        shi[k] = (g - R.vox_begin) | ((int)B.vclass[g] << 10);
-    }
+    for (int k = tid; k < ns; k += BLOCK) shi[k] = B.surf_code[R.surf_begin + k];      // local voxel index | class of every surface voxel
     __syncthreads();
     VXH_RB_MARK(2100)
     if (tid < ns) {
@@ -252,51 +249,102 @@ __device__ __forceinline__ unsigned writelane_u32(unsigned old, unsigned sval, i
 // CalcL1Bonds (VX_Sim.cpp:2357-2413) as a BIT MATRIX built from 64 x 64 blocks of surface-voxel pairs, every unordered pair tested
 // once.  The plain scan above lets thread i walk all ns candidates (ns^2 tests, wavefront w busy for as long as its rows need, the
 // SIMD with three wavefronts three times as long as the one with two); here
-//   1. positions are staged by surface ordinal (`stg`: x y z planes of NS = 64 * nb doubles; slots past ns hold +infinity-like
-//      values that fail every test), so a candidate's address is uniform -- a broadcast LDS read, no index indirection;
-//   2. the nb (nb + 1) / 2 block pairs (I <= J) are dealt round-robin to the wavefronts.  In a pair lane l holds row i = 64 I + l
-//      and walks the 64 candidates j = 64 J + u: d2 < thr_i with thr_i = min(FilterDist^2, ActDist_i^2) -- the reference's two
-//      tests `Dist2 < FilterDist2` and `Dist2 < ActDist * ActDist` (:2378-2383) are both `d2 <`, so one compare against the smaller
-//      bound decides both, exactly; ActDist uses the scale of the EARLIER voxel (:2382), which is the row's in every pair with
-//      I < J and in the upper triangle of a diagonal block.  The compare's lane mask IS row j's word for block I (the test is
-//      symmetric in everything but that scale, and the earlier voxel is the same seen from either side): it is kept by lane u
-//      (v_writelane); the lane's own bit is shifted into row i's word for block J with one add-with-carry;
-//   3. both go to the matrix `mat` [nb][NS] (word-major: conflict-free), one writer per word; a diagonal block contributes the
-//      upper triangle of the rows' own words and the lower triangle of the masks;
-//   4. after a barrier thread i walks its row's nb words in ascending order -- the creation order of the reference's collision bonds,
-//      hence the order CalcContactForce sums them in -- drops the pairs within the hop horizon (`excl` bit rows = !IsNearbyVox, :2380)
-//      and writes partner and pair stiffness of the rest.
+//   1. positions are staged by surface ordinal (`stg`: x y z planes of NS = 64 * nb doubles; slots past ns hold far-away values that
+//      fail every test), so a candidate's address is uniform -- a broadcast LDS read, no index indirection; the wavefront that
+//      stages block b also reduces its bounding box and the largest acceptance radius of its rows;
+//   2. the nb (nb + 1) / 2 block pairs (I <= J) are handed out through a counter in LDS (whoever is free takes the next one).  A pair
+//      whose bounding boxes are farther apart than any row of I accepts is answered with zeros (exact: a pair's distance is at
+//      least the gap between the boxes; a margin of 1e-12 covers the roundings of the two expressions).  Else lane l holds row
+//      i = 64 I + l and walks the 64 candidates j = 64 J + u: d2 < thr_i with thr_i = min(FilterDist^2, ActDist_i^2) -- the
+//      reference's two tests `Dist2 < FilterDist2` and `Dist2 < ActDist * ActDist` (:2378-2383) are both `d2 <`, so one compare
+//      against the smaller bound decides both, exactly; ActDist uses the scale of the EARLIER voxel (:2382), which is the row's in
+//      every pair with I < J and in the upper triangle of a diagonal block.  The compare's lane mask IS row j's word for block I
+//      (the test is symmetric in everything but that scale, and the earlier voxel is the same seen from either side): lane u keeps
+//      it; the lane's own bit goes into row i's word for block J;
+//   3. both words lose the pairs within the hop horizon (`excl` bit rows = !IsNearbyVox, :2380; loaded when the pair starts, used
+//      when it ends) and go to the matrix `mat` [nb][NS] (word-major: conflict-free), one writer per word; a diagonal block
+//      contributes the upper triangle of the rows' own words and the lower triangle of the masks;
+//   4. after a barrier thread i walks its row's nb words in ascending order -- the creation order of the reference's collision
+//      bonds, hence the order CalcContactForce sums them in -- and writes partner and pair stiffness.
 // Same arithmetic per pair as the plain scan, hence the same rows (developer build, what-if switch 16: both run, rows compared).
-// Measured: DESIGN.md "Broad-phase".  `mat`: nb * NS words; `stg`: 3 * NS doubles.
+// Measured: DESIGN.md "Broad-phase".  `mat`: nb * NS words; `stg`: fused_sym_stage_doubles(nb) doubles (positions, boxes, the pair
+// counter, and per ordinal the local voxel index | class << 10 that step 4 turns bits into partners with).
+enum { VXH_A1TAB_CLASSES = 8 };     // robots of up to this many voxel classes: pair stiffnesses from a table built once per run
+__device__ __forceinline__ int fused_sym_stage_doubles(int nb) { return 3 * (nb << 6) + 8 * nb + 2 + (nb << 5) + VXH_A1TAB_CLASSES * VXH_A1TAB_CLASSES; }
+
 template <int BLOCK>
 __device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, unsigned long long* mat,
                                                   double* stg, const DVoxClass* vct)
 {
     const int tid = opaque_tid<BLOCK>(), ns = R.nsurf;
     const int nb = (ns + 63) >> 6, NS = nb << 6;
-    const int lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = BLOCK / 64;
+    const int lane = tid & 63;
+    double* const box = stg + 3 * NS;                          // per block: min x y z, max x y z, largest thr of its rows, -
+    int* const next_pair = (int*)(box + 8 * nb);
+    int* const shi = next_pair + 4;                            // [NS] local voxel index | class << 10 of every surface voxel
+    double* const a1tab = box + 8 * nb + 2 + (nb << 5);        // [nvc][nvc] contact_a1(class of the earlier voxel, class of the later one)
+    const int nvc = R.n_vclass;
+    const bool tab = nvc <= VXH_A1TAB_CLASSES;
+    if (tab && tid < nvc * nvc) a1tab[tid] = contact_a1(vct[tid / nvc], vct[tid % nvc]);
+    const double H = R.col_horizon, filter2 = R.filter_dist2;
 #ifdef VXH_PHASE_TIMING
     unsigned long long t_rb = __builtin_readcyclecounter();
 #endif
-    for (int k = tid; k < NS; k += BLOCK) {
-        double x = 1.0e150, y = 1.0e150, z = 1.0e150;          // (a slot past the list: farther than any bound from every voxel; rows past the list accept nothing, thr < 0)
-        if (k < ns) { const int l = B.surf[R.surf_begin + k] - R.vox_begin; x = ps[l]; y = ps[BLOCK + l]; z = ps[2 * BLOCK + l]; }
-        stg[k] = x; stg[NS + k] = y; stg[2 * NS + k] = z;
+    if (tid == 0) *next_pair = 0;
+    if (tid < NS) {                                            // (NS <= BLOCK: one slot per thread, wavefront b stages block b)
+        const int k = tid;
+        double x = 1.0e150, y = 1.0e150, z = 1.0e150, thr = -1.0;   // a slot past the list: farther than any bound from every voxel; accepts nothing
+        int code = 0;
+        if (k < ns) {
+            code = B.surf_code[R.surf_begin + k];
+            const int l = code & 1023;
+            x = ps[l]; y = ps[BLOCK + l]; z = ps[2 * BLOCK + l];
+            const double sk = ps[3 * BLOCK + l];
+            const double act = H * (sk + sk) * 0.5, act2 = act * act;
+            thr = act2 < filter2 ? act2 : filter2;
+        }
+        stg[k] = x; stg[NS + k] = y; stg[2 * NS + k] = z; shi[k] = code;
+        const bool real = k < ns;
+        const double lox = wave_minmax<false>(real ? x : 1.0e300), loy = wave_minmax<false>(real ? y : 1.0e300), loz = wave_minmax<false>(real ? z : 1.0e300);
+        const double hix = wave_minmax<true>(real ? x : -1.0e300), hiy = wave_minmax<true>(real ? y : -1.0e300), hiz = wave_minmax<true>(real ? z : -1.0e300);
+        const double tmax = wave_minmax<true>(thr);
+        if (lane == 0) { double* e = box + 8 * (tid >> 6); e[0] = lox; e[1] = loy; e[2] = loz; e[3] = hix; e[4] = hiy; e[5] = hiz; e[6] = tmax; }
     }
     __syncthreads();
     VXH_RB_MARK(2100)      // staging
-    const double H = R.col_horizon, filter2 = R.filter_dist2;
     const int npairs = nb * (nb + 1) / 2;
-    for (int p = wave; p < npairs; p += NW) {
+    for (;;) {
+        int p = 0;
+        if (lane == 0) p = atomicAdd(next_pair, 1);
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (p >= npairs) break;
         int I = 0, rem = p;
         while (rem >= nb - I) { rem -= nb - I; ++I; }
         const int J = I + rem;
-        const int i = (I << 6) + lane;
+        const int i = (I << 6) + lane, jrow = (J << 6) + lane;
+        // exclusion words of my two rows for this pair: requested now, needed after the candidate loop
+        unsigned long long e_own = ~0ull, e_col = ~0ull;
+        if (i < ns) e_own = B.excl[R.excl_begin + (long long)i * R.excl_wpr + J];
+        if (jrow < ns) e_col = B.excl[R.excl_begin + (long long)jrow * R.excl_wpr + I];
+        if (I != J) {
+            const double* bi = box + 8 * I; const double* bj = box + 8 * J;
+            double gap2 = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double g1 = bi[a] - bj[3 + a], g2 = bj[a] - bi[3 + a];
+                const double g = g1 > g2 ? g1 : g2;
+                if (g > 0) gap2 += g * g;
+            }
+            if (gap2 > bi[6] * (1.0 + 1.0e-12)) {              // no row of I reaches any voxel of J
+                mat[(size_t)J * NS + i] = 0ull;
+                mat[(size_t)I * NS + jrow] = 0ull;
+                continue;
+            }
+        }
         const d3 pi = mk3(stg[i], stg[NS + i], stg[2 * NS + i]);
         double thr = -1.0;                                      // (rows past the list accept nothing)
         if (i < ns) {
-            const double si = ps[3 * BLOCK + (B.surf[R.surf_begin + i] - R.vox_begin)];
+            const double si = ps[3 * BLOCK + (shi[i] & 1023)];
             const double act = H * (si + si) * 0.5;             // the row is Vox1 = the earlier voxel of every pair this block pair keeps
             const double act2 = act * act;
             thr = act2 < filter2 ? act2 : filter2;
@@ -321,14 +369,13 @@ __device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot&
             }
             own_w[half] = own;
         }
-        const unsigned own_lo = own_w[0], own_hi = own_w[1];
-        const unsigned long long own = ((unsigned long long)own_hi << 32) | own_lo, col = ((unsigned long long)col_hi << 32) | col_lo;
+        const unsigned long long own = ((unsigned long long)own_w[1] << 32) | own_w[0], col = ((unsigned long long)col_hi << 32) | col_lo;
         if (I == J) {
             const unsigned long long below = (1ull << lane) - 1ull;          // partners before me / after me inside the block
-            mat[(size_t)I * NS + i] = (own & ~(below | (1ull << lane))) | (col & below);
+            mat[(size_t)I * NS + i] = ((own & ~(below | (1ull << lane))) | (col & below)) & ~e_own;
         } else {
-            mat[(size_t)J * NS + i] = own;                                   // row i, partners of block J
-            mat[(size_t)I * NS + (J << 6) + lane] = col;                     // row 64 J + lane, partners of block I
+            mat[(size_t)J * NS + i] = own & ~e_own;                          // row i, partners of block J
+            mat[(size_t)I * NS + jrow] = col & ~e_col;                       // row 64 J + lane, partners of block I
         }
     }
     VXH_RB_MARK(2101)      // wave 0's block pairs
@@ -336,22 +383,23 @@ __device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot&
     VXH_RB_MARK(2102)      // waiting for the slowest wavefront
     if (tid < ns) {
         const int i = tid;
-        const int gi = B.surf[R.surf_begin + i];
-        const DVoxClass& Ci = vct[B.vclass[gi]];
-        const unsigned long long* row = B.excl + R.excl_begin + (long long)i * R.excl_wpr;
+        const int ci = shi[i] >> 10;
+        const DVoxClass& Ci = vct[ci];
         int cnt = 0;
         for (int w = 0; w < nb; ++w) {
-            unsigned long long word = mat[(size_t)w * NS + i] & ~row[w];     // !pV1->IsNearbyVox(SIndex2)
+            unsigned long long word = mat[(size_t)w * NS + i];
             while (word) {
                 const int u = __builtin_ctzll(word);
                 word &= word - 1;
                 const int j = (w << 6) + u;
                 if (cnt < R.col_cap) {
-                    const int gj = B.surf[R.surf_begin + j];
-                    const DVoxClass& Cj = vct[B.vclass[gj]];
+                    const int other = shi[j], cj = other >> 10;
                     const size_t at = col_at(R, cnt, R.surf_begin + i);
-                    B.col_partner[at] = gj;
-                    B.col_a1[at] = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci);
+                    B.col_partner[at] = R.vox_begin + (other & 1023);
+                    double a1;
+                    if (tab) a1 = (j > i) ? a1tab[ci * nvc + cj] : a1tab[cj * nvc + ci];       // (the same function of the same two classes: the same bits)
+                    else { const DVoxClass& Cj = vct[cj]; a1 = (j > i) ? contact_a1(Ci, Cj) : contact_a1(Cj, Ci); }
+                    B.col_a1[at] = a1;
                 }
                 ++cnt;
             }
@@ -364,7 +412,7 @@ __device__ __forceinline__ void fused_rebuild_sym(const DBatch& B, const DRobot&
 }
 
 // The broad-phase of a resident robot: the bit-matrix scan when its matrix (nb * NS words) fits the scratch tile and the staged
-// positions (3 * NS doubles) fit behind it or in the contact-row pool (`pool`, dead during a run: rows_to_lds refills it afterwards);
+// positions (fused_sym_stage_doubles) fit behind it or in the contact-row pool (`pool`, dead during a run: rows_to_lds refills it afterwards);
 // else the staged / plain scans.  `scratch` is left dirty: the caller re-zeroes what it needs zero.
 template <int BLOCK>
 __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, DRobotState& rs, const double* ps, double* scratch, int scratch_doubles,
@@ -376,7 +424,7 @@ __device__ __forceinline__ void fused_rebuild(const DBatch& B, const DRobot& R, 
         fused_rebuild_staged<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
     } else {
         const int nb = (R.nsurf + 63) >> 6, NS = nb << 6;
-        const int need_mat = nb * NS, need_stg = 3 * NS;
+        const int need_mat = nb * NS, need_stg = fused_sym_stage_doubles(nb);
 #ifdef VXH_NO_SYM          // (developer what-if: the scan of round 2)
         if (true) fused_rebuild_plain<BLOCK>(B, R, rs, ps, (int*)scratch, vct);
         else
@@ -882,10 +930,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         rowd = ccnt;
         if (fits && ccnt_l > 0) {
             rowd = ccnt | ((off + 1) << VXH_ROWD_BITS);
-            for (int k = 0; k < ccnt; ++k) {
-                const size_t at = col_at(R, k, row);
-                rc_code[off + k] = (B.col_partner[at] - base) | (tid_r << 10) | (k << 20);
-                rc_a1[off + k] = B.col_a1[at];
+            for (int k0 = 0; k0 < ccnt; k0 += 4) {           // (four entries' loads in flight: a row of 16 costs four round trips, not sixteen)
+                int pj[4]; double aj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const size_t at = col_at(R, min(k0 + j, ccnt - 1), row); pj[j] = B.col_partner[at]; aj[j] = B.col_a1[at]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j < ccnt) { rc_code[off + k0 + j] = (pj[j] - base) | (tid_r << 10) | ((k0 + j) << 20); rc_a1[off + k0 + j] = aj[j]; }
             }
         }
         __syncthreads();

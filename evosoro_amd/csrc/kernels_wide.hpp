@@ -191,10 +191,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
         rowd = ccnt;
         if (fits && ccnt_l > 0) {
             rowd = ccnt | ((off + 1) << VXH_ROWD_BITS);
-            for (int k = 0; k < ccnt; ++k) {
-                const size_t at = col_at(R, k, row);
-                rc_code[off + k] = (B.col_partner[at] - base) | (tid_r << 10) | (k << 20);
-                rc_a1[off + k] = B.col_a1[at];
+            for (int k0 = 0; k0 < ccnt; k0 += 4) {           // (four entries' loads in flight)
+                int pj[4]; double aj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const size_t at = col_at(R, min(k0 + j, ccnt - 1), row); pj[j] = B.col_partner[at]; aj[j] = B.col_a1[at]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j < ccnt) { rc_code[off + k0 + j] = (pj[j] - base) | (tid_r << 10) | ((k0 + j) << 20); rc_a1[off + k0 + j] = aj[j]; }
             }
         }
         __syncthreads();

@@ -108,6 +108,21 @@ def probe_material():
     return mat
 
 
+def folded_material(plates=4, side=10):
+    """A sheet folded back and forth: `plates` full side x side layers at z = 0, 2, 4, ..., joined along alternating edges -- so that a
+    voxel has dozens of others a gap away in space but many bonds away along the sheet, i.e. long collision lists
+    (CalcL1Bonds pairs what is within CollisionHorizon voxel sizes and more than 1.5 x CollisionHorizon bonds away, VX_Sim.cpp:2357-2413):
+    with <CollisionHorizon> 5 the rows of the inner plates hold well over 64 partners.  Muscle plates (materials 3 / 4 in stripes: they
+    actuate in antiphase, the sheet flaps and the plates touch), soft joints."""
+    mat = np.zeros((side, side, 2 * plates - 1), dtype=np.int64)
+    for k in range(plates):
+        mat[:, :, 2 * k] = 3
+        mat[::2, :, 2 * k] = 4
+        if k + 1 < plates:
+            mat[0 if k % 2 == 0 else side - 1, :, 2 * k + 1] = 1
+    return mat
+
+
 def full_material(n, seed=1):
     """Full n^3 lattice with materials {1..4} (the 'large' config uses n=20)."""
     return np.random.RandomState(seed).randint(1, 5, size=(n, n, n)).astype(np.int64)

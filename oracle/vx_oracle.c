@@ -83,6 +83,16 @@ static qt q_from_angle_to_pos_x(v3 from)                                        
     v3 n = from;
     double l = sqrt(n.x * n.x + n.y * n.y + n.z * n.z);                            /* NormalizeFast :117 */
     if (l > 0) { double li = 1.0 / l; n.x *= li; n.y *= li; n.z *= li; }
+#ifdef VXO_HALF_ANGLE
+    /* NOT the reference's evaluation: the same rotation written with the half-angle identities the HIP engine uses (kernels.hpp
+     * from_angle_to_pos_x; DESIGN.md "Numerics").  Built only into libvxoracle_ha.so, with which tests/test_gpu_ledger.py measures
+     * how far THIS ONE rewrite moves the reference algorithm's own answer over a whole run. */
+    if (n.x < -0.999999999999995) return Q(0, 0, 1, 0);
+    {
+        double c = sqrt(0.5 + 0.5 * n.x), h = 0.5 / c;
+        return Q(c, 0, n.z * h, -n.y * h);
+    }
+#endif
     double theta = acos(n.x);
     if (theta > VX_PI - DISCARD_ANGLE_RAD) return Q(0, 0, 1, 0);
     double AxisMagInv = 1.0 / sqrt(n.z * n.z + n.y * n.y);
@@ -256,6 +266,22 @@ static void bond_add_damp(vxo_sim* s, ibond* b)
     if (s->dt != 0) {
         double BondZ = 0.5 * s->m.bond_damping_z;
         double DtInv = 1.0 / s->dt;
+#ifdef VXO_FOLD_DAMP   /* instrument: the engine's folding of 1 / dt and BondDampingZ / 2 into the 2 sqrt(k m) constants (DBondClass) */
+        {
+        v3 RelVel2 = vsub(b->pos2, b->last_pos2), W1 = vsub(b->angle1, b->last_angle1), W2 = vsub(b->angle2, b->last_angle2);
+        {
+            double zi = BondZ * DtInv, zh = 0.5 * zi;
+            double dA1 = b->sq_a1m1 * zi, dB1 = b->sq_b1ym1 * zi, dF1 = b->sq_b2yfm1 * zi, dA2 = b->sq_a1m2 * zi, dB2 = b->sq_b1ym2 * zi, dF2 = b->sq_b2yfm2 * zi;
+            double dT1 = b->sq_a2i1 * zh, dG1 = b->sq_b2yfm1 * zh, dH1 = b->sq_b3yi1 * zh, dT2 = b->sq_a2i2 * zh, dG2 = b->sq_b2yfm2 * zh, dH2 = b->sq_b3yi2 * zh;
+            b->f1 = vadd(b->f1, V(dA1 * RelVel2.x, dB1 * RelVel2.y - dF1 * (W1.z + W2.z), dB1 * RelVel2.z + dF1 * (W1.y + W2.y)));
+            if (!b->homogeneous) b->f2 = vadd(b->f2, V(-dA2 * RelVel2.x, -dB2 * RelVel2.y + dF2 * (W1.z + W2.z), -dB2 * RelVel2.z - dF2 * (W1.y + W2.y)));
+            b->m1 = vadd(b->m1, V(-dT1 * (W2.x - W1.x), dG1 * RelVel2.z + dH1 * (2 * W1.y + W2.y), -dG1 * RelVel2.y + dH1 * (2 * W1.z + W2.z)));
+            b->m2 = vadd(b->m2, V(dT2 * (W2.x - W1.x), dG2 * RelVel2.z + dH2 * (W1.y + 2 * W2.y), -dG2 * RelVel2.y + dH2 * (W1.z + 2 * W2.z)));
+        }
+        b->last_pos2 = b->pos2; b->last_angle1 = b->angle1; b->last_angle2 = b->angle2;
+        return;
+        }
+#endif
         v3 RelVel2 = vmul(vsub(b->pos2, b->last_pos2), DtInv);
         v3 W1 = vmul(vsub(b->angle1, b->last_angle1), DtInv);
         v3 W2 = vmul(vsub(b->angle2, b->last_angle2), DtInv);
@@ -548,7 +574,14 @@ static void euler_step(vxo_sim* s, int vi)
         /* LW/VXS_Voxel.cpp:211-235 */
         double TempFact = 1.0;
         if (s->m.temp_enabled && s->cur_time >= s->m.init_cm_time)
+#ifdef VXO_ANGLE_ADD   /* instrument (libvxoracle_aa.so): the engine's angle-addition form of the actuation sine, see VXO_HALF_ANGLE */
+        {
+            double a = (double)(2 * 3.1415926f) * (s->cur_time / (double)v->temp_period), b = (double)(2 * 3.1415926f) * (double)v->phase_offset;
+            TempFact = (1 + (v->temp_amplitude * (sin(a) * cos(b) + cos(a) * sin(b))) * v->cte);
+        }
+#else
             TempFact = (1 + (v->temp_amplitude * sin(2 * 3.1415926f * (s->cur_time / v->temp_period + v->phase_offset))) * v->cte);
+#endif
         if (TempFact < 0.1) TempFact = 0.1;                                         /* MIN_TEMP_FACTOR LW/VX_Sim.h:31 */
         v->scale = TempFact * v->nom_size;
     }
@@ -935,6 +968,22 @@ void vxo_get_constants(const vxo_sim* s, double* vox12n, double* bond23n)
         o[7] = b->b1y; o[8] = b->b2y; o[9] = b->b3y; o[10] = b->b1z; o[11] = b->b2z; o[12] = b->b3z;
         o[13] = b->sq_a1m1; o[14] = b->sq_a1m2; o[15] = b->sq_a2i1; o[16] = b->sq_a2i2;
         o[17] = b->sq_b1ym1; o[18] = b->sq_b1ym2; o[19] = b->sq_b2yfm1; o[20] = b->sq_b2yfm2; o[21] = b->sq_b3yi1; o[22] = b->sq_b3yi2;
+    }
+}
+
+/* Test instrument, not part of the restatement: moves every position and quaternion component of every voxel to the next representable double
+ * above or below (pseudo-random choice from `seed`).  tests/test_gpu_ledger.py applies it before every step of a twin run to
+ * measure how far the reference algorithm itself drifts under rounding-size noise in its state -- the size of noise any
+ * re-association or fused multiply-add of its arithmetic introduces at every step. */
+void vxo_jitter(vxo_sim* s, unsigned seed)
+{
+    unsigned long long x = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)seed * 0xD1B54A32D192ED03ull);
+    for (int i = 0; i < s->nvox; i++) {
+        double* c[7] = {&s->vox[i].pos.x, &s->vox[i].pos.y, &s->vox[i].pos.z, &s->vox[i].angle.w, &s->vox[i].angle.x, &s->vox[i].angle.y, &s->vox[i].angle.z};
+        for (int k = 0; k < 7; k++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            *c[k] = nextafter(*c[k], (x & 1) ? INFINITY : -INFINITY);
+        }
     }
 }
 

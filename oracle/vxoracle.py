@@ -78,13 +78,15 @@ def build(force=False):
 
 
 _lib = None
+_libs = {}
 
 
-def lib():
+def lib(half_angle=False):
+    """the restatement; half_angle=True: the instrument build with the engine's half-angle rewrite (oracle/Makefile)"""
     global _lib
-    if _lib is None:
+    if half_angle not in _libs:
         build()
-        _lib = ctypes.CDLL(LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH.replace("libvxoracle.so", "libvxoracle_ha.so") if half_angle else LIB_PATH)
         _lib.vxo_create.restype = ctypes.c_void_p
         _lib.vxo_create.argtypes = [ctypes.POINTER(VxoModel)]
         _lib.vxo_destroy.argtypes = [ctypes.c_void_p]
@@ -94,12 +96,14 @@ def lib():
         _lib.vxo_get_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_bond_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.vxo_jitter.argtypes = [ctypes.c_void_p, ctypes.c_uint]
         _lib.vxo_get_result.argtypes = [ctypes.c_void_p, ctypes.POINTER(VxoResult)]
         _lib.vxo_get_cm_trace.restype = ctypes.c_int
         _lib.vxo_get_cm_trace.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
         _lib.vxo_alg_bytes_per_step.restype = ctypes.c_double
         _lib.vxo_alg_bytes_per_step.argtypes = [ctypes.c_void_p]
-    return _lib
+        _libs[half_angle] = _lib
+    return _libs[half_angle]
 
 
 # ---------------------------------------------------------------------------------------------- .vxa reader
@@ -263,8 +267,9 @@ def _dptr(arr):
 class OracleSim(object):
     """One robot stepped by the CPU restatement."""
 
-    def __init__(self, model):
+    def __init__(self, model, half_angle=False):
         self.model = model  # keeps the numpy buffers alive
+        self._lib = lib(half_angle)     # (half_angle: the instrument build, see lib())
         m = VxoModel()
         for name, _ in VxoModel._fields_:
             if name in ("structure", "nmat", "mat_E", "mat_rho", "mat_nu", "mat_cte", "mat_us", "mat_ud",
@@ -281,7 +286,7 @@ class OracleSim(object):
         for _, key in DEV_LAYERS:
             setattr(m, key, _dptr(model.get(key)))
         self._cmodel = m
-        self._h = lib().vxo_create(ctypes.byref(m))
+        self._h = self._lib.vxo_create(ctypes.byref(m))
 
     @classmethod
     def from_vxa(cls, path, variant=0):
@@ -289,7 +294,7 @@ class OracleSim(object):
 
     def close(self):
         if self._h:
-            lib().vxo_destroy(self._h)
+            self._lib.vxo_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -299,46 +304,58 @@ class OracleSim(object):
             pass
 
     def step(self, n=-1):
-        return lib().vxo_step(self._h, n)
+        return self._lib.vxo_step(self._h, n)
 
     def info(self):
         out = VxoInfo()
-        lib().vxo_get_info(self._h, ctypes.byref(out))
+        self._lib.vxo_get_info(self._h, ctypes.byref(out))
         return out
 
     def state(self):
         n = self.info().nvox
         out = np.zeros((n, 14), dtype=np.float64)
-        lib().vxo_get_state(self._h, out.ctypes.data)
+        self._lib.vxo_get_state(self._h, out.ctypes.data)
         return out
 
     def bonds(self):
         n = self.info().nbond
         v1, v2, ax = (np.zeros(n, dtype=np.int32) for _ in range(3))
-        lib().vxo_get_bond_table(self._h, v1.ctypes.data, v2.ctypes.data, ax.ctypes.data)
+        self._lib.vxo_get_bond_table(self._h, v1.ctypes.data, v2.ctypes.data, ax.ctypes.data)
         return v1, v2, ax
+
+    def step_jittered(self, n, seed=1):
+        """n steps, every position component moved by one ulp (up or down, pseudo-random) before each of them: the twin run that
+        measures the reference algorithm's own drift under rounding-size noise (tests/test_gpu_ledger.py)"""
+        L = self._lib
+        done = 0
+        for k in range(n):
+            L.vxo_jitter(self._h, ctypes.c_uint(seed * 1000003 + self.info().steps if False else seed + k))
+            if L.vxo_step(self._h, 1) != 1:
+                break
+            done += 1
+        return done
 
     def constants(self):
         """([nvox, 12], [nbond, 23]): the constants Import leaves on voxels and bonds (vx_oracle.c vxo_get_constants)"""
         info = self.info()
         vox, bond = np.zeros((info.nvox, 12)), np.zeros((max(info.nbond, 1), 23))
-        lib().vxo_get_constants(self._h, vox.ctypes.data, bond.ctypes.data)
+        self._lib.vxo_get_constants(self._h, vox.ctypes.data, bond.ctypes.data)
         return vox, bond[:info.nbond]
 
     def result(self):
         out = VxoResult()
-        lib().vxo_get_result(self._h, ctypes.byref(out))
+        self._lib.vxo_get_result(self._h, ctypes.byref(out))
         return out
 
     def cm_trace(self):
         """[n, 4] (time, x, y, z): SS.CMTraceTime / SS.CMTrace"""
-        n = lib().vxo_get_cm_trace(self._h, None, 0)
+        n = self._lib.vxo_get_cm_trace(self._h, None, 0)
         out = np.zeros((max(n, 1), 4), dtype=np.float64)
-        lib().vxo_get_cm_trace(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n)
+        self._lib.vxo_get_cm_trace(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n)
         return out[:n]
 
     def alg_bytes_per_step(self):
-        return lib().vxo_alg_bytes_per_step(self._h)
+        return self._lib.vxo_alg_bytes_per_step(self._h)
 
 
 # ------------------------------------------------------------------------------------------- probe traces

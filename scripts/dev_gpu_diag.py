@@ -326,7 +326,8 @@ if __name__ == "__main__" and "e2emem" in sys.argv[1:]:
     sim = Sim(dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1)
     env = Env()
     pop = list(workloads.population(512, (10, 10, 10)))
-    with engine.Engine(engine.VOXCAD, 0) as eng:
+    n_eng = int(os.environ.get("VXH_E2E_ENGINES", "1"))      # > 1: one handle, several engines (host threads, streams) on the ONE device
+    with engine.Engine(engine.VOXCAD, [0] * n_eng if n_eng > 1 else 0) as eng:
         eng.add_vxa_text(write_voxelyze_file(sim, env, pop[0], tmp, "w", write=False, want_text=True)[1]); eng.step(1); eng.clear()   # (HIP runtime, code objects: once per process)
         for rep in range(2):
             t0 = time.perf_counter()
@@ -636,3 +637,128 @@ if __name__ == "__main__" and "lc2" in sys.argv[1:]:
             (La, na, ka), (Lb, nb, kb) = rows
             fixed = (kb - ka) / (nb - na)
             print("%s col=1  -> fixed cost per launch %.0f us, per step without it %.2f us" % (os.path.basename(engine.LIB_PATH), 1e6 * fixed, 1e6 * (ka - na * fixed) / 1000), flush=True)
+
+
+if __name__ == "__main__" and "drift" in sys.argv[1:]:
+    # round 3: error growth of a long run against the oracle, per kernel path (the shipped land_water examples: 26 k and 68 k steps)
+    from oracle import vxoracle as vo
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "vxa")
+    for name, variant in (("lw_hexapus", 1), ("lw_quadruped_land", 1), ("example_1", 0)):
+        path = os.path.join(golden, name + ".vxa")
+        model = vo.parse_vxa(path, variant)
+        lat = model["lattice_dim"]
+        checkpoints = (100, 1000, 4000, 16000, 25000, 60000)
+        sim = vo.OracleSim(model)
+        want = []
+        for upto in checkpoints:
+            sim.step(upto - sim.info().steps)
+            want.append((sim.info().steps, sim.state()))
+        for label, opts in (("wide", {}), ("resident", {"wide": 0, "tiled": 0}), ("streaming", {"fused": 0, "tiled": 0})):
+            with engine.Engine(variant, 0) as eng:
+                for k, v in opts.items():
+                    eng.set_option(k, v)
+                eng.add_vxa_file(path)
+                done, line = 0, []
+                for (steps, st) in want:
+                    eng.step(steps - done)
+                    done = steps
+                    got = eng.state(0)
+                    line.append("%d: %.1e" % (steps, np.abs(got[:, :3] - st[:, :3]).max() / lat))
+                print("%-18s %-10s max position error in voxels at step  %s" % (name, label, "  ".join(line)), flush=True)
+
+
+if __name__ == "__main__" and "drift2" in sys.argv[1:]:
+    # round 3: which ingredient of the shipped land_water example makes the engine leave the oracle by 1e-10 voxel within 100 steps
+    import re
+    from oracle import vxoracle as vo
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "vxa")
+    base = open(os.path.join(golden, "lw_hexapus.vxa")).read()
+    swim = open(os.path.join(golden, "lw_swim6.vxa")).read()
+
+    def sub(text, tag, val):
+        out, n = re.subn(r"<%s>[^<]*</%s>" % (tag, tag), "<%s>%s</%s>" % (tag, val, tag), text)
+        assert n >= 1, tag
+        return out
+    variants = [("hexapus as shipped", base),
+                ("hexapus, TempPeriod 0.25", sub(base, "TempPeriod", "0.25")),
+                ("hexapus, DtFrac 0.9", sub(base, "DtFrac", "0.9")),
+                ("hexapus, Lattice_Dim 0.01", sub(base, "Lattice_Dim", "0.01")),
+                ("hexapus, no actuation", sub(base, "TempEnabled", "0")),
+                ("hexapus, no fluid", sub(base, "FluidEnvironment", "0")),
+                ("swim6 as generated", swim),
+                ("swim6, Lattice_Dim 0.05", sub(swim, "Lattice_Dim", "0.05")),
+                ("swim6, TempPeriod 0.263662540539", sub(swim, "TempPeriod", "0.263662540539")),
+                ("swim6, DtFrac 0.7", sub(swim, "DtFrac", "0.7"))]
+    tmp = tempfile.mkdtemp()
+    for label, text in variants:
+        path = os.path.join(tmp, "v.vxa")
+        open(path, "w").write(text)
+        model = vo.parse_vxa(path, 1)
+        lat = model["lattice_dim"]
+        sim = vo.OracleSim(model)
+        with engine.Engine(1, 0) as eng:
+            eng.add_vxa_file(path)
+            done, line = 0, []
+            for upto in (1, 2, 3, 5, 10, 100, 1000):
+                eng.step(upto - done); done = upto
+                sim.step(upto - sim.info().steps)
+                got, want = eng.state(0), sim.state()
+                line.append("%d: %.1e/%.0e/%.0e" % (upto, np.abs(got[:, :3] - want[:, :3]).max() / lat, np.abs(got[:, 3:7] - want[:, 3:7]).max(), np.abs(got[:, 7] - want[:, 7]).max() / lat))
+            print("%-36s pos/quat/scale error at step  %s" % (label, "  ".join(line)), flush=True)
+
+
+if __name__ == "__main__" and "drift3" in sys.argv[1:]:
+    # round 3: step by step through the start of the shipped land_water example: where does the first non-rounding deviation appear
+    from oracle import vxoracle as vo
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "vxa")
+    path = os.path.join(golden, "lw_hexapus.vxa")
+    model = vo.parse_vxa(path, 1)
+    lat = model["lattice_dim"]
+    sim = vo.OracleSim(model)
+    with engine.Engine(1, 0) as eng:
+        eng.add_vxa_file(path)
+        for step in range(1, 16):
+            eng.step(1)
+            sim.step(1)
+            got, want = eng.state(0), sim.state()
+            d = np.abs(got - want)
+            worst = int(d[:, :3].max(axis=1).argmax())
+            print("step %2d: pos %.1e (voxel %d, z %.4f)  quat %.1e  scale %.1e  vel %.1e (rel %.1e)  angvel %.1e (rel %.1e)   oracle: max |vel| %.2e max |angvel| %.2e  min quat w - 1: %.2e" % (
+                step, d[:, :3].max() / lat, worst, want[worst, 2] / lat, d[:, 3:7].max(), d[:, 7].max() / lat, d[:, 8:11].max(), d[:, 8:11].max() / max(1e-300, np.abs(want[:, 8:11]).max()),
+                d[:, 11:14].max(), d[:, 11:14].max() / max(1e-300, np.abs(want[:, 11:14]).max()), np.abs(want[:, 8:11]).max(), np.abs(want[:, 11:14]).max(), (want[:, 3] - 1).min()), flush=True)
+
+
+if __name__ == "__main__" and "drift6" in sys.argv[1:]:
+    # round 3: do engine and oracle ever disagree on a bond's small-/large-angle mode?  (count of large-angle bonds after every step)
+    from oracle import vxoracle as vo
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "vxa")
+    for name, variant, nsteps in (("lw_hexapus", 1, 3000), ("lw_quadruped_land", 1, 3000), ("lw_swim6", 1, 1500)):
+        path = os.path.join(golden, name + ".vxa")
+        model = vo.parse_vxa(path, variant)
+        sim = vo.OracleSim(model)
+        bad, flips, last = [], 0, 0
+        with engine.Engine(variant, 0) as eng:
+            eng.set_option("steps_per_launch", 1)
+            eng.add_vxa_file(path)
+            for step in range(1, nsteps + 1):
+                eng.step(1); sim.step(1)
+                info = sim.info()
+                want = info.nbond - info.n_small_angle
+                got = eng.bond_modes()[0]
+                flips += abs(want - last); last = want
+                if got != want:
+                    bad.append((step, got, want))
+        print("%s: %d steps, net mode changes %d, steps where the counts of large-angle bonds differ: %d %s" % (name, nsteps, flips, len(bad), bad[:10]), flush=True)
+
+
+if __name__ == "__main__" and sys.argv[1:2] and sys.argv[1] in ("cfg1", "cfg3", "cfg4"):
+    # one BASELINE config each, for the counter passes of scripts/profile_bench.sh
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    if sys.argv[1] == "cfg1":
+        timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.1, Env(), {})
+    elif sys.argv[1] == "cfg3":
+        timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, {}, per_voxel_phase=True)
+    else:
+        timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.02, Env(), {}, full=True)

@@ -40,6 +40,36 @@ if len(sys.argv) > 3 and sys.argv[3] == "sq":      # `profile_sum.py <out_root> 
                 if kk == kern:
                     f.write("   %-28s %16.0f  (%d dispatches)\n" % (c, tot[(kk, c)], n[(kk, c)]))
     print("wrote", path)
+    # what binds the dominant kernel, for bench.py's roofline.compute: SQ counters are in quad-cycles (ACTIVE / WAVE_CYCLES / WAIT), the
+    # kernel's duration from the stats pass of the same command
+    kinds = sorted({k for k, _ in tot}, key=lambda k: -tot.get((k, "SQ_INSTS_VALU"), 0.0))
+    if kinds and tot.get((kinds[0], "SQ_WAVE_CYCLES")):
+        dom = kinds[0]
+        g = lambda c: tot.get((dom, c), 0.0)
+        dur_ns = sum(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in rows("stats", "kernel_trace.csv") if r["Kernel_Name"] == dom)
+        import re
+        m = re.search(r"<(\d+)", dom)
+        block = int(m.group(1)) if m else 0
+        waves_per_simd = max(1, block // 256)
+        f64 = {c: g(c) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")}
+        flops = 64.0 * (f64["SQ_INSTS_VALU_ADD_F64"] + f64["SQ_INSTS_VALU_MUL_F64"] + 2.0 * f64["SQ_INSTS_VALU_FMA_F64"] + f64["SQ_INSTS_VALU_TRANS_F64"])
+        comp = {"kernel": dom, "command": "python bench.py --no-cpu-baseline --no-other-configs", "dispatches": n.get((dom, "SQ_INSTS_VALU"), 0),
+                "valu_busy": g("SQ_ACTIVE_INST_VALU") * waves_per_simd / g("SQ_WAVE_CYCLES"),
+                "valu_busy_note": "SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / %d): share of the SIMD cycles (while the workgroup's %d wavefronts per SIMD are "
+                                  "resident) in which a vector instruction was executing" % (waves_per_simd, waves_per_simd),
+                "cycles_per_valu_inst": 4.0 * g("SQ_ACTIVE_INST_VALU") / max(1.0, g("SQ_INSTS_VALU")),
+                "wait_share": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
+                "lds_bank_conflict": g("SQ_LDS_BANK_CONFLICT") / max(1.0, g("SQ_LDS_IDX_ACTIVE")),
+                "bound": "fp64-issue"}
+        if dur_ns > 0 and flops > 0:
+            comp.update({"fp64_flops_per_s": flops / (dur_ns * 1e-9), "peak": 78.6e12, "unit": "FLOP/s", "frac": flops / (dur_ns * 1e-9) / 78.6e12,
+                         "fp64_insts": f64,
+                         "peak_note": "vector FP64 peak = half the FP32 vector peak of MI355X_MICROARCH.md (157.3 TFLOP/s): one FP64 wave-instruction per "
+                                      "4 cycles and SIMD at 2.4 GHz (measured under load: 4.3-4.9 cycles at 2.05-2.2 GHz, scripts/ubench/fp64_issue.hip); "
+                                      "flops = 64 lanes x (ADD + MUL + 2 FMA + TRANS) FP64 wave-instructions"})
+        with open(os.path.join(prof_dir, "%s_compute.json" % tag), "w") as f:
+            json.dump(comp, f, indent=1)
+        print(json.dumps(comp, indent=1))
     sys.exit(0)
 if len(sys.argv) > 3:          # `profile_sum.py <out_root> <tag> tiled`: only the per-kernel table of that trace
     sub = sys.argv[3]

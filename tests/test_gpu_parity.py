@@ -968,3 +968,57 @@ def test_device_side_result_reductions_equal_the_host_path(eng_mod, golden_dir):
             seen[host] = out
     assert seen[0] == seen[1]
     assert all(r["status"] == eng_mod.ROBOT_FINISHED and r["num_touching_floor"] > 0 for r in seen[0][2])
+
+
+def test_collision_rows_longer_than_64_partners(eng_mod, tmp_path):
+    """The reference's collision lists have no cap (CVX_Sim::CreateColBond, VX_Sim.cpp:753-769).  A folded sheet with
+    <CollisionHorizon> 5 gives the voxels of its inner plates rows of far more than 64 partners (rounds 1-2 ended such a robot with
+    VXH_ROBOT_COL_OVERFLOW): the engine must follow the oracle through the flapping, contacts included; with the option col_cap = 64
+    the same robot must be reported as overflowed while the other robot of the batch is untouched, bit for bit."""
+    import re
+    from oracle import vxoracle as vo
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.6, fitness_eval_init_time=0.02)
+    env = Env(temp_amp=39, frequency=8.0)
+    paths = []
+    for i, mat in enumerate((workloads.folded_material(), workloads.random_material((6, 6, 6), 7))):
+        write_voxelyze_file(sim, env, workloads.make_individual(i, mat), str(tmp_path), "fold")
+        p = str(tmp_path / "voxelyzeFiles" / ("fold--id_%05i.vxa" % i))
+        text, n = re.subn(r"<CollisionHorizon>[^<]*</CollisionHorizon>", "<CollisionHorizon>5</CollisionHorizon>", open(p).read())
+        assert n == 1
+        open(p, "w").write(text)
+        paths.append(p)
+    models = [vo.parse_vxa(p) for p in paths]
+    sims = [vo.OracleSim(m) for m in models]
+    checkpoints = (1, 10, 100, 400, 900)
+    spreads = [_spread(m, checkpoints) for m in models]
+    states = {}
+    for cap in (0, 64):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("col_cap", cap)
+            for p in paths:
+                eng.add_vxa_file(p)
+            done = 0
+            for upto in checkpoints:
+                eng.step(upto - done)
+                done = upto
+                if cap == 0:
+                    for i in range(2):
+                        sims[i].step(upto - sims[i].info().steps)
+                        want, got = sims[i].state(), eng.state(i)
+                        tol = FLOOR_VOX if upto <= 10 else max(FLOOR_VOX, 20 * spreads[i][0])
+                        assert _pos_err(got, want, models[i]["lattice_dim"]) <= tol, (i, upto, _pos_err(got, want, models[i]["lattice_dim"]), tol)
+            states[cap] = [eng.state(i) for i in range(2)]
+            status = [eng.result(i).status for i in range(2)]
+            rebuilds = eng.result(0).col_rebuilds
+        if cap == 0:
+            assert status == [eng_mod.ROBOT_PENDING, eng_mod.ROBOT_PENDING]
+            info = sims[0].info()
+            assert rebuilds == info.col_rebuilds and rebuilds >= 2
+            assert 2 * info.ncol > 64 * info.nsurf                      # a collision bond sits in two rows: more than 64 partners per row ON AVERAGE
+        else:
+            assert status[0] == eng_mod.ROBOT_COL_OVERFLOW and status[1] == eng_mod.ROBOT_PENDING
+    assert np.array_equal(states[0][1], states[64][1])                    # the neighbour in the batch: the same bits either way

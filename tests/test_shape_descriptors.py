@@ -1,0 +1,60 @@
+"""land_water shape descriptors: the per-vertex angle excesses of the deformable surface mesh,
+CVX_MeshUtil::computeShapeComplexity (LW/VX_MeshUtil.cpp:956-1031), against the vectors the reference binary itself wrote to
+<CurvaturesTmpFile> (tests/golden/make_curvature_golden.py; six significant digits per value, tab-separated)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from evosoro_amd import engine
+
+CASES = ["lw_swim6", "lw_land6", "lw_stiff5"]
+
+
+def _golden(golden_dir, case, which):
+    return np.array([float(t) for t in open(os.path.join(golden_dir, "expected", "%s.curv_%s.txt" % (case, which))).read().split()])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rest_state_angle_excess_equals_the_reference_file(golden_dir, case):
+    """host-only (no GPU): the vector of the undeformed mesh, what computeInitialShapeComplexity hands to the entropy script"""
+    got = engine.inspect_angle_excess(os.path.join(golden_dir, "vxa", case + ".vxa"), engine.VOXCAD_LAND_WATER)
+    want = _golden(golden_dir, case, "start")
+    assert got.shape == want.shape and len(got) > 100
+    # the file carries six significant digits; flat vertices are rounding noise around zero on both sides
+    assert np.allclose(got, want, rtol=6e-6, atol=1e-12), np.abs(got - want).max()
+    printed = np.array([float("%g" % v) for v in got])
+    assert np.array_equal(printed[np.abs(want) > 1e-9], want[np.abs(want) > 1e-9])        # digit for digit where the value is not noise
+    # right angles of a voxel surface: multiples of pi/2
+    assert np.allclose(np.round(want / (np.pi / 2)) * (np.pi / 2), want, atol=1e-4)
+
+
+def test_a_voxcad_robot_has_no_mesh(golden_dir):
+    assert len(engine.inspect_angle_excess(os.path.join(golden_dir, "vxa", "probe6.vxa"), engine.VOXCAD)) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_final_state_angle_excess_and_the_curvatures_file(golden_dir, tmp_path, case):
+    """after the whole evaluation on the GPU: vxh_get_angle_excess and the <CurvaturesTmpFile> that vxh_write_result_xml leaves,
+    against the file the reference binary left at the end of its run"""
+    text = open(os.path.join(golden_dir, "vxa", case + ".vxa")).read()
+    curv = str(tmp_path / "curvatures.txt")
+    text = re.sub(r"<CurvaturesTmpFile>.*?</CurvaturesTmpFile>", "<CurvaturesTmpFile>%s</CurvaturesTmpFile>" % curv, text)
+    want_start, want_end = _golden(golden_dir, case, "start"), _golden(golden_dir, case, "end")
+    with engine.Engine(engine.VOXCAD_LAND_WATER, 0) as eng:
+        eng.add_vxa_text(text)
+        assert np.allclose(eng.angle_excess(0, at_end=False), want_start, rtol=6e-6, atol=1e-12)
+        eng.run()
+        got = eng.angle_excess(0, at_end=True)
+        eng.write_result_xml(0, str(tmp_path / "out.xml"))
+    assert got.shape == want_end.shape
+    # the end state is a simulation result: six printed digits of the reference against ours, up to the robot's own conditioning
+    assert np.allclose(got, want_end, rtol=6e-6, atol=2e-7), np.abs(got - want_end).max()
+    assert np.abs(got - want_start).max() > 1e-3                                          # (the mesh did deform)
+    written = open(curv).read()
+    assert written.endswith("\t") and len(written.split()) == len(got)
+    assert [float(t) for t in written.split()] == [float("%g" % v) for v in got]
+    xml = open(str(tmp_path / "out.xml")).read()
+    assert "<ShapeComplexityStart>-1</ShapeComplexityStart>" in xml and "<ShapeComplexityEnd>-1</ShapeComplexityEnd>" in xml
