@@ -87,6 +87,14 @@ struct Engine::Device {
     hipEvent_t tile_t0 = nullptr, tile_t1 = nullptr;
     int n_cu = 0;
     DResult* results = nullptr;               // [robots] output of k_results (freed with the batch)
+    // a call that has been launched and not yet waited for (advance_launch / advance_finish)
+    struct Pending {
+        bool active = false;
+        long long todo = 0, launches = 0, tile_launch_count = 0;
+        bool fused = false, tiled = false, streaming = false;
+        std::vector<int> steps_before;
+        std::vector<long long> group_launches;
+    } pending;
     int reb_blocks = 0;                   // streaming path: collision-rebuild blocks appended to k_bonds
     const int* reb_robot = nullptr;
     const int* reb_i0 = nullptr;
@@ -250,6 +258,34 @@ std::vector<RobotModel> Engine::build_vxa_files(const std::vector<std::string>& 
 // occupied-voxel counter in file order (VX_Object.cpp:1879-1900), optionally through the writer's decimal text.
 std::vector<RobotModel> Engine::build_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* in, int n, bool round_like_text) const
 {
+    return build_models(models_from_arrays(template_vxa, len, in, n, round_like_text));
+}
+
+// ... in two steps: the cheap one (template parse, argument checks, the arrays copied into .vxa models: everything that can be
+// REFUSED) and the expensive one (model building).  A handle that pipelines a generation does the first when the robots are
+// added and the second chunk by chunk while earlier chunks already step (EngineSet::run).
+std::vector<RobotModel> Engine::build_models(std::vector<VxaModel>&& models) const
+{
+    const int n = (int)models.size();
+    std::vector<RobotModel> built(n);
+    std::vector<std::exception_ptr> errors(n);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            try { built[i] = build_robot(models[i]); } catch (...) { errors[i] = std::current_exception(); }
+        }
+    };
+    const int nthreads = std::max(1, std::min({n, (int)std::thread::hardware_concurrency(), 32}));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    for (int i = 0; i < n; ++i) if (errors[i]) std::rethrow_exception(errors[i]);
+    return built;
+}
+
+std::vector<VxaModel> Engine::models_from_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* in, int n, bool round_like_text) const
+{
     VxaModel base = read_vxa(template_vxa, len, variant_);
     if (!base.unsupported.empty()) {
         std::string msg = "unsupported .vxa feature(s):";
@@ -270,7 +306,7 @@ std::vector<RobotModel> Engine::build_arrays(const char* template_vxa, size_t le
     };
     for (const auto& sl : slots) { base.*(sl.has) = false; (base.*(sl.values)).clear(); }
     base.structure.clear();
-    std::vector<RobotModel> built(n);
+    std::vector<VxaModel> built(n);
     std::vector<std::exception_ptr> errors(n);
     std::atomic<int> next{0};
     auto worker = [&]() {
@@ -302,7 +338,7 @@ std::vector<RobotModel> Engine::build_arrays(const char* template_vxa, size_t le
                         out.push_back(v);
                     }
                 }
-                built[i] = build_robot(m);
+                built[i] = std::move(m);
             } catch (...) {
                 errors[i] = std::current_exception();
             }
@@ -1111,7 +1147,12 @@ static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool
     else { if (tabg) launch_sized<false, true>(B, block, list, count, lds, s, cap, iters); else launch_sized<false, false>(B, block, list, count, lds, s, cap, iters); }
 }
 
-void Engine::advance(long long max_rounds)
+// A call in two halves: advance_launch enqueues every kernel of the call and returns; advance_finish waits for the device, reads
+// the control blocks back and does the accounting.  advance() = one after the other; a handle that pipelines a generation over
+// several engines of one device (EngineSet::run) launches them all before it waits for the first.
+void Engine::advance(long long max_rounds) { advance_launch(max_rounds); advance_finish(); }
+
+void Engine::advance_launch(long long max_rounds)
 {
     HIP_OK(hipSetDevice(device_id_));
     Device& D = *dev_;
@@ -1127,12 +1168,14 @@ void Engine::advance(long long max_rounds)
     const bool streaming = fused ? D.n_rest > 0 : D.n_all > 0;
     B.streamed = fused ? D.streamed_rest : D.streamed_all;
     // per-robot step counts before, to attribute the work of this call
-    std::vector<int> steps_before(robots_.size());
+    if (D.pending.active) throw std::logic_error("a launched call has not been finished");
+    std::vector<int>& steps_before = D.pending.steps_before;
+    steps_before.assign(robots_.size(), 0);
     for (size_t r = 0; r < robots_.size(); ++r) steps_before[r] = host_.size() == robots_.size() ? host_[r].steps : 0;
-    HostStages hs;
     HIP_OK(hipEventRecord(D.ev0, D.stream));
     long long launches = 0;
-    std::vector<long long> group_launches(D.groups.size(), 0);
+    std::vector<long long>& group_launches = D.pending.group_launches;
+    group_launches.assign(D.groups.size(), 0);
     if (fused) {
         const int iters = std::max(1, steps_per_launch_);
         for (auto& g : D.groups) { HIP_OK(hipStreamWaitEvent(g.stream, D.ev0, 0)); HIP_OK(hipEventRecord(g.t0, g.stream)); }
@@ -1199,6 +1242,21 @@ void Engine::advance(long long max_rounds)
     if (tiled) HIP_OK(hipStreamWaitEvent(D.stream, D.tile_t1, 0));
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(D.ev1, D.stream));
+    D.pending.active = true; D.pending.todo = todo; D.pending.launches = launches; D.pending.tile_launch_count = tile_launch_count;
+    D.pending.fused = fused; D.pending.tiled = tiled; D.pending.streaming = streaming;
+}
+
+void Engine::advance_finish()
+{
+    HIP_OK(hipSetDevice(device_id_));
+    Device& D = *dev_;
+    if (!D.pending.active) return;
+    D.pending.active = false;
+    const long long todo = D.pending.todo, launches = D.pending.launches, tile_launch_count = D.pending.tile_launch_count;
+    const bool fused = D.pending.fused, tiled = D.pending.tiled, streaming = D.pending.streaming;
+    const std::vector<int>& steps_before = D.pending.steps_before;
+    const std::vector<long long>& group_launches = D.pending.group_launches;
+    HostStages hs;
     HIP_OK(hipStreamSynchronize(D.stream));
     float ms = 0;
     HIP_OK(hipEventElapsedTime(&ms, D.ev0, D.ev1));
@@ -1265,6 +1323,14 @@ void Engine::run()
     advance(0x7fffffffffffffffLL / 4);
     counters_.run_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
+
+void Engine::run_launch()
+{
+    if (robots_.empty()) return;
+    if (!prepared_) prepare();
+    advance_launch(0x7fffffffffffffffLL / 4);
+}
+void Engine::run_finish() { if (!robots_.empty()) advance_finish(); }
 
 void Engine::step(long long n)
 {

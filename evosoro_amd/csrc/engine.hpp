@@ -34,10 +34,14 @@ public:
     std::vector<RobotModel> build_vxa(const char* data, size_t len) const;
     std::vector<RobotModel> build_vxa_files(const std::vector<std::string>& paths) const;
     std::vector<RobotModel> build_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text) const;
+    std::vector<VxaModel> models_from_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text) const;   // checks + copies
+    std::vector<RobotModel> build_models(std::vector<VxaModel>&& models) const;                                                                 // the expensive part
     int append(std::vector<RobotModel>&& built);             // returns first index
     int num_robots() const { return (int)robots_.size(); }
     const RobotModel& robot(int i) const { return robots_[i]; }
     void run();                                // to completion
+    void run_launch();                         // ... in two halves: enqueue everything / wait + accounting (EngineSet pipelines engines with them)
+    void run_finish();
     void step(long long n);                    // at most n more steps per robot
     void reset();
     void clear();
@@ -60,7 +64,9 @@ public:
 private:
     struct Device;                             // HIP-side members (engine.hip)
     void prepare();                            // build + upload the batch
-    void advance(long long max_rounds);        // launch step rounds
+    void advance(long long max_rounds);        // launch step rounds and wait
+    void advance_launch(long long max_rounds);
+    void advance_finish();
     void download();
     void download_control();
     void download_reduced();                   // k_results + the traces: what results need, without the voxel state
@@ -119,9 +125,17 @@ private:
     void gather();          // every robot back to engine 0, in order (before an addition)
     void distribute();      // ... and out to the devices (before a run)
     void each(const std::function<void(Engine&)>& body);   // on every engine that holds robots, concurrently; rethrows the first failure
+    void no_tiling_if_shared();   // several engines of the handle on one device are about to hold robots: no multi-workgroup kernel
+    bool repeated_ = false;       // the device list names a device more than once
+    void flush_pending();   // build what a pipelining handle has only checked so far (any reader or addition before the run)
     std::vector<std::unique_ptr<Engine>> engines_;
     std::vector<std::pair<int, int>> where_;   // robot -> (engine, index there), valid while distributed_
     bool distributed_ = false;
+    // Several engines on ONE device (vxh_create_multi with a repeated device id): the handle pipelines a generation handed over as
+    // arrays -- vxh_add_robots only checks and copies, vxh_run builds, uploads and launches chunk after chunk (one per engine) before
+    // it waits for the first, so the device steps chunk k while the host cores build chunk k + 1
+    bool pipelined_ = false;
+    std::vector<VxaModel> pending_;
 };
 
 int hip_device_count();      // engine.hip: HIP devices this process can use (0 when the runtime reports none)

@@ -1,6 +1,7 @@
 // EngineSet: the engines behind one C-ABI handle (engine.hpp).  Host-only code.
 #include <algorithm>
 #include <exception>
+#include <iterator>
 #include <stdexcept>
 #include <thread>
 
@@ -13,11 +14,26 @@ EngineSet::EngineSet(int variant, const std::vector<int>& device_ids)
     if (device_ids.empty()) throw std::invalid_argument("no device");
     for (int d : device_ids) engines_.emplace_back(new Engine(variant, d));
     // two engines on ONE device would have their multi-workgroup launches compete for the CUs (kernels_tiled.hpp: the tiles of a robot
-    // wait for each other): such a handle -- a test configuration, one engine per GPU is the point -- steps with the other kernels
+    // wait for each other): when such a handle spreads robots over its engines they step with the other kernels (no_tiling_if_shared)
     std::vector<int> sorted = device_ids;
     std::sort(sorted.begin(), sorted.end());
-    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+    repeated_ = std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end();
+    pipelined_ = device_ids.size() > 1 && sorted.front() == sorted.back();
+}
+
+void EngineSet::no_tiling_if_shared()
+{
+    if (repeated_ && engines_.size() > 1)
         for (auto& e : engines_) e->set_option("tiled", 0);
+}
+
+void EngineSet::flush_pending()
+{
+    if (pending_.empty()) return;
+    std::vector<RobotModel> m = engines_[0]->build_models(std::move(pending_));
+    pending_.clear();
+    gather();
+    engines_[0]->append(std::move(m));
 }
 
 void EngineSet::gather()
@@ -42,6 +58,7 @@ void EngineSet::distribute()
         distributed_ = true;
         return;
     }
+    no_tiling_if_shared();
     std::vector<RobotModel> all = engines_[0]->take_robots();
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) order[i] = i;
@@ -77,50 +94,102 @@ void EngineSet::each(const std::function<void(Engine&)>& body)
 // additions: parse and build first -- a refused call (bad file, unsupported feature) leaves the robots where they are, with the
 // results of earlier runs readable -- then bring every robot back to engine 0 and append
 int EngineSet::add_vxa(const char* data, size_t len)
-{ std::vector<RobotModel> m = engines_[0]->build_vxa(data, len); gather(); return engines_[0]->append(std::move(m)); }
+{ std::vector<RobotModel> m = engines_[0]->build_vxa(data, len); flush_pending(); gather(); return engines_[0]->append(std::move(m)); }
 int EngineSet::add_vxa_files(const std::vector<std::string>& paths)
-{ std::vector<RobotModel> m = engines_[0]->build_vxa_files(paths); gather(); return engines_[0]->append(std::move(m)); }
+{ std::vector<RobotModel> m = engines_[0]->build_vxa_files(paths); flush_pending(); gather(); return engines_[0]->append(std::move(m)); }
 int EngineSet::add_arrays(const char* t, size_t len, const vxh_robot_arrays* robots, int n, bool round_like_text)
-{ std::vector<RobotModel> m = engines_[0]->build_arrays(t, len, robots, n, round_like_text); gather(); return engines_[0]->append(std::move(m)); }
+{
+    if (pipelined_ && !distributed_ && engines_[0]->num_robots() == 0) {     // a fresh generation on a pipelining handle: check + copy now, build at the run
+        std::vector<VxaModel> m = engines_[0]->models_from_arrays(t, len, robots, n, round_like_text);
+        const int first = (int)pending_.size();
+        for (auto& x : m) pending_.push_back(std::move(x));
+        return first;
+    }
+    std::vector<RobotModel> m = engines_[0]->build_arrays(t, len, robots, n, round_like_text);
+    flush_pending(); gather();
+    return engines_[0]->append(std::move(m));
+}
 
-int EngineSet::num_robots() const { return distributed_ ? (int)where_.size() : engines_[0]->num_robots(); }
+int EngineSet::num_robots() const { return (distributed_ ? (int)where_.size() : engines_[0]->num_robots()) + (int)pending_.size(); }
 const RobotModel& EngineSet::robot(int i) const
-{ return distributed_ ? engines_[where_[i].first]->robot(where_[i].second) : engines_[0]->robot(i); }
+{
+    const_cast<EngineSet*>(this)->flush_pending();                          // (a reader before the run: the models are needed now)
+    return distributed_ ? engines_[where_[i].first]->robot(where_[i].second) : engines_[0]->robot(i);
+}
 
-void EngineSet::run() { distribute(); each([](Engine& e) { e.run(); }); }
-void EngineSet::step(long long n) { distribute(); each([n](Engine& e) { e.step(n); }); }
-void EngineSet::reset() { distribute(); each([](Engine& e) { e.reset(); }); }      // (distribute first: not the whole population on device 0)
-void EngineSet::clear() { for (auto& e : engines_) e->clear(); where_.clear(); distributed_ = false; }
+void EngineSet::run()
+{
+    if (!pending_.empty() && !distributed_ && engines_[0]->num_robots() == 0) {
+        // the pipeline: chunk k = robots [k n / K, (k + 1) n / K) goes to engine k: built on the host cores, uploaded, its kernels
+        // enqueued -- and the host moves on to chunk k + 1 while the device steps; then the engines are waited for in order, so the
+        // control blocks of chunk k come back while chunk k + 1 is still stepping.  Which kernel steps a robot, and therefore its
+        // result, does not depend on the chunking.
+        const int n = (int)pending_.size();
+        where_.assign(n, {0, 0});
+        std::vector<VxaModel> all = std::move(pending_);
+        pending_.clear();
+        // a lattice of more than 1024 voxels needs the tiled kernel, which must own the device: such a generation is not pipelined
+        bool large = false;
+        for (const auto& m : all) { size_t occ = 0; for (unsigned char c : m.structure) occ += c != 0; large = large || occ > 1024; }
+        const int K = large ? 1 : (int)engines_.size();
+        if (!large) no_tiling_if_shared();
+        int launched = 0;
+        try {
+            for (int k = 0; k < K; ++k) {
+                const int lo = (int)((long long)n * k / K), hi = (int)((long long)n * (k + 1) / K);
+                if (hi <= lo) continue;
+                std::vector<VxaModel> chunk(std::make_move_iterator(all.begin() + lo), std::make_move_iterator(all.begin() + hi));
+                engines_[k]->append(engines_[k]->build_models(std::move(chunk)));
+                for (int i = lo; i < hi; ++i) where_[i] = {k, i - lo};
+                engines_[k]->run_launch();
+                launched = k + 1;
+            }
+        } catch (...) {
+            for (int k = 0; k < launched; ++k) { try { engines_[k]->run_finish(); } catch (...) {} }
+            distributed_ = true;
+            throw;
+        }
+        distributed_ = true;
+        for (int k = 0; k < K; ++k) engines_[k]->run_finish();
+        return;
+    }
+    flush_pending();
+    distribute();
+    each([](Engine& e) { e.run(); });
+}
+void EngineSet::step(long long n) { flush_pending(); distribute(); each([n](Engine& e) { e.step(n); }); }
+void EngineSet::reset() { flush_pending(); distribute(); each([](Engine& e) { e.reset(); }); }      // (distribute first: not the whole population on device 0)
+void EngineSet::clear() { for (auto& e : engines_) e->clear(); where_.clear(); pending_.clear(); distributed_ = false; }
 
 // (readers distribute first, like run(): after an addition, or a reset, the engine that holds the robot says what is missing)
 void EngineSet::result(int robot, vxh_result* out)
 {
-    distribute();
+    flush_pending(); distribute();
     engines_[where_[robot].first]->result(where_[robot].second, out);
 }
 void EngineSet::state14(int robot, double* out, int capacity)
 {
-    distribute();
+    flush_pending(); distribute();
     engines_[where_[robot].first]->state14(where_[robot].second, out, capacity);
 }
 int EngineSet::cm_trace(int robot, double* out4n, int capacity)
 {
-    distribute();
+    flush_pending(); distribute();
     return engines_[where_[robot].first]->cm_trace(where_[robot].second, out4n, capacity);
 }
 const std::vector<double>& EngineSet::trace_of(int robot)
 {
-    distribute();
+    flush_pending(); distribute();
     return engines_[where_[robot].first]->trace_of(where_[robot].second);
 }
 std::vector<double> EngineSet::angle_excess(int robot, bool at_end)
 {
-    distribute();
+    flush_pending(); distribute();
     return engines_[where_[robot].first]->angle_excess(where_[robot].second, at_end);
 }
 void EngineSet::bond_modes(long long* large_angle, long long* total)
 {
-    distribute();
+    flush_pending(); distribute();
     *large_angle = *total = 0;
     for (auto& e : engines_) { if (e->num_robots() == 0) continue; long long l = 0, t = 0; e->bond_modes(&l, &t); *large_angle += l; *total += t; }
 }

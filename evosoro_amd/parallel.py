@@ -112,13 +112,18 @@ def gather_records(local_records, local_indices, total, device=None, per_rank=No
     return table
 
 
+PIPELINE_ENGINES = 2      # in-memory hand-off: engines of the one handle a generation is pipelined over (chunk k + 1 is built on the host
+                          # cores while chunk k steps: include/vxhip.h vxh_create_multi with a repeated device id); 1 = no pipeline
+
+
 def run_shard(engine_module, paths, variant, device_index, options=None, write_xml=True, loader=None):
     """Step the given .vxa files as one batch on one GPU; returns (records [n, RECORD_LEN], counters).  `loader(eng)`, when given,
     adds the robots instead (the in-memory hand-off); `paths` then only says how many there are."""
     records = np.zeros((len(paths), RECORD_LEN), dtype=np.float64)
     if not paths:
         return records, None
-    with engine_module.Engine(variant, device_index) as eng:
+    device = [device_index] * PIPELINE_ENGINES if (loader is not None and PIPELINE_ENGINES > 1) else device_index
+    with engine_module.Engine(variant, device) as eng:
         for key, val in (options or {}).items():
             eng.set_option(key, val)
         if loader is not None:
