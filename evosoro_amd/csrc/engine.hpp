@@ -68,7 +68,7 @@ private:
     void advance_launch(long long max_rounds);
     void advance_finish();
     void download();
-    void download_control();
+    void download_control(bool already_copied = false);
     void download_reduced();                   // k_results + the traces: what results need, without the voxel state
     int variant_, device_id_;
     std::vector<RobotModel> robots_;

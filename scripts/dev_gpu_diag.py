@@ -762,3 +762,15 @@ if __name__ == "__main__" and sys.argv[1:2] and sys.argv[1] in ("cfg1", "cfg3", 
         timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, {}, per_voxel_phase=True)
     else:
         timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.02, Env(), {}, full=True)
+
+
+if __name__ == "__main__" and "satcheck" in sys.argv[1:]:
+    # round 3: the wide kernel against the resident one on populations that fill the chip (is the latency layout slower there?)
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    for rep in range(2):
+        for opts in ({}, {"wide": 0}):
+            timing_cfg(engine.VOXCAD, 2048, (6, 6, 6), 0.05, Env(), opts)
+            timing_cfg(engine.VOXCAD, 512, (8, 8, 8), 0.05, Env(), opts)
+            timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.05, env_w, opts, per_voxel_phase=True)

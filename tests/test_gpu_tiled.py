@@ -112,3 +112,35 @@ def test_kernel_choice_follows_the_robot_alone_unless_tile_small(golden_dir):
     assert blk == 513 and np.array_equal(small_small, small_default)  # small robots are never worth tiling: unchanged
     small_narrow, blk = run(small, {"wide": 0})
     assert blk == 256 and np.abs(small_narrow[:, :8] - small_default[:, :8]).max() < 1e-11   # resident on request: other summation order
+
+
+def test_one_tiled_robot_inside_a_large_resident_batch(tmp_path):
+    """A lattice of more than 1024 voxels (tiled kernel: its tiles wait for each other and must all be on the chip) among hundreds of
+    robots of the one-workgroup-per-robot kernels: the tiled launches run after the launch groups, not next to them (a tile launch is
+    sized for an empty chip; placed tiles would spin on CUs the other workgroups occupy).  The big robot must come out bit for bit as
+    when it is evaluated alone, and so must a small one."""
+    from evosoro_amd import engine as eng_mod, workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.05, fitness_eval_init_time=0.01)
+    inds = [workloads.make_individual(0, workloads.full_material(11, 3))] + [workloads.random_robot(1 + i, (6, 6, 6), 50 + i) for i in range(300)]
+    paths = []
+    for ind in inds:
+        write_voxelyze_file(sim, Env(), ind, str(tmp_path), "mix")
+        paths.append(str(tmp_path / "voxelyzeFiles" / ("mix--id_%05i.vxa" % ind.id)))
+
+    def run(which):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 1); eng.set_option("tiles_per_robot", 0); eng.set_option("wide", 1)     # the engine's own policy
+            eng.add_vxa_files([paths[i] for i in which])
+            eng.step(300)
+            assert all(eng.result(k).status in (eng_mod.ROBOT_PENDING, eng_mod.ROBOT_FINISHED) for k in range(len(which)))
+            return [eng.state(k) for k in range(len(which))], eng.counters()
+
+    batch, counters = run(list(range(len(paths))))
+    assert counters.dominant_block == 513          # most voxel-steps are the small robots' (wide kernel); the 1331-voxel lattice can only be tiled
+    big_alone, _ = run([0])
+    small_alone, _ = run([17])
+    assert np.array_equal(batch[0], big_alone[0])
+    assert np.array_equal(batch[17], small_alone[0])
