@@ -17,12 +17,11 @@ of the timed window).  After the timed region the fitness records of all ranks a
 With N > 1 the same line carries `strong`: BASELINE configs[2] as stated -- ONE population of 512, partitioned over the
 N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak run.
 
-READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 1024 steps (engine option steps_per_launch), and a
-launch of a self-colliding population carries ~0.27 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
-robots run a ~0.17 ms collision broad-phase).  `--steps 20 --warmup 5` (what the round-end driver runs) therefore reports ~7.4-7.6e9
-voxel-steps/s (~47-48 us per step), the default `--steps 2000` ~1.13e10 (~31.4 us) -- same kernel, same population; `timed_region` in
-the line says which case it is.  (Round 1's line for `--steps 20` was 9.5e9, on CHEAPER physics: it timed steps 6-25 from rest;
-this one pre-advances past InitCmTime first, as the round-1 review asked.)
+READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 1024 steps (engine option steps_per_launch), a
+launch of a self-colliding population carries ~0.07 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
+robots run a ~0.04 ms collision broad-phase; 0.27 and 0.17 ms until round 3), and a call ~0.06 ms on the host.  `--steps 20 --warmup 5`
+(what the round-end driver runs) therefore reports ~1.0e10 voxel-steps/s (~36 us per step; round 2: 7.4e9), the default `--steps 2000`
+~1.16e10 (~30.7 us) -- same kernel, same population; `timed_region` in the line says which case it is.
 
 The JSON line also carries
   roofline      HBM: algorithmic bytes (224*Nvox + 144*Nbond per voxel-step) of the dominant kernel over its
@@ -420,12 +419,12 @@ def main():
                     "launches": int(c1.dominant_launches),          # (of the timed call: this counter is per call, not cumulative)
                     "mean_steps_per_launch": args.steps / max(1, int(c1.dominant_launches)),
                     "note": "a launch of the resident kernel ends with its slowest workgroup and carries a fixed cost: ~0.02 ms for a "
-                            "population without self-collision, ~0.27 ms for this one (prologue/epilogue of two robots per CU ~0.04 ms; the "
-                            "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.17 ms per run, ~50 of 512 robots in "
-                            "any 20-step launch).  Per step WITHOUT that cost: ~30.5 us.  --steps 20 times ONE 20-step launch (~47-48 us per "
-                            "step, ~7.4-7.6e9 voxel-steps/s); the default --steps 2000 times two launches of up to 1024 steps (~31.5 us, ~1.13e10; eight launches of 250 "
-                            "steps until late in round 2: ~32.2 us).  "
-                            "DESIGN.md section 4 'The cost of a launch'"},
+                            "population without self-collision, ~0.07 ms for this one (prologue/epilogue of two robots per CU ~0.04 ms; the "
+                            "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.04 ms per run, ~50 of 512 robots in "
+                            "any 20-step launch; 0.27 / 0.17 ms until round 3); a call costs ~0.06 ms on the host.  Per step WITHOUT those: "
+                            "~30.4 us.  --steps 20 times ONE 20-step launch (~36 us per step, ~1.0e10 voxel-steps/s); the default "
+                            "--steps 2000 times two launches of up to 1024 steps (~30.7 us, ~1.16e10).  "
+                            "DESIGN.md section 4 'The cost of a launch' and 'Measured (round 3)'"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,
             }

@@ -80,7 +80,7 @@ private:
     int graph_steps_ = 32;                     // streaming path: step rounds captured per hipGraph launch (0 = plain launches)
     int dbg_ = 0;
     bool fused_ = true;                        // one-workgroup-per-robot fused kernel when every robot has <= 1024 voxels
-    // fused and tiled paths: time steps per kernel launch.  A launch of a self-colliding population carries ~0.27 ms of fixed cost (it
+    // fused and tiled paths: time steps per kernel launch.  A launch of a self-colliding population carries ~0.07 ms of fixed cost (0.27 ms until round 3; it
     // ends with its slowest workgroup: DESIGN.md "The cost of a launch"); a whole evaluation of the bench population (7806 steps),
     // us per step by launch length: 256: 31.2 | 512: 30.7 | 1024: 30.6 | 2048: 30.6 | 8192 (one launch): 30.3.  (256 until late in round 2.)
     int steps_per_launch_ = 1024;

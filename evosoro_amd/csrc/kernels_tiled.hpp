@@ -551,8 +551,20 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         // ---- 2. workers: bond phase, every bond with an owned end, all axes in one round.  Service wavefront, on steps that do
         // not speculate: the per-robot barrier
         bool div = false;
+        double dt_prev_spec = 0.0;             // (service wavefront, speculating step: rs.dt_prev as it was before the next step's control overwrote it)
         if (svc) {
             if (!speculate) { robot_barrier(mvq, tag, mg, go, K, rs.dt_prev); VXH_TT_MARK(2) }
+            else {
+                // Speculating step: the NEXT step's control now, while the workers are in the bond phase and this wavefront has nothing
+                // to do (it shares no field with the horizon update but dt_prev, handed over by value; nothing a worker reads before
+                // the next step: K stays, Knext is written).  Until round 3 it ran after barrier (B), in front of the per-robot
+                // barrier -- 4 k cycles of one lane's serial work (two snapshots of the control block, the stop rule, a sincos) with
+                // the workers done with their 5.7 k-cycle voxel phase and waiting at (C) for this wavefront: a third of the step.
+                // If the barrier then reports that the robot stopped a step ago, the control block goes back two snapshots instead of one.
+                dt_prev_spec = rs.dt_prev;
+                if (ctl_thread) { rs_bak2 = rs_bak; rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
+                VXH_TT_MARK(7)
+            }
         } else if (go && !s_abort) {
             for (int b = tid; b < nb; b += BLOCK) {
                 const int e = bent[b];
@@ -649,13 +661,12 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             }
             if (svc && attempt == 0) {
                 if (speculate) {
-                    // the next step's control first (it shares no field with the horizon update but dt_prev, handed over by
-                    // value): it is done by the time the per-robot barrier resolves.  If the barrier then reports that the robot
-                    // stopped a step ago, the control block goes back two snapshots instead of one.
-                    const double dt_prev = rs.dt_prev;
-                    if (ctl_thread) { rs_bak2 = rs_bak; rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
-                    VXH_TT_MARK(7)
-                    const bool neg = robot_barrier(mvq, tag, mg, go, K, dt_prev);
+                    // the per-robot barrier of this step, behind the voxel phase of the workers: the words are requested afresh (the
+                    // copies requested at the top of the step are from before the other tiles published them)
+#pragma unroll
+                    for (int c = 0; c < MVC; ++c)
+                        if (tid - BLOCK + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(tid - BLOCK + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
+                    const bool neg = robot_barrier(mvq, tag, mg, go, K, dt_prev_spec);
                     VXH_TT_MARK(2)
                     VXH_TS(5, ctl_thread)
                     if (ctl_thread) {

@@ -103,8 +103,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
     // roles of this thread: the translation of voxel `tid` (valid), the rotation + size of voxel `la` (angr); the same voxel unless the
     // robot is small enough to give the two halves to different wavefronts
     const bool split = 2 * nvox <= BLOCK;
-    const int la = tid - (split ? BLOCK / 2 : 0);
-    const bool valid = tid < nvox, angr = la >= 0 && la < nvox;
+    // ... to wavefronts on OTHER SIMDs where that is possible (wavefront w sits on SIMD w % 4): the rotation halves take the
+    // wavefronts from the top down -- 7, 6, 5, ... for voxels 0-63, 64-127, ... -- so that a robot of up to 192 voxels has its three
+    // translation wavefronts (the slowest: floor and friction) on SIMDs 0 1 2 and its rotation wavefronts on SIMDs 3 2 1
+    const int la = split ? ((BLOCK / 64 - 1 - (tid >> 6)) << 6) + (tid & 63) : tid;
+    const bool valid = tid < nvox, angr = la >= 0 && la < nvox && (!split || tid >= BLOCK / 2);
     const int v = base + tid, va = base + la;
     if (tid == 0) rs = B.rstate[r];
     double* const tabs = rec + R.wregion;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
         __syncthreads();
     };
 
-    const bool ctl_thread = tid == BLOCK - 64;
+    const bool ctl_thread = tid == (split ? 3 * 64 : BLOCK - 64);      // (split: wavefront 3 has the fewest voxels of either kind; else the last one)
     if (ctl_thread) { fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]); fused_control_horizon(R, rs, s_ctl[0]); s_div = 0; }
     rows_to_lds();
     __syncthreads();                           // control of the first step + every voxel's pose visible

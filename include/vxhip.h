@@ -138,7 +138,12 @@ int  vxh_create(vxh_engine** out, int variant, int device_id);
 /* One handle over several GPUs of the node: the robots are partitioned over the devices by cost (voxels x
  * planned steps, largest first) at the first vxh_run / vxh_step after an addition, every device steps its share from its own host
  * thread, and every other call works on the global robot numbering as with one device.  (The results of one process live in its
- * host memory: no collective is involved; the RCCL gather belongs to the one-process-per-GPU route, evosoro_amd/parallel.py.) */
+ * host memory: no collective is involved; the RCCL gather belongs to the one-process-per-GPU route, evosoro_amd/parallel.py.)
+ * The SAME device id given more than once makes several engines on that one GPU, and such a handle PIPELINES a generation handed
+ * over with vxh_add_robots: the additions are checked and copied (everything that can be refused is refused there), and vxh_run
+ * builds, uploads and launches chunk after chunk -- one per engine -- before it waits for the first, so the device steps chunk k
+ * while the host cores build chunk k + 1.  Results do not depend on it, bit for bit.  A reader before the run (vxh_robot_dims ...)
+ * builds on demand; a generation with a lattice of more than 1024 voxels is not pipelined (its kernel must own the device). */
 int  vxh_create_multi(vxh_engine** out, int variant, const int* device_ids, int n_devices);
 void vxh_destroy(vxh_engine* e);
 
@@ -207,8 +212,9 @@ int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long 
  *                       vxh_reset (VXH_ERR_STATE once a step has been taken).  The tiles of a robot wait for each other on the
  *                       device: an engine that tiles must own its GPU (with another process on the same GPU set "tiled" to 0).
  *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 1024).  A launch of a self-colliding population
- *                       carries ~0.27 ms of fixed cost, so vxh_step(e, n) with a small n is paid for: 20 steps at a time run at
- *                       ~47 us per step where 1000 at a time run at ~31.5 (512 robots of 10x10x10).
+ *                       carries ~0.07 ms of fixed cost (0.27 until round 3), and a call ~0.06 ms on the host, so vxh_step(e, n) with a
+ *                       small n is paid for: 20 steps at a time run at ~36 us per step where 1000 at a time run at ~30.5 (512 robots
+ *                       of 10x10x10).
  *   "fused"             0 = robots the tiled kernel does not take go through the streaming kernels (cross-checks)
  *   "graph_steps"       streaming kernels: step rounds per captured hipGraph (0 = plain launches)
  *   "host_results"      1 = vxh_get_result evaluates every tag on the host from the downloaded voxel state instead of from the

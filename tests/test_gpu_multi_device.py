@@ -105,3 +105,51 @@ def test_more_engines_than_robots_and_reuse_of_the_handle(golden_dir):
         many.add_vxa_file(paths[1])                       # a different population afterwards
         many.run()
         assert _same(many.result(0), want[1])
+
+
+def test_a_generation_pipelined_over_two_engines_of_one_device(tmp_path):
+    """vxh_create_multi with a repeated device id + vxh_add_robots: the additions are only checked and copied, vxh_run builds, uploads
+    and launches chunk after chunk before it waits for the first.  Nothing about a robot's result may
+    depend on that: bit for bit the records of the one-engine route; a refused addition leaves nothing behind; readers and later
+    additions see the robots whether or not they have been built yet."""
+    from evosoro_amd import engine as eng_mod, workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file, phenotype_arrays
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.06, fitness_eval_init_time=0.02)
+    pop = [workloads.random_robot(i, (6, 6, 6), 20 + i, phase_offset=(i % 2 == 0)) for i in range(21)] + \
+          [workloads.random_robot(21 + i, (9, 9, 9), 70 + i) for i in range(4)]
+    template = write_voxelyze_file(sim, Env(), pop[0], str(tmp_path), "t", write=False, want_text=True)[1]
+    robots = []
+    for ind in pop:
+        material, layers = phenotype_arrays(ind)
+        robots.append((material, layers, None))
+
+    def run(device):
+        with eng_mod.Engine(eng_mod.VOXCAD, device) as eng:
+            eng.set_option("tiled", 0)                       # (engines that share a device do not tile: the same kernels on both sides,
+            first = eng.add_robots(template, robots[:10])    # whatever VXH_ENGINE_OPTIONS says)
+            second = eng.add_robots(template, robots[10:])
+            assert (first, second, eng.num_robots()) == (0, 10, len(robots))
+            eng.run()
+            return [eng.result(i) for i in range(len(robots))], [eng.state(i) for i in (0, 9, 10, 24)]
+
+    want, want_states = run(0)
+    got, got_states = run((0, 0))
+    for i in range(len(robots)):
+        assert got[i].status == eng_mod.ROBOT_FINISHED and _same(got[i], want[i]), i
+    for a, b in zip(got_states, want_states):
+        assert np.array_equal(a, b)
+    with eng_mod.Engine(eng_mod.VOXCAD, (0, 0)) as eng:
+        eng.set_option("tiled", 0)
+        eng.add_robots(template, robots[:5])
+        bad = np.array(robots[5][0]).copy()
+        bad[0, 0, 0] = 9                                     # a material index outside the palette: refused at the addition
+        with pytest.raises(eng_mod.VxhError):
+            eng.add_robots(template, [(bad, robots[5][1], None)])
+        assert eng.num_robots() == 5
+        assert eng.dims(3)["nvox"] == want[3].nvox           # a reader before the run: the models are built on demand
+        eng.add_robots(template, robots[5:7])
+        eng.run()
+        for i in range(7):
+            assert _same(eng.result(i), want[i]), i
