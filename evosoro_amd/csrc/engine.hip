@@ -429,6 +429,8 @@ void Engine::clear()
         if (h[2103]) fprintf(stderr, "   prologue of the resident kernel, cycle sums of the first thread over all workgroup-launches: tables + first barrier %.3e | state load, zeroing, "
                              "first control %.3e | rows_to_lds %.3e  = (its parts, incl. the calls after broad-phase runs) ordinal -> count loads + barrier %.3e | scan + allotment %.3e | copy + barrier %.3e\n",
                              (double)h[2103], (double)h[2106], (double)h[2113], (double)h[2114], (double)h[2115], (double)h[2116]);
+        if (h[2131]) fprintf(stderr, "   drag, facet pass (first thread, cycle sums): barrier behind the vertices %.3e | facet loop %.3e | barrier %.3e | per-voxel sums %.3e | barrier %.3e\n",
+                             (double)h[2130], (double)h[2131], (double)h[2132], (double)h[2133], (double)h[2134]);
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};
         static const char* tnames[8] = {"halo-wait", "bond", "svc:poll", "barB", "latch/rebuild", "voxel", "barC+mv", "svc:reduce+horizon"};
         const bool tiled = !dev_->tile_launches.empty();
@@ -538,7 +540,7 @@ void Engine::prepare()
     auto wide_layout = [&](const RobotModel& M) {
         WideLayout W;
         const bool in_fluid = variant_ == 1 && M.vxa.fluid_env;
-        const int scratch = 12 * WIDE_BLOCK + (in_fluid ? 3 * M.nmv : 0);
+        const int scratch = 12 * WIDE_BLOCK + (in_fluid ? 3 * ((M.nvox + 63) / 64 * 64) + 3 * M.nmv : 0);
         W.zidx = std::max(M.nbond, (scratch + VXH_WIDE_REC - 1) / VXH_WIDE_REC);
         W.region = (VXH_WIDE_REC * (W.zidx + 1) + 1) & ~1;
         return W;

@@ -43,7 +43,11 @@ enum { VXH_FUSED_STATIC_LDS = 448 };      // upper bound of the kernel's static 
 #define VXH_T_FLUSH if (B.prof && (threadIdx.x & 63) == 0) { for (int k = 0; k < 6; ++k) atomicAdd(&B.prof[(threadIdx.x >> 6) * 8 + k], t_acc[k]); }
 #define VXH_T_SUB_BEGIN unsigned long long t_sub = __builtin_readcyclecounter();
 #define VXH_T_SUB(k) { const unsigned long long t_now = __builtin_readcyclecounter(); if (B.prof && (threadIdx.x & 63) == 0) atomicAdd(&B.prof[(threadIdx.x >> 6) * 8 + (k)], t_now - t_sub); t_sub = t_now; }
+#define VXH_T_DRAG_BEGIN unsigned long long t_dr = __builtin_readcyclecounter();
+#define VXH_T_DRAG(slot) { const unsigned long long t_now = __builtin_readcyclecounter(); if (B.prof && threadIdx.x == 0) atomicAdd(&B.prof[2130 + (slot)], t_now - t_dr); t_dr = t_now; }
 #else
+#define VXH_T_DRAG_BEGIN
+#define VXH_T_DRAG(slot)
 #define VXH_T_DECL
 #define VXH_T_MARK(k)
 #define VXH_T_FLUSH
@@ -465,6 +469,7 @@ template <int BLOCK>
 struct DragCache {
     static constexpr bool KEEP = BLOCK <= 512;
     VertRec vert0, vert1; d3 v00, v01; FacetRec f0, f1, f2, f3;
+    int my_first = 0, my_count = 0;                 // the voxel's own facets (set by the kernel: it knows the thread's voxel)
     __device__ __forceinline__ void load(const DBatch& B, const DRobot& R, int tid)
     {
         vert0 = load_vert(B, R, tid); vert1 = load_vert(B, R, tid + BLOCK);
@@ -477,9 +482,15 @@ struct DragCache {
 // robot's slice of DBatch::strain with plane stride nv (1024-thread variant, where LDS is full).
 // `scr`: the accumulator tile, idle until the bond rounds: first the voxels' corner positions (four or two of the eight
 // corners at a time: twelve or six planes), then every voxel's velocity (and its direction), then the facets' drag.
-template <int BLOCK, int SCR_DOUBLES>
+// LEAN (the wide kernel, where a step is latency, not instruction count): the voxels' velocities live in planes of their own
+// (`spd_ext`, plane stride `spd_stride`) and are published before the vertex pass instead of behind a barrier of their own; the whole
+// tile then takes the facets' contributions -- one chunk of up to SCR_DOUBLES / 3 facets, where the resident kernel needs two for a
+// robot of 8^3 --; a voxel's sum over its facets requests four contributions at a time (same order of additions); the tile is not
+// re-zeroed (the wide kernel's bond records are written, not accumulated).  Same operations per vertex and facet, same sums: same bits.
+template <int BLOCK, int SCR_DOUBLES, bool LEAN = false>
 __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const double* ps, const double* st, unsigned st_stride, double* sh,
-                                         double* scr, bool valid, int v, d3 lm, double mass_inv, const DragCache<BLOCK>& kept)
+                                         double* scr, bool valid, int v, d3 lm, double mass_inv, const DragCache<BLOCK>& kept,
+                                         double* spd_ext = nullptr, int spd_stride = 0)
 {
     constexpr bool WIDE = SCR_DOUBLES >= 12 * BLOCK;
     constexpr int CPP = WIDE ? 4 : 2;               // voxel corners per pass
@@ -506,6 +517,17 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
     // 1024-thread variant (six planes, short of registers) is faster when every vertex recomputes its corners itself (same
     // operations): measured 42.4 against 46.5 us per step on dense 10^3 swimmers.
     constexpr bool GATHER = BLOCK < 1024;
+    constexpr bool SDIR = WIDE && !LEAN;                            // the velocity's direction published next to it (else: per facet)
+    double* const spd = LEAN ? spd_ext : scr;                       // [VPL][sstr]
+    const int sstr = LEAN ? spd_stride : BLOCK;
+    auto publish_speed = [&]() {                                    // every voxel's velocity for the facet pass
+        if (valid) {
+            const d3 sp = lm * mass_inv;
+            spd[tid] = sp.x; spd[sstr + tid] = sp.y; spd[2 * sstr + tid] = sp.z;
+            if constexpr (SDIR) { const d3 sd = normalized3(sp); spd[3 * BLOCK + tid] = sd.x; spd[4 * BLOCK + tid] = sd.y; spd[5 * BLOCK + tid] = sd.z; }
+        }
+    };
+    if constexpr (LEAN) publish_speed();
     if constexpr (GATHER) {
         d3 vp = mk3(0, 0, 0), hp = mk3(0, 0, 0), hn = mk3(0, 0, 0);
         RotFwd M;
@@ -536,7 +558,8 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
                 VertRec vr;
                 vr.w0 = s0 ? vert0.w0 : (s1 ? vert1.w0 : vnext.w0); vr.w1 = s0 ? vert0.w1 : (s1 ? vert1.w1 : vnext.w1); vr.w2 = s0 ? vert0.w2 : (s1 ? vert1.w2 : vnext.w2);
                 const d3 v0 = mk3(s0 ? v00.x : (s1 ? v01.x : v0next.x), s0 ? v00.y : (s1 ? v01.y : v0next.y), s0 ? v00.z : (s1 ? v01.z : v0next.z));
-                if (k + 1 >= NKV) { vnext = load_vert(B, R, i + BLOCK); if (p0 + CPP == 8) v0next = load_vert_v0(B, R, i + BLOCK); }   // one iteration ahead
+                if (k + 1 >= NKV && i + BLOCK < nmv) { vnext = load_vert(B, R, i + BLOCK); if (p0 + CPP == 8) v0next = load_vert_v0(B, R, i + BLOCK); }   // one iteration ahead (a request for
+                                                                      // nothing would still be waited for at the barrier below)
                 d3 part = p0 == 0 ? mk3(0, 0, 0) : mk3(sh[i], sh[nmv + i], sh[2 * nmv + i]);
     #pragma unroll
                 for (int c = 0; c < CPP; ++c) {
@@ -565,7 +588,7 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
             VertRec vr;
             vr.w0 = s0 ? vert0.w0 : (s1 ? vert1.w0 : vnext.w0); vr.w1 = s0 ? vert0.w1 : (s1 ? vert1.w1 : vnext.w1); vr.w2 = s0 ? vert0.w2 : (s1 ? vert1.w2 : vnext.w2);
             const d3 v0 = mk3(s0 ? v00.x : (s1 ? v01.x : v0next.x), s0 ? v00.y : (s1 ? v01.y : v0next.y), s0 ? v00.z : (s1 ? v01.z : v0next.z));
-            if (k + 1 >= NKV) { vnext = load_vert(B, R, i + BLOCK); v0next = load_vert_v0(B, R, i + BLOCK); }   // one iteration ahead
+            if (k + 1 >= NKV && i + BLOCK < nmv) { vnext = load_vert(B, R, i + BLOCK); v0next = load_vert_v0(B, R, i + BLOCK); }   // one iteration ahead
             d3 part = mk3(0, 0, 0);
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
@@ -585,23 +608,20 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
         }
     }
     VXH_T_SUB(6)
+    VXH_T_DRAG_BEGIN
     // Phase 2, one thread per FACET (the robot's facets in the reference's order: per voxel, faces +X,-X,+Y,-Y,+Z,-Z, two
     // triangles each), so the wavefronts are full whatever the number of exposed faces of a voxel.  `scr` holds every
     // voxel's velocity (and its direction), then chunk after chunk the facets' contributions, which each voxel sums in
     // facet order.
     const int nfac = R.nfacet;
-    constexpr int VPL = WIDE ? 6 : 3;                               // planes of per-voxel data
+    constexpr int VPL = LEAN ? 0 : (WIDE ? 6 : 3);                  // planes of per-voxel data inside the tile
     constexpr int CHF = (SCR_DOUBLES / BLOCK - VPL) * BLOCK / 3;    // facets per chunk
-    double* const spd = scr;                                        // [VPL][BLOCK]
     double* const fd = scr + VPL * BLOCK;                           // [3][CHF] drag of the facets of the current chunk
-    if (valid) {
-        const d3 sp = lm * mass_inv;
-        spd[tid] = sp.x; spd[BLOCK + tid] = sp.y; spd[2 * BLOCK + tid] = sp.z;
-        if constexpr (WIDE) { const d3 sd = normalized3(sp); spd[3 * BLOCK + tid] = sd.x; spd[4 * BLOCK + tid] = sd.y; spd[5 * BLOCK + tid] = sd.z; }
-    }
-    __syncthreads();
+    if constexpr (!LEAN) publish_speed();
+    if constexpr (!(LEAN && GATHER)) __syncthreads();               // (LEAN: published before the vertex pass, whose last barrier is enough)
+    VXH_T_DRAG(0)
     d3 drag = mk3(0, 0, 0);
-    const int my_first = valid ? B.facet_first[v] : 0, my_count = valid ? (int)B.facet_count[v] : 0;
+    const int my_first = KEEP ? kept.my_first : (valid ? B.facet_first[v] : 0), my_count = KEEP ? kept.my_count : (valid ? (int)B.facet_count[v] : 0);
     static_assert(CHF % BLOCK == 0, "a thread's facets are tid + m * BLOCK in every chunk");
     for (int c0 = 0; c0 < nfac; c0 += CHF) {
         int m = c0 / BLOCK;
@@ -617,23 +637,40 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
                     rec.ic = m == 0 ? kc[0] : (m == 1 ? kc[1] : (m == 2 ? kc[2] : kc[3]));
                 }
             }
-            if (m + 1 >= NKF) next = load_facet(B, R, f + BLOCK);     // one iteration ahead
+            if (m + 1 >= NKF && f + BLOCK < min(nfac, c0 + CHF)) next = load_facet(B, R, f + BLOCK);     // one iteration ahead
             const int u = rec.u, ia = rec.ia, ib = rec.ib, ic = rec.ic;
-            const d3 speed = mk3(spd[u], spd[BLOCK + u], spd[2 * BLOCK + u]);
+            const d3 speed = mk3(spd[u], spd[sstr + u], spd[2 * sstr + u]);
             d3 sdir;
-            if constexpr (WIDE) sdir = mk3(spd[3 * BLOCK + u], spd[4 * BLOCK + u], spd[5 * BLOCK + u]);
+            if constexpr (SDIR) sdir = mk3(spd[3 * BLOCK + u], spd[4 * BLOCK + u], spd[5 * BLOCK + u]);
             else sdir = normalized3(speed);
             const d3 A = mk3(sh[ia], sh[nmv + ia], sh[2 * nmv + ia]);
             const d3 contrib = facet_drag_force(speed, sdir, A, mk3(sh[ib], sh[nmv + ib], sh[2 * nmv + ib]), mk3(sh[ic], sh[nmv + ic], sh[2 * nmv + ic]), R.drag_coef);
             fd[f - c0] = contrib.x; fd[CHF + (f - c0)] = contrib.y; fd[2 * CHF + (f - c0)] = contrib.z;
         }
+        VXH_T_DRAG(1)
         __syncthreads();
-        for (int k = max(my_first, c0); k < min(my_first + my_count, c0 + CHF); ++k)     // my facets of this chunk, in order
-            drag = drag + mk3(fd[k - c0], fd[CHF + (k - c0)], fd[2 * CHF + (k - c0)]);
+        VXH_T_DRAG(2)
+        if constexpr (LEAN) {
+            const int ke = min(my_first + my_count, c0 + CHF);
+            for (int k0 = max(my_first, c0); k0 < ke; k0 += 4) {                         // my facets of this chunk, in order, four requests in flight
+                d3 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int at = min(k0 + j, ke - 1) - c0; t[j] = mk3(fd[at], fd[CHF + at], fd[2 * CHF + at]); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k0 + j < ke) drag = drag + t[j];
+            }
+        } else {
+            for (int k = max(my_first, c0); k < min(my_first + my_count, c0 + CHF); ++k)     // my facets of this chunk, in order
+                drag = drag + mk3(fd[k - c0], fd[CHF + (k - c0)], fd[2 * CHF + (k - c0)]);
+        }
+        VXH_T_DRAG(3)
+        __syncthreads();
+        VXH_T_DRAG(4)
+    }
+    if constexpr (!LEAN) {
+        for (int k = tid; k < SCR_DOUBLES; k += BLOCK) scr[k] = 0.0;    // the accumulators must be zero when the bond rounds start
         __syncthreads();
     }
-    for (int k = tid; k < SCR_DOUBLES; k += BLOCK) scr[k] = 0.0;    // the accumulators must be zero when the bond rounds start
-    __syncthreads();
     VXH_T_SUB(7)
     return drag;
 }
@@ -882,7 +919,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     for (int k = 0; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;
     const FetchLds<BLOCK> fetch{ps, base};
     DragCache<BLOCK> dcache;
-    if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) dcache.load(B, R, tid); }
+    if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) { dcache.load(B, R, tid); if (valid) { dcache.my_first = B.facet_first[v]; dcache.my_count = (int)B.facet_count[v]; } } }
     // my contact row: partner count | (start of the workgroup's LDS copy of it + 1) << VXH_ROWD_BITS; s_seg: where the rows of each wavefront's
     // lanes start in the copy and how many pairs they hold (-1: they did not fit, that wavefront reads its rows from memory).
     // Refreshed after every broad-phase run.  (every thread calls: barriers inside)

@@ -19,7 +19,7 @@
 //   rec  [region]     bond records, VXH_WIDE_REC doubles each (13: twelve values + one of padding, 26 dwords -- a wavefront's
 //                     64-bit accesses at that stride are conflict-free); record DRobot::wzidx stays zero: what the missing
 //                     directions of a voxel point at.  Between steps the same memory is the scratch of latch / broad-phase /
-//                     drag (12 * BLOCK doubles, then the mesh vertices of a robot in a fluid), all below the zero record.
+//                     drag (12 * BLOCK doubles, then the velocities and the mesh vertices of a robot in a fluid), all below the zero record.
 //   tabs              class tables (not TABG)
 //   st   [6][BLOCK]   MESH: directional strains
 //   cmask, rc_a1, rc_code   contact rows of colliding robots (rows_to_lds)
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
         vct = (const DVoxClass*)(tabs + nbd);
     }
     double* const st = tabs + nbd + nvd;                       // MESH: [6][BLOCK]
-    double* const mesh = rec + 12 * BLOCK;                     // mesh vertices of a robot in a fluid: inside the record region, behind the scratch
+    const int nvs = (nvox + 63) & ~63;
+    double* const mesh = rec + 12 * BLOCK + 3 * nvs;           // a robot in a fluid: the voxels' velocities [3][nvs] and the mesh vertices, inside the record region, behind the scratch
     unsigned long long* const cmask = (unsigned long long*)(st + (MESH ? 6 * BLOCK : 0));
     double* const rc_a1 = (double*)cmask + BLOCK;
     const int pool_cap = (R.flags & RF_SELF_COL) ? max(0, (int)((lds_doubles - (int)(rc_a1 - lds)) * 2 / 3) - 1) : 0;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
     }
     const FetchLds<BLOCK> fetch{ps, base};
     DragCache<BLOCK> dcache;
-    if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) dcache.load(B, R, tid); }
+    if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) { dcache.load(B, R, tid); if (valid) { dcache.my_first = B.facet_first[v]; dcache.my_count = (int)B.facet_count[v]; } } }
     // my contact row (see k_robot_steps): partner count | (start of the LDS copy + 1) << VXH_ROWD_BITS
     int rowd = 0;
     auto rows_to_lds = [&]() {
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
         }
         d3 drag = mk3(0, 0, 0);
         const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
-        if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK, 12 * BLOCK>(B, R, ps, st, (unsigned)BLOCK, mesh, rec, valid, vv, lm, Cl.mass_inv, dcache); }
+        if constexpr (MESH) { if (fluid) drag = fused_drag<BLOCK, 12 * BLOCK, true>(B, R, ps, st, (unsigned)BLOCK, mesh, rec, valid, vv, lm, Cl.mass_inv, dcache, rec + 12 * BLOCK, nvs); }
         const bool damp_on = (kf & 32) != 0;
         VXH_T_MARK(1)
 
