@@ -410,7 +410,7 @@ void Engine::clear()
         if (std::getenv("VXH_PROF_TILES")) {    // the first tiles at one step of the last launch: real-time counter (10 ns ticks) at the step's boundaries
             unsigned long long t0 = ~0ull;
             for (int t = 0; t < std::min(256, dev_->B.n_tiles); ++t) if (h[128 + t * 8]) t0 = std::min(t0, h[128 + t * 8]);
-            fprintf(stderr, "tile: top  halo-done  bond-done  voxel-done  C-passed | svc: barrier-resolved control-done | mv-published   (us after the first tile's top)\n");
+            fprintf(stderr, "tile: top  halo-done  bond-done  voxel-done  C-passed | svc: barrier-resolved | next top | mv-published   (us after the first tile's top)\n");
             for (int t = 0; t < std::min(256, dev_->B.n_tiles); ++t) {
                 fprintf(stderr, "tile %3d:", t);
                 for (int k : {0, 1, 2, 3, 4, 5, 6, 7}) fprintf(stderr, " %7.2f", 0.01 * (double)(long long)(h[128 + t * 8 + k] - t0));

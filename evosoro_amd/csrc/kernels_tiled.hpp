@@ -487,6 +487,9 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         FusedCtl& Knext = s_ctl[(it + 1) & 1];
         VXH_TT_MARK(6)
         VXH_TS(0, tid == 0)
+#ifdef VXH_PHASE_TIMING
+        if (B.prof && it == VXH_TS_STEP + 1 && tid == 0 && ti < 256) B.prof[128 + ti * 8 + 6] = __builtin_amdgcn_s_memrealtime();   // (the next step's top, in the place of "control done")
+#endif
         const unsigned ringn = ring == 2 ? 0 : ring + 1, ringp = ring == 0 ? 2 : ring - 1;
         const unsigned long long* const xq = B.xch + (size_t)ring * xbuf;      // poses at the start of this step
         unsigned long long* const xqn = B.xch + (size_t)ringn * xbuf;          // ... of the next one
@@ -619,6 +622,10 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         }
         VXH_TT_MARK(4)
 
+        // (Tried in round 3 and taken out: the two halves of the voxel update -- voxel_update_lin / voxel_update_ang, independent within a
+        // step -- on different wavefronts, as the wide kernel does: a 64-voxel tile has one wavefront of voxels and three without.  Each
+        // half then took as long as the two together had (per-wave phase shares 28.8 % and 33.4 % against 31.7 %), scratch went from
+        // 236 to 368 bytes per lane, and the 20^3 lattice from 10.4 to 11.1 us per step.)
         // ---- 3. voxel phase; on a speculating step the service wavefront resolves the per-robot barrier meanwhile, and the phase
         // is redone (attempt 1) after the broad-phase if the lists turn out to have been due for a rebuild
         const bool diverged_here = s_div != 0;
@@ -681,7 +688,6 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                     if (ctl_thread && !s_abort) { rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
                     VXH_TT_MARK(7)
                 }
-                VXH_TS(6, ctl_thread)
             }
             if (!svc) {
                 // the tile's max |v|^2 goes out with the last worker wave to finish, not behind the workgroup barrier

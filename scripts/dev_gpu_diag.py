@@ -751,6 +751,10 @@ if __name__ == "__main__" and "drift6" in sys.argv[1:]:
         print("%s: %d steps, net mode changes %d, steps where the counts of large-angle bonds differ: %d %s" % (name, nsteps, flips, len(bad), bad[:10]), flush=True)
 
 
+if __name__ == "__main__" and sys.argv[1:2] and sys.argv[1] == "cfg4l":      # configs[4] over ~2000 steps, like the bench line's other_configs
+    timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.13, Env(), {}, full=True)
+
+
 if __name__ == "__main__" and sys.argv[1:2] and sys.argv[1] in ("cfg1", "cfg3", "cfg4"):
     # one BASELINE config each, for the counter passes of scripts/profile_bench.sh
     env_w = Env()
