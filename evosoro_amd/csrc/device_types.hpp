@@ -123,6 +123,7 @@ struct DBatch {
     int dbg, pad1;                    // developer switches (scripts/dev_gpu_diag.py), 0 in production
     const DRobot* robot;
     DRobotState* rstate;
+    DRobotState* rstate_mirror;       // the same blocks in pinned host memory (or null): the resident kernels write a robot's block to both when a launch ends
     const int* wave_robot;            // [nv/64] robot of each 64-voxel group
     const DVoxClass* vclass_tab;      // per-robot class tables, concatenated (DRobot::vtab_begin / btab_begin)
     const DBondClass* bclass_tab;

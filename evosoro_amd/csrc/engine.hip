@@ -93,7 +93,7 @@ struct Engine::Device {
     struct Pending {
         bool active = false;
         long long todo = 0, launches = 0, tile_launch_count = 0;
-        bool fused = false, tiled = false, streaming = false;
+        bool fused = false, tiled = false, streaming = false, single = false;
         std::vector<int> steps_before;
         std::vector<long long> group_launches;
     } pending;
@@ -517,7 +517,7 @@ struct HostStages {
     {
         if (!on) return;
         const auto now = std::chrono::steady_clock::now();
-        char buf[96]; std::snprintf(buf, sizeof(buf), " %s %.1f ms |", what, 1e3 * std::chrono::duration<double>(now - t).count());
+        char buf[96]; std::snprintf(buf, sizeof(buf), " %s %.3f ms |", what, 1e3 * std::chrono::duration<double>(now - t).count());
         line += buf; t = now;
     }
     void print(const char* head) { if (on) std::fprintf(stderr, "%s:%s\n", head, line.c_str()); }
@@ -809,6 +809,18 @@ void Engine::prepare()
     B.n_robots = nr; B.nv = nv; B.dbg = dbg_;
     B.robot = D.upload(D.h_robot);
     B.rstate = D.upload(rstate);
+    {   // ... and their mirror in pinned host memory, which the resident kernels write as well (a call that runs one launch group and
+        // nothing else needs no copy back: ~10-15 us of a 0.7 ms call); start values for the robots no kernel touches
+        if (D.h_rstate_cap < (size_t)nr) {
+            if (D.h_rstate) HIP_OK(hipHostFree(D.h_rstate));
+            D.h_rstate = nullptr; D.h_rstate_cap = 0;
+            HIP_OK(hipHostMalloc((void**)&D.h_rstate, sizeof(DRobotState) * std::max(nr, 1), hipHostMallocDefault));
+            D.h_rstate_cap = (size_t)std::max(nr, 1);
+        }
+        std::memcpy(D.h_rstate, rstate.data(), sizeof(DRobotState) * nr);
+        void* dp = nullptr;
+        B.rstate_mirror = hipHostGetDevicePointer(&dp, D.h_rstate, 0) == hipSuccess ? (DRobotState*)dp : nullptr;
+    }
     B.wave_robot = D.upload(wave_robot);
     B.vclass_tab = D.upload(vtab);
     B.bclass_tab = D.upload(btab);
@@ -1187,7 +1199,9 @@ void Engine::advance_launch(long long max_rounds)
     std::vector<int>& steps_before = D.pending.steps_before;
     steps_before.assign(robots_.size(), 0);
     for (size_t r = 0; r < robots_.size(); ++r) steps_before[r] = host_.size() == robots_.size() ? host_[r].steps : 0;
+    HostStages hs_l;
     HIP_OK(hipEventRecord(D.ev0, D.stream));
+    hs_l.mark("first event");
     long long launches = 0;
     std::vector<long long>& group_launches = D.pending.group_launches;
     group_launches.assign(D.groups.size(), 0);
@@ -1202,9 +1216,9 @@ void Engine::advance_launch(long long max_rounds)
     if (fused) {
         const int iters = std::max(1, steps_per_launch_);
         for (auto& g : D.groups) {
-            hipStream_t gs = single ? D.stream : g.stream;
-            if (!single) HIP_OK(hipStreamWaitEvent(gs, D.ev0, 0));
-            HIP_OK(hipEventRecord(g.t0, gs));
+            if (single) break;               // (its span is the call's: ev0 .. ev1; every event record is a packet the command processor works through)
+            HIP_OK(hipStreamWaitEvent(g.stream, D.ev0, 0));
+            HIP_OK(hipEventRecord(g.t0, g.stream));
         }
         for (long long done = 0; done < todo || done == 0; done += iters) {
             for (size_t k = 0; k < D.groups.size(); ++k) {
@@ -1213,7 +1227,7 @@ void Engine::advance_launch(long long max_rounds)
                 ++launches; ++group_launches[k];
             }
         }
-        for (auto& g : D.groups) HIP_OK(hipEventRecord(g.t1, single ? D.stream : g.stream));
+        if (!single) for (auto& g : D.groups) HIP_OK(hipEventRecord(g.t1, g.stream));
     }
     long long tile_launch_count = 0;
     if (tiled) {
@@ -1276,10 +1290,13 @@ void Engine::advance_launch(long long max_rounds)
             HIP_OK(hipHostMalloc((void**)&D.h_rstate, sizeof(DRobotState) * nr, hipHostMallocDefault));
             D.h_rstate_cap = nr;
         }
-        HIP_OK(hipMemcpyAsync(D.h_rstate, B.rstate, sizeof(DRobotState) * nr, hipMemcpyDeviceToHost, D.stream));
+        if (!(single && B.rstate_mirror))      // (one launch group and nothing else: its kernel has written the mirror itself)
+            HIP_OK(hipMemcpyAsync(D.h_rstate, B.rstate, sizeof(DRobotState) * nr, hipMemcpyDeviceToHost, D.stream));
     }
+    hs_l.mark("kernels + last event queued");
+    hs_l.print("advance_launch");
     D.pending.active = true; D.pending.todo = todo; D.pending.launches = launches; D.pending.tile_launch_count = tile_launch_count;
-    D.pending.fused = fused; D.pending.tiled = tiled; D.pending.streaming = streaming;
+    D.pending.fused = fused; D.pending.tiled = tiled; D.pending.streaming = streaming; D.pending.single = single;
 }
 
 void Engine::advance_finish()
@@ -1303,7 +1320,6 @@ void Engine::advance_finish()
     hs.mark("wait for the GPU");
     download_control(true);
     hs.mark("control blocks back");
-    hs.print("advance");
 
     // dominant kernel of this call: the launch group that processed most voxel-steps (fused) / the whole call (streaming)
     std::vector<double> grp_vs(D.groups.size(), 0.0), grp_ab(D.groups.size(), 0.0);
@@ -1339,7 +1355,7 @@ void Engine::advance_finish()
             counters_.dominant_alg_bytes = rest_ab; counters_.dominant_voxel_steps = rest_vs;
         } else {
             float cms = 0;
-            HIP_OK(hipEventElapsedTime(&cms, D.groups[best].t0, D.groups[best].t1));
+            if (D.pending.single) cms = ms; else HIP_OK(hipEventElapsedTime(&cms, D.groups[best].t0, D.groups[best].t1));
             counters_.dominant_block = D.groups[best].block + (D.groups[best].wide ? 1 : 0); counters_.dominant_robots = D.groups[best].count;
             counters_.dominant_launches = group_launches[best]; counters_.dominant_seconds = cms * 1e-3;
             counters_.dominant_alg_bytes = grp_ab[best]; counters_.dominant_voxel_steps = grp_vs[best];
@@ -1349,6 +1365,8 @@ void Engine::advance_finish()
         counters_.dominant_launches = todo; counters_.dominant_seconds = ms * 1e-3;
         counters_.dominant_alg_bytes = all_ab - tile_ab; counters_.dominant_voxel_steps = all_vs - tile_vs;
     }
+    hs.mark("accounting");
+    hs.print("advance_finish");
 }
 
 void Engine::run()

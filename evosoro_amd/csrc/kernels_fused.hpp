@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #pragma unroll
     for (int a = 0; a < 3; ++a)
         if (entry[a] != -1) B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] = (unsigned char)((modebits >> (2 * a)) & 3u);
-    if (tid == 0) B.rstate[r] = rs;
+    if (tid == 0) { B.rstate[r] = rs; if (B.rstate_mirror) B.rstate_mirror[r] = rs; }
 #ifdef VXH_PHASE_TIMING
     __builtin_amdgcn_s_waitcnt(0);          // (the write-back has left the wavefront)
     if (!MESH && B.prof && (tid & 63) == 0) atomicAdd(&B.prof[(tid >> 6) * 8 + 7], __builtin_readcyclecounter() - t_loop_end);   // epilogue

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
     }
     if (e0 != -1) B.small_angle[(unsigned)((e0 >> 18) & 3) * nv + (base + (e0 & 511))] = (unsigned char)(modebits & 3u);
     if (e1 != -1) B.small_angle[(unsigned)((e1 >> 18) & 3) * nv + (base + (e1 & 511))] = (unsigned char)((modebits >> 2) & 3u);
-    if (tid == 0) B.rstate[r] = rs;
+    if (tid == 0) { B.rstate[r] = rs; if (B.rstate_mirror) B.rstate_mirror[r] = rs; }
 }
 
 }  // namespace vxh
