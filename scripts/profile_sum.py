@@ -78,16 +78,23 @@ if len(sys.argv) > 3:          # `profile_sum.py <out_root> <tag> tiled`: only t
         dur[r["Kernel_Name"]] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); cnt[r["Kernel_Name"]] += 1
     total = sum(dur.values()) or 1.0
     path = os.path.join(prof_dir, "%s_%s_kernel_stats.csv" % (tag, sub))
+    what = {"tiled": "python scripts/dev_gpu_diag.py tileprof (the populations are printed in profiles/%s_%s_run.log)" % (tag, sub),
+            "driver": "python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs (the command the round-end driver "
+                      "runs; its JSON line is in profiles/%s_%s_run.log)" % (tag, sub)}.get(sub, sub)
     with open(path, "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python scripts/dev_gpu_diag.py tileprof (the populations are printed in "
-                "profiles/%s_%s_run.log); durations in ns\n" % (tag, sub))
+        f.write("# rocprofv3 --kernel-trace --stats -- %s; durations in ns\n" % what)
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
         for k in sorted(dur, key=dur.get, reverse=True):
             f.write('"%s",%d,%.0f,%.1f,%.2f\n' % (k, cnt[k], dur[k], dur[k] / cnt[k], 100 * dur[k] / total))
+        if sub == "driver" and dur:
+            # every dispatch of the dominant kernel in time order: the pre-advance + warm-up launch, then the timed 20-step launch
+            dom = max(dur, key=dur.get)
+            disp = sorted((float(r["Start_Timestamp"]), float(r["End_Timestamp"])) for r in rows(sub, "kernel_trace.csv") if r["Kernel_Name"] == dom)
+            f.write("# dispatches of the dominant kernel in time order, ns: %s  (the last one is the timed launch of --steps 20)\n" % ", ".join("%.0f" % (b - a) for a, b in disp))
     log = os.path.join(out_root, "prof_%s_%s.log" % (tag, sub))
     if os.path.exists(log):
         with open(os.path.join(prof_dir, "%s_%s_run.log" % (tag, sub)), "w") as f:
-            f.write("".join(l for l in open(log) if l.startswith(("variant", "   broad"))))
+            f.write("".join(l for l in open(log) if l.startswith(("variant", "   broad", '{"metric"'))))
     print(open(path).read())
     sys.exit(0)
 
