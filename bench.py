@@ -19,8 +19,8 @@ N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak
 
 READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 1024 steps (engine option steps_per_launch), a
 launch of a self-colliding population carries ~0.07 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
-robots run a ~0.04 ms collision broad-phase; 0.27 and 0.17 ms until round 3), and a call ~0.06 ms on the host.  `--steps 20 --warmup 5`
-(what the round-end driver runs) therefore reports ~1.0e10 voxel-steps/s (~36 us per step; round 2: 7.4e9), the default `--steps 2000`
+robots run a ~0.04 ms collision broad-phase; 0.27 and 0.17 ms until round 3), and a call ~0.04 ms on the host.  `--steps 20 --warmup 5`
+(what the round-end driver runs) therefore reports ~1.02e10 voxel-steps/s (~35 us per step; round 2: 7.4e9), the default `--steps 2000`
 ~1.16e10 (~30.7 us) -- same kernel, same population; `timed_region` in the line says which case it is.
 
 The JSON line also carries
@@ -421,8 +421,8 @@ def main():
                     "note": "a launch of the resident kernel ends with its slowest workgroup and carries a fixed cost: ~0.02 ms for a "
                             "population without self-collision, ~0.07 ms for this one (prologue/epilogue of two robots per CU ~0.04 ms; the "
                             "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.04 ms per run, ~50 of 512 robots in "
-                            "any 20-step launch; 0.27 / 0.17 ms until round 3); a call costs ~0.06 ms on the host.  Per step WITHOUT those: "
-                            "~30.4 us.  --steps 20 times ONE 20-step launch (~36 us per step, ~1.0e10 voxel-steps/s); the default "
+                            "any 20-step launch; 0.27 / 0.17 ms until round 3); a call costs ~0.04 ms on the host.  Per step WITHOUT those: "
+                            "~30.4 us.  --steps 20 times ONE 20-step launch (~35 us per step, ~1.02e10 voxel-steps/s); the default "
                             "--steps 2000 times two launches of up to 1024 steps (~30.7 us, ~1.16e10).  "
                             "DESIGN.md section 4 'The cost of a launch' and 'Measured (round 3)'"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,

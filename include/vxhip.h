@@ -212,8 +212,8 @@ int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long 
  *                       vxh_reset (VXH_ERR_STATE once a step has been taken).  The tiles of a robot wait for each other on the
  *                       device: an engine that tiles must own its GPU (with another process on the same GPU set "tiled" to 0).
  *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 1024).  A launch of a self-colliding population
- *                       carries ~0.07 ms of fixed cost (0.27 until round 3), and a call ~0.06 ms on the host, so vxh_step(e, n) with a
- *                       small n is paid for: 20 steps at a time run at ~36 us per step where 1000 at a time run at ~30.5 (512 robots
+ *                       carries ~0.07 ms of fixed cost (0.27 until round 3), and a call ~0.04 ms on the host, so vxh_step(e, n) with a
+ *                       small n is paid for: 20 steps at a time run at ~35 us per step where 1000 at a time run at ~30.5 (512 robots
  *                       of 10x10x10).
  *   "fused"             0 = robots the tiled kernel does not take go through the streaming kernels (cross-checks)
  *   "graph_steps"       streaming kernels: step rounds per captured hipGraph (0 = plain launches)
