@@ -712,6 +712,14 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
 
 // acc[.][l] += (f, -m): the calling thread is the only writer of voxel l's entry between two barriers.  FIRST: the entry
 // still holds the zero the voxel phase left there, so the sum is the value itself (0 + x == x: same bits, no read).
+__device__ __forceinline__ void lds_add(double* p, double x)
+{
+#ifdef VXH_NO_LDS_ADD          // (developer what-if: the read-modify-write of round 2)
+    *p += x;
+#else
+    __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
 template <int BLOCK, bool FIRST>
 __device__ __forceinline__ void fused_accumulate(double* acc, int l, d3 f, d3 m)
 {
@@ -719,7 +727,9 @@ __device__ __forceinline__ void fused_accumulate(double* acc, int l, d3 f, d3 m)
     if constexpr (FIRST) {
         e[0] = f.x; e[BLOCK] = f.y; e[2 * BLOCK] = f.z; e[3 * BLOCK] = -m.x; e[4 * BLOCK] = -m.y; e[5 * BLOCK] = -m.z;
     } else {
-        e[0] += f.x; e[BLOCK] += f.y; e[2 * BLOCK] += f.z; e[3 * BLOCK] -= m.x; e[4 * BLOCK] -= m.y; e[5 * BLOCK] -= m.z;
+        // one ds_add_f64 each (no value returned) instead of read + add + write: the same addition of the same two operands,
+        // a third of the LDS instructions and no round trip inside the bond's chain
+        lds_add(e, f.x); lds_add(e + BLOCK, f.y); lds_add(e + 2 * BLOCK, f.z); lds_add(e + 3 * BLOCK, -m.x); lds_add(e + 4 * BLOCK, -m.y); lds_add(e + 5 * BLOCK, -m.z);
     }
 }
 
