@@ -58,14 +58,21 @@ __device__ __forceinline__ d3 rotinv(dq q, d3 f)    // CQuat::RotateVec3DInv, Ve
                tw * q.y - tx * q.z + ty * q.w + tz * q.x,
                tw * q.z + tx * q.y - ty * q.x + tz * q.w);
 }
-// v -> conj(q) v q for a UNIT quaternion as a matrix-vector product: 24 operations once, 9 per vector (rotinv: 24 each)
+// v -> conj(q) v q as a matrix-vector product: 28 operations once, 9 per vector (rotinv: 24 each).  NOT for unit quaternions only:
+// the diagonal carries |q|^2, as the sandwich does.  The bond frame's quaternion is not always a unit one -- FromAngleToPosX's
+// small-angle branch returns (1 - (y^2 + z^2) / 2, 0, y, z), of norm^2 1 + (y^2 + z^2)^2 / 4, up to 1 + 5e-9 -- and the reference's
+// RotateVec3DInv scales the back-rotated forces and moments of such a bond by it.  Until round 3 the diagonal was 1 - 2 (y^2 + z^2):
+// every large-angle bond with a small bend differed from the reference by that factor, 1e-13 .. 1e-9 of its force, step after step
+// in the same direction -- the "creep" of the long runs (scripts/dev_gpu_diag.py drift7: one step of engine and oracle from the
+// same state differed by 1e-12 voxel, 500 x what a one-ulp change of the inputs does to the oracle).
 struct RotInv {
     double m00, m01, m02, m10, m11, m12, m20, m21, m22;
     __device__ __forceinline__ explicit RotInv(dq q)
     {
         const double x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
         const double xx = x2 * q.x, yy = y2 * q.y, zz = z2 * q.z, xy = x2 * q.y, xz = x2 * q.z, yz = y2 * q.z, wx = x2 * q.w, wy = y2 * q.w, wz = z2 * q.w;
-        m00 = 1.0 - (yy + zz); m11 = 1.0 - (xx + zz); m22 = 1.0 - (xx + yy);
+        const double n = (q.w * q.w + q.x * q.x) + (q.y * q.y + q.z * q.z);
+        m00 = n - (yy + zz); m11 = n - (xx + zz); m22 = n - (xx + yy);
         m01 = xy + wz; m10 = xy - wz;        // row i of R^T = column i of the rotation matrix of q
         m02 = xz - wy; m20 = xz + wy;
         m12 = yz + wx; m21 = yz - wx;

@@ -987,6 +987,21 @@ void vxo_jitter(vxo_sim* s, unsigned seed)
     }
 }
 
+/* test instrument (scripts/dev_gpu_diag.py drift7): the voxels' state replaced by the one given, in the layout of vxo_get_state (momenta
+ * from the velocities); bond histories and modes stay.  One step from the ENGINE's state shows what a single step of the two
+ * implementations differs by, without the history of earlier differences. */
+void vxo_set_state(vxo_sim* s, const double* in14n)
+{
+    for (int i = 0; i < s->nvox; i++) {
+        voxel* v = &s->vox[i]; const double* r = in14n + 14 * (size_t)i;
+        v->pos = V(r[0], r[1], r[2]);
+        v->angle.w = r[3]; v->angle.x = r[4]; v->angle.y = r[5]; v->angle.z = r[6];
+        v->scale = r[7];
+        v->vel = V(r[8], r[9], r[10]); v->ang_vel = V(r[11], r[12], r[13]);
+        v->lin_mom = vmul(v->vel, v->mass); v->ang_mom = vmul(v->ang_vel, v->inertia);
+    }
+}
+
 int vxo_get_cm_trace(const vxo_sim* s, double* out4n, int capacity)
 {
     for (int i = 0; i < s->ntrace && i < capacity; i++) memcpy(out4n + 4 * i, s->trace + 4 * i, 4 * sizeof(double));

@@ -88,6 +88,7 @@ void     vxo_get_bond_table(const vxo_sim* s, int* vox1, int* vox2, int* axis);
 void     vxo_get_result(const vxo_sim* s, vxo_result* out);
 void     vxo_get_constants(const vxo_sim* s, double* vox12n, double* bond23n); /* per voxel / per bond constants of Import (see vx_oracle.c) */
 void     vxo_jitter(vxo_sim* s, unsigned seed);   /* test instrument: every position component one ulp up or down (see vx_oracle.c) */
+void     vxo_set_state(vxo_sim* s, const double* in14n); /* test instrument: overwrite the voxels' state (layout of vxo_get_state) */
 int      vxo_get_cm_trace(const vxo_sim* s, double* out4n, int capacity); /* (time, x, y, z) per entry; returns the number recorded */
 double   vxo_alg_bytes_per_step(const vxo_sim* s); /* 224*nvox + 144*nbond, SURVEY.md 8(d) */
 

@@ -97,6 +97,8 @@ def lib(half_angle=False):
         _lib.vxo_get_bond_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_jitter.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        if hasattr(_lib, "vxo_set_state"):
+            _lib.vxo_set_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_result.argtypes = [ctypes.c_void_p, ctypes.POINTER(VxoResult)]
         _lib.vxo_get_cm_trace.restype = ctypes.c_int
         _lib.vxo_get_cm_trace.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
@@ -316,6 +318,12 @@ class OracleSim(object):
         out = np.zeros((n, 14), dtype=np.float64)
         self._lib.vxo_get_state(self._h, out.ctypes.data)
         return out
+
+    def set_state(self, state14):
+        """test instrument: overwrite the voxels' state (the layout of state())"""
+        a = np.ascontiguousarray(state14, dtype=np.float64)
+        assert a.shape == (self.info().nvox, 14)
+        self._lib.vxo_set_state(self._h, a.ctypes.data)
 
     def bonds(self):
         n = self.info().nbond

@@ -751,6 +751,45 @@ if __name__ == "__main__" and "drift6" in sys.argv[1:]:
         print("%s: %d steps, net mode changes %d, steps where the counts of large-angle bonds differ: %d %s" % (name, nsteps, flips, len(bad), bad[:10]), flush=True)
 
 
+if __name__ == "__main__" and "drift7" in sys.argv[1:]:
+    # round 3: what ONE step of the engine and of the oracle differ by, from the same state (the oracle is put on the engine's state
+    # before every step: oracle instrument vxo_set_state): size, which voxels, and whether the differences have a direction
+    from oracle import vxoracle as vo
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "vxa")
+    for name, variant, nsteps in (("lw_hexapus", 1, 4000), ("bench10_0", 0, 2000)):
+        path = os.path.join(golden, name + ".vxa")
+        model = vo.parse_vxa(path, variant)
+        lat = model["lattice_dim"]
+        sim = vo.OracleSim(model, half_angle="ha" in sys.argv[1:])      # ("ha": the oracle build with the engine's half-angle form of FromAngleToPosX)
+        with engine.Engine(variant, 0) as eng:
+            eng.set_option("steps_per_launch", 1)
+            eng.add_vxa_file(path)
+            prev = sim.state()
+            cm_bias = np.zeros(3)
+            big = []
+            for step in range(1, nsteps + 1):
+                eng.step(1)
+                E = eng.state(0)
+                sim.set_state(prev)
+                sim.step(1)
+                O = sim.state()
+                d = E - O
+                dpos = np.abs(d[:, :3]).max() / lat
+                cm_bias += d[:, :3].mean(axis=0) / lat
+                vmax = max(1e-300, np.abs(O[:, 8:11]).max())
+                wmax = max(1e-300, np.abs(O[:, 11:14]).max())
+                dv, dw = np.abs(d[:, 8:11]).max() / vmax, np.abs(d[:, 11:14]).max() / wmax
+                if step <= 12 or step % 250 == 0:
+                    wv = int(np.abs(d[:, 11:14]).max(axis=1).argmax())
+                    print("%s step %5d: one-step difference pos %.1e voxel, vel %.1e, angvel %.1e (rel. to the largest; worst voxel %d)   sum of the CoM differences so far %s voxel" % (
+                        name, step, dpos, dv, dw, wv, np.array2string(cm_bias, precision=2)), flush=True)
+                big.append((dw, dv, dpos))
+                prev = E
+            a = np.array(big)
+            print("%s: over %d steps: one-step angvel difference median %.1e max %.1e; vel median %.1e max %.1e; pos median %.1e max %.1e" % (
+                name, nsteps, np.median(a[:, 0]), a[:, 0].max(), np.median(a[:, 1]), a[:, 1].max(), np.median(a[:, 2]), a[:, 2].max()), flush=True)
+
+
 if __name__ == "__main__" and sys.argv[1:2] and sys.argv[1] == "cfg4l":      # configs[4] over ~2000 steps, like the bench line's other_configs
     timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.13, Env(), {}, full=True)
 

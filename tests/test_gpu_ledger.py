@@ -4,18 +4,17 @@ the tolerance that follows from it, the error actually achieved against the refe
 1e-9-voxel bar held over the whole run -- as gpurun_out/r03_parity_<kernel path>.json (copied to profiles/ when a round is closed).
 Asserts the tolerance for every case and a floor on the number of cases that meet the strict bar.
 
-Stated tolerance: max(1e-9 voxel, 3e-13 voxel x steps, 20 x spread).  The first term is tests/test_gpu_parity.py's 1e-9 voxel, the
-second an allowance for runs of more than 3333 steps: round 3 measured that the engine's distance from the reference on WELL-CONDITIONED robots settles at
-1e-11 .. 1e-10 voxel within the first hundreds of steps (it appears when the first bonds turn large-angle) and then creeps up by
-about 1e-13 voxel per step -- 8e-9 voxel after the 68 319 steps of the reference's own hexapus.vxa, 7e-9 after the 25 770 of
-quadruped_land.vxa, the two longest runs of the set -- on all three kernel paths alike, i.e. in the shared bond / voxel arithmetic,
-not in the summation orders.  Its source is not isolated: measured and ruled out, each as an instrument build of the oracle or a
-what-if build of the engine (scripts/dev_gpu_diag.py drift .. drift6): FMA contraction (an engine built with -ffp-contract=off
-drifts the same), the half-angle form of FromAngleToPosX (moves the oracle by 2e-14 over that run), the angle-addition form of the
-actuation sine (5e-14), the damping constants folded with 1 / dt (3e-15), a bond in different angle modes on the two sides (never
-in 3000 steps).  One contributor was found and removed: 1 - w * w in ToRotationVector contracted into one FMA (kernels.hpp
-one_minus_square).  The reference algorithm itself, fed one-ulp noise in every position and quaternion before every step, moves
-by 7e-14 over the hexapus run: the engine's creep is a systematic difference, small, and recorded here instead of hidden."""
+Stated tolerance: max(1e-9 voxel, 20 x spread) -- tests/test_gpu_parity.py's.  For most of round 3 it carried a third term, 3e-13 voxel
+x steps, for a creep of the engine against the reference that grew with the length of the run (8e-9 voxel after the 68 319 steps of
+the reference's own hexapus.vxa) and whose source had not been found.  It was found late in the round (scripts/dev_gpu_diag.py drift7:
+the oracle put on the ENGINE's state before every step shows what one step of the two differs by -- 1e-12 voxel where a one-ulp
+change of the inputs moves the oracle by 2e-15): the back-rotation of a bond's forces through a rotation MATRIX that assumed a unit
+quaternion, where the reference's RotateVec3DInv carries |q|^2 -- and FromAngleToPosX's small-angle branch returns a quaternion of
+norm^2 1 + (y^2 + z^2)^2 / 4 (kernels.hpp RotInv).  With the diagonal corrected one step differs by 2e-15 voxel, the hexapus run ends
+4e-14 voxel from the reference, and the term is gone.  Ruled out on the way, each as an instrument build of the oracle or a what-if
+build of the engine (drift .. drift6): FMA contraction, the half-angle form of FromAngleToPosX, the angle-addition form of the
+actuation sine, the damping constants folded with 1 / dt, a bond in different angle modes on the two sides; one other contributor
+was real and is pinned: 1 - w * w in ToRotationVector contracted into one FMA (kernels.hpp one_minus_square)."""
 import json
 import os
 
@@ -63,7 +62,7 @@ def test_parity_ledger(golden_dir, manifest, kernel_path):
                 if n not in _SPREADS:
                     _SPREADS[n] = _whole_run_spread(vo, model, planned)
                 spread = _SPREADS[n]
-                tol = max(FLOOR_VOX, 3e-13 * planned, 20 * spread)
+                tol = max(FLOOR_VOX, 20 * spread)
                 res = eng.result(i)
                 final = os.path.join(golden_dir, "expected", n + ".final.bin")
                 row = {"case": n, "variant": variant, "kernel_path": kernel_path, "nvox": res.nvox, "nbond": res.nbond, "steps": res.steps,
@@ -84,22 +83,25 @@ def test_parity_ledger(golden_dir, manifest, kernel_path):
                     row["against"] = "oracle (pinned on the reference), final state"
                 err = max(row["err_cur_cm_vox"], row["err_ini_cm_vox"])
                 row["strict_1e-9"] = bool(err <= FLOOR_VOX and res.steps == row["steps_reference"])
+                row["within_1e-12"] = bool(err <= 1e-12 and res.steps == row["steps_reference"])
                 row["within_tolerance"] = bool(err <= tol and res.steps == row["steps_reference"] and res.status == eng_mod.ROBOT_FINISHED)
                 rows.append(row)
     strict = sum(1 for r in rows if r["strict_1e-9"])
-    ledger = {"kernel_path": kernel_path, "cases": len(rows), "strict_1e-9": strict,
+    tight = sum(1 for r in rows if r["within_1e-12"])
+    ledger = {"kernel_path": kernel_path, "cases": len(rows), "strict_1e-9": strict, "within_1e-12": tight,
               "within_tolerance": sum(1 for r in rows if r["within_tolerance"]),
               "note": "error = max over x, y, z of |centre of mass - reference| at the end of the whole evaluation, in voxels (also IniCM); "
-                      "tolerance = max(1e-9, 3e-13 x steps, 20 x spread of the reference algorithm under a 1-ulp change of one input); "
+                      "tolerance = max(1e-9, 20 x spread of the reference algorithm under a 1-ulp change of one input); "
                       "strict_1e-9 = within 1e-9 voxel whatever the length of the run",
               "rows": rows}
     for out_dir in (os.path.join(REPO, "gpurun_out"),):
         os.makedirs(out_dir, exist_ok=True)
         with open(os.path.join(out_dir, "r03_parity_%s.json" % kernel_path), "w") as f:
             json.dump(ledger, f, indent=1)
-    print("parity ledger [%s]: %d cases, %d within the strict 1e-9 voxel bar over the whole run, %d within tolerance" % (
-        kernel_path, len(rows), strict, ledger["within_tolerance"]))
+    print("parity ledger [%s]: %d cases, %d within the strict 1e-9 voxel bar over the whole run (%d within 1e-12), %d within tolerance" % (
+        kernel_path, len(rows), strict, tight, ledger["within_tolerance"]))
     assert len(rows) == len(manifest)
     bad = [r["case"] for r in rows if not r["within_tolerance"]]
     assert not bad, bad
-    assert strict >= (2 * len(rows)) // 3, "only %d of %d cases meet the strict bar" % (strict, len(rows))
+    assert strict >= len(rows) - 3, "only %d of %d cases meet the strict bar" % (strict, len(rows))
+    assert tight >= len(rows) - 6, "only %d of %d cases end within 1e-12 voxel of the reference" % (tight, len(rows))
