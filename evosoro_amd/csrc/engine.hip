@@ -1285,11 +1285,7 @@ void Engine::advance_launch(long long max_rounds)
     HIP_OK(hipEventRecord(D.ev1, D.stream));
     {   // the control blocks come back on the same stream, behind the kernels: one wait for both
         const size_t nr = robots_.size();
-        if (D.h_rstate_cap < nr) {
-            if (D.h_rstate) HIP_OK(hipHostFree(D.h_rstate));
-            HIP_OK(hipHostMalloc((void**)&D.h_rstate, sizeof(DRobotState) * nr, hipHostMallocDefault));
-            D.h_rstate_cap = nr;
-        }
+        if (D.h_rstate_cap < nr) throw std::logic_error("control-block mirror smaller than the batch");      // (sized by prepare())
         if (!(single && B.rstate_mirror))      // (one launch group and nothing else: its kernel has written the mirror itself)
             HIP_OK(hipMemcpyAsync(D.h_rstate, B.rstate, sizeof(DRobotState) * nr, hipMemcpyDeviceToHost, D.stream));
     }
