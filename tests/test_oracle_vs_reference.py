@@ -137,3 +137,34 @@ def test_cm_trace_equals_the_reference_xml(golden_dir):
     plain = _sim(golden_dir, "phase4")
     plain.step(-1)
     assert len(plain.cm_trace()) == 0
+
+
+def test_the_test_instruments_leave_the_algorithm_alone(golden_dir):
+    """vxo_set_state / vxo_jitter are instruments of the GPU tests (tests/test_gpu_parity.py test_one_step_from_the_same_state, the
+    ledger's spreads), not part of the restatement: an oracle put on ITS OWN state before every step must walk the trajectory of the
+    untouched one (bit for bit in the poses; the momenta are rebuilt from the velocities, an ulp), and one-ulp noise must stay
+    one-ulp-sized after one step -- the yardstick the one-step test reads the engine against."""
+    import numpy as np
+    from oracle import vxoracle as vo
+    for name, variant in (("bench10_0", 0), ("lw_swim6", 1)):
+        model = vo.parse_vxa(os.path.join(golden_dir, "vxa", name + ".vxa"), variant)
+        lat = model["lattice_dim"]
+        a, b, c = vo.OracleSim(model), vo.OracleSim(model), vo.OracleSim(model)
+        worst_self = 0.0
+        noise = []
+        for step in range(120):
+            before = a.state()
+            b.set_state(before)
+            c.set_state(before)
+            a.step(1)
+            b.step(1)
+            c.step_jittered(1, seed=step + 1)
+            sa, sb, sc = a.state(), b.state(), c.state()
+            worst_self = max(worst_self, np.abs(sa[:, :3] - sb[:, :3]).max() / lat)
+            noise.append(np.abs(sa[:, :3] - sc[:, :3]).max() / lat)
+            assert a.info().steps == b.info().steps == c.info().steps == step + 1
+        assert worst_self <= 1e-15, (name, worst_self)
+        # (in the first steps of a robot at rest many bonds sit exactly on the small- / large-angle thresholds: there an ulp flips a
+        # mode on one side, a 1e-10-voxel event; everywhere else the noise stays noise)
+        noise = np.array(noise)
+        assert 0 < np.median(noise) <= 1e-14 and (noise > 5e-14).sum() <= 12, (name, np.median(noise), noise.max(), (noise > 5e-14).sum())
