@@ -962,10 +962,10 @@ __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap
     const DRobot& R = B.robot[r];
     DRobotState& rs = B.rstate[r];
     __shared__ double sh[5 * 256];
-    __shared__ int s_go, s_latch, s_eol, s_trace, s_tidx;
+    __shared__ int s_latch, s_eol, s_trace, s_tidx;
     if (threadIdx.x == 0) {
         StepCtl c = step_control(R, rs, step_cap, begin_new_step);
-        s_go = c.go; s_latch = c.latch; s_eol = c.eol; s_trace = c.trace; s_tidx = c.trace_index;
+        s_latch = c.latch; s_eol = c.eol; s_trace = c.trace; s_tidx = c.trace_index;
         if (c.go) actuation_sincos(R, rs.cur_time, rs.act_sin, rs.act_cos);
     }
     __syncthreads();
