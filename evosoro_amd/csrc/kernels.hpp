@@ -48,6 +48,15 @@ __device__ __forceinline__ dq qmul(dq a, dq f)      // Vec3D.h:193
                a.w * f.y - a.x * f.z + a.y * f.w + a.z * f.x,
                a.w * f.z + a.x * f.y - a.y * f.x + a.z * f.w);
 }
+// qmul(a, f) for a quaternion whose x component is an exact zero (what FromAngleToPosX returns): the four products with it and their
+// additions left out -- x +- 0 == x, so the same values; the compiler may not drop a multiplication by a zero it cannot prove finite
+__device__ __forceinline__ dq qmul_x0(dq a, dq f)
+{
+    return mkq(a.w * f.w - a.y * f.y - a.z * f.z,
+               a.w * f.x + a.y * f.z - a.z * f.y,
+               a.w * f.y + a.y * f.w + a.z * f.x,
+               a.w * f.z - a.y * f.x + a.z * f.w);
+}
 __device__ __forceinline__ d3 rotinv(dq q, d3 f)    // CQuat::RotateVec3DInv, Vec3D.h:300-314
 {
     double tw = q.x * f.x + q.y * f.y + q.z * f.z;
@@ -354,10 +363,10 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
         rot = conj(a1);
     } else {
         dq align = from_angle_to_pos_x(rel);
-        rot = qmul(align, conj(a1));
+        rot = qmul_x0(align, conj(a1));
         pos2 = mk3(vsqrt(len2(xrel)) - nom_dist, 0, 0);
         ang1 = to_rotvec(align, B.slthresh_acos2sqrt);
-        qb2 = qmul(rot, a2);
+        qb2 = qmul(rot, a2);               // (re-associated as align (conj(a1) a2), with the product that is there already: 8 operations fewer, no gain measured, not kept)
     }
     const d3 ang2 = to_rotvec(qb2, B.slthresh_acos2sqrt);   // one instance for both modes: a mixed wave runs it once
 
