@@ -45,6 +45,7 @@ struct Engine::Device {
     struct Group {
         int block = 0, nacc = 0, fluid = 0, tabg = 0;   // template arguments of k_robot_steps
         int wide = 0;                     // 1: k_robot_wide<block, fluid, tabg> (kernels_wide.hpp)
+        int two_tiles = 0;                // wide kernel: a second pose tile in LDS (two barriers per step instead of three)
         int count = 0;
         const int* list = nullptr;
         size_t lds = 0;                   // dynamic LDS bytes
@@ -473,11 +474,11 @@ void Engine::check_option(const std::string& key, double value) const
     if (key == "fused" || key == "host_results") return;
     if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); return; }
     if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); return; }
-    if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "col_cap") {
+    if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "wide_two_tiles" || key == "col_cap") {
         // which kernel steps a robot, its tiling and the size of its contact rows are part of the uploaded batch: set before the first
         // vxh_run / vxh_step, or right after vxh_reset (no step taken yet: the batch is then assembled again at the next run)
         if (prepared_ && rounds_done_ > 0) throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or right after vxh_reset)");
-        if (key == "wide" && value != 0 && value != 1) throw std::invalid_argument("wide: 0 or 1");
+        if ((key == "wide" || key == "wide_two_tiles") && value != 0 && value != 1) throw std::invalid_argument(key + ": 0 or 1");
         if (key == "col_cap" && !(value >= 0 && value <= 1e6)) throw std::invalid_argument("col_cap out of range");
         if (key == "tiled" && value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2");
         if (key == "tile_small" && value != 0 && value != 1) throw std::invalid_argument("tile_small: 0 or 1");
@@ -500,6 +501,7 @@ void Engine::set_option(const std::string& key, double value)
     else {
         prepared_ = false;                    // (the batch is assembled again at the next run)
         if (key == "wide") wide_ = value != 0;
+        else if (key == "wide_two_tiles") wide_two_tiles_ = value != 0;
         else if (key == "col_cap") col_cap_ = (int)value;
         else if (key == "tiled") tiled_ = (int)value;
         else if (key == "tile_small") tile_small_ = value != 0;
@@ -873,7 +875,7 @@ void Engine::prepare()
     hs.mark("allocations + uploads");
     // Which kernel steps which robot.  Resident kernel (kernels_fused.hpp), one workgroup per robot: its variant is a function
     // of the robot alone (size, fluid, LDS need of its own tables), never of the batch.
-    struct FusedVariant { int block = 0, nacc = 0, fluid = 0, tabg = 0, wide = 0; size_t lds = 0; };
+    struct FusedVariant { int block = 0, nacc = 0, fluid = 0, tabg = 0, wide = 0, two_tiles = 0; size_t lds = 0; };
     auto fused_variant = [&](const RobotModel& M) {
         FusedVariant fv;
         const size_t lds_max = 160 * 1024 - VXH_FUSED_STATIC_LDS;
@@ -892,8 +894,14 @@ void Engine::prepare()
             const int wtabg = wneed(true) > lds_max ? 1 : 0;
             if (wneed(!wtabg) <= lds_max) {
                 fv.block = WIDE_BLOCK; fv.nacc = 0; fv.fluid = mesh; fv.tabg = wtabg; fv.wide = 1; fv.lds = wneed(!wtabg);
-                if (M.vxa.self_col_enabled && lds_max > fv.lds) fv.lds += std::min<size_t>(lds_max - fv.lds, (size_t)24 * 1024);
+                // a second pose tile (64 B per thread) where the layout leaves room for it and, for a colliding robot, for at least
+                // 8 KB of contact rows: the step then has two workgroup barriers instead of three (kernels_wide.hpp)
+                const size_t tile = (size_t)64 * WIDE_BLOCK, rows_min = M.vxa.self_col_enabled ? (size_t)8 * 1024 : 0;
+                if (wide_two_tiles_ && fv.lds + tile + rows_min <= lds_max) fv.two_tiles = 1;
+                const size_t room = lds_max - (fv.two_tiles ? tile : 0);
+                if (M.vxa.self_col_enabled && room > fv.lds) fv.lds += std::min<size_t>(room - fv.lds, (size_t)24 * 1024);
                 fv.lds &= ~(size_t)7;
+                if (fv.two_tiles) fv.lds += tile;
                 return fv;
             }
         }
@@ -1057,8 +1065,8 @@ void Engine::prepare()
             const FusedVariant fv = fused_variant(robots_[r]);
             if (fv.block == 0) continue;                              // streaming kernels
             Device::Group* g = nullptr;
-            for (auto& q : D.groups) if (q.block == fv.block && q.nacc == fv.nacc && q.fluid == fv.fluid && q.tabg == fv.tabg && q.wide == fv.wide) g = &q;
-            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = fv.block; g->nacc = fv.nacc; g->fluid = fv.fluid; g->tabg = fv.tabg; g->wide = fv.wide; }
+            for (auto& q : D.groups) if (q.block == fv.block && q.nacc == fv.nacc && q.fluid == fv.fluid && q.tabg == fv.tabg && q.wide == fv.wide && q.two_tiles == fv.two_tiles) g = &q;
+            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = fv.block; g->nacc = fv.nacc; g->fluid = fv.fluid; g->tabg = fv.tabg; g->wide = fv.wide; g->two_tiles = fv.two_tiles; }
             g->robots.push_back(r);
             g->lds = std::max(g->lds, fv.lds);
         }
@@ -1156,18 +1164,18 @@ static void launch_sized(const DBatch& B, int block, const int* list, int count,
 }
 
 template <int BLOCK, bool MESH, bool TABG>
-static void launch_wide(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+static void launch_wide(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles)
 {
     static size_t granted[64] = {};
     grant_dynamic_lds((const void*)k_robot_wide<BLOCK, MESH, TABG>, granted, lds);
-    hipLaunchKernelGGL((k_robot_wide<BLOCK, MESH, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
+    hipLaunchKernelGGL((k_robot_wide<BLOCK, MESH, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8), two_tiles);
 }
 
-static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool wide, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool wide, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles = 0)
 {
     if (wide) {
-        if (fluid) { if (tabg) launch_wide<512, true, true>(B, list, count, lds, s, cap, iters); else launch_wide<512, true, false>(B, list, count, lds, s, cap, iters); }
-        else { if (tabg) launch_wide<512, false, true>(B, list, count, lds, s, cap, iters); else launch_wide<512, false, false>(B, list, count, lds, s, cap, iters); }
+        if (fluid) { if (tabg) launch_wide<512, true, true>(B, list, count, lds, s, cap, iters, two_tiles); else launch_wide<512, true, false>(B, list, count, lds, s, cap, iters, two_tiles); }
+        else { if (tabg) launch_wide<512, false, true>(B, list, count, lds, s, cap, iters, two_tiles); else launch_wide<512, false, false>(B, list, count, lds, s, cap, iters, two_tiles); }
         return;
     }
     if (fluid) { if (tabg) launch_sized<true, true>(B, block, list, count, lds, s, cap, iters); else launch_sized<true, false>(B, block, list, count, lds, s, cap, iters); }
@@ -1223,7 +1231,7 @@ void Engine::advance_launch(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters) {
             for (size_t k = 0; k < D.groups.size(); ++k) {
                 const auto& g = D.groups[k];
-                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.wide != 0, g.list, g.count, g.lds, single ? D.stream : g.stream, cap, iters);
+                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.wide != 0, g.list, g.count, g.lds, single ? D.stream : g.stream, cap, iters, g.two_tiles);
                 ++launches; ++group_launches[k];
             }
         }

@@ -87,6 +87,7 @@ private:
     int tiled_ = 1;                            // several workgroups per robot (kernels_tiled.hpp): 0 never, 1 when the population is too
                                                // small to fill the CUs one robot each or a robot has more than 1024 voxels, 2 always
     int tiles_per_robot_ = 0;                  // 0 = chosen from the population size; > 0: requested for every tiled robot (tests)
+    bool wide_two_tiles_ = true;               // ... with a second pose tile in LDS where it fits (two barriers per step instead of three); 0: cross-checks
     bool wide_ = true;                         // small robots (up to 512 voxels, 1023 bonds) go to the wide kernel (kernels_wide.hpp); 0: resident kernel
     int col_cap_ = 0;                          // partners a contact row can hold; 0 = every other surface voxel (unbounded, like the reference)
     bool tile_small_ = false;                  // also tile large robots the resident kernel could take when the population is small (see prepare())

@@ -85,15 +85,26 @@ __device__ __forceinline__ d3 wide_gather(const double* rec, int g0, int g1, int
 template <int BLOCK, bool MESH, bool TABG>
 __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, const DRobot* __restrict__ robots,
                                                                    const int* __restrict__ robot_list, long long step_cap, int iters,
-                                                                   int lds_doubles)
+                                                                   int lds_doubles_all, int two_tiles)
 {
     extern __shared__ __align__(16) double lds[];
-    double* const ps = lds;
+    // two_tiles: a second pose tile at the end of the dynamic LDS (the host grants it where the robot's layout leaves 8 * BLOCK
+    // doubles: every walker, the smaller swimmers).  The new poses then go into the OTHER tile during the voxel phase -- nobody reads
+    // it -- and the step has two workgroup barriers instead of three (see the step loop).
+    const int lds_doubles = lds_doubles_all - (two_tiles ? 8 * BLOCK : 0);
+    double* const ps_a = lds;
+    double* const ps_b = two_tiles ? lds + lds_doubles : lds;
+    double* ps = ps_a;                        // the tile that holds the poses at the start of the step
     double* const rec = lds + 8 * BLOCK;
     __shared__ DRobotState rs;
     __shared__ FusedCtl s_ctl[2];
-    __shared__ int s_div, s_seg[2 * (BLOCK / 64)];
-    static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + 2 * sizeof(int) + 2 * 16 * sizeof(int) + 16 <= VXH_WIDE_STATIC_LDS, "static LDS bound");
+    // ping-pong control words of the step loop (slot = step parity): a bond diverged in this step; max |v|^2 of this step's voxel
+    // phase; MaxDispSinceLastBondUpdate before this step's collision-horizon update
+    __shared__ int s_divf[2];
+    __shared__ unsigned long long s_mv[2];
+    __shared__ double s_disp[2];
+    __shared__ int s_seg[2 * (BLOCK / 64)];
+    static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + 2 * sizeof(int) + 4 * sizeof(double) + 2 * 16 * sizeof(int) + 16 <= VXH_WIDE_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
     const int r = __builtin_amdgcn_readfirstlane(robot_list[blockIdx.x]);
@@ -164,7 +175,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
             ps[4 * BLOCK + la] = QUAT(0, va); ps[5 * BLOCK + la] = QUAT(1, va); ps[6 * BLOCK + la] = QUAT(2, va); ps[7 * BLOCK + la] = QUAT(3, va);
         }
     }
-    const FetchLds<BLOCK> fetch{ps, base};
     DragCache<BLOCK> dcache;
     if constexpr (MESH && DragCache<BLOCK>::KEEP) { if ((R.flags & RF_FLUID) && R.nmv > 0 && R.nfacet > 0) { dcache.load(B, R, tid); if (valid) { dcache.my_first = B.facet_first[v]; dcache.my_count = (int)B.facet_count[v]; } } }
     // my contact row (see k_robot_steps): partner count | (start of the LDS copy + 1) << VXH_ROWD_BITS
@@ -208,15 +218,31 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
     };
 
     const bool ctl_thread = tid == (split ? 3 * 64 : BLOCK - 64);      // (split: wavefront 3 has the fewest voxels of either kind; else the last one)
-    if (ctl_thread) { fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]); fused_control_horizon(R, rs, s_ctl[0]); s_div = 0; }
+    if (ctl_thread) {
+        fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]); fused_control_horizon(R, rs, s_ctl[0]);
+        s_divf[0] = s_divf[1] = 0; s_mv[0] = s_mv[1] = 0ull; s_disp[0] = s_disp[1] = rs.max_disp;
+    }
     rows_to_lds();
     __syncthreads();                           // control of the first step + every voxel's pose visible
+    // The step loop.  Barriers of a step: (B) behind the bond phase, (X) behind the voxel phase -- and, with ONE pose tile, (A) behind
+    // the pose stores that then follow (X).  What used to sit between two barriers on one lane, the collision-horizon update
+    // (UpdateCollisions: MaxDisp += |MaxVoxVel dt / lattice|, rebuild when it passes the horizon), every thread now evaluates for
+    // itself behind (X) from the control words of the step's parity -- the same operations on the same operands, one result -- and
+    // the control thread alone stores the next step's words.  Who reads and who writes a slot are always a barrier apart:
+    //   s_mv[p]    atomicMax in voxel phase p (behind (B)) | read behind (X) of step p | zeroed behind (X) of step p - 1
+    //   s_disp[p]  read behind (X) of step p | written behind (X) of step p - 1
+    //   s_divf[p]  set in bond phase p | read behind (B) of step p | zeroed in voxel phase p - 1
+    bool reb_next = false;                     // this step starts with a broad-phase run (decided behind (X) of the step before)
+    long long steps_done = 0;
     VXH_T_DECL
     for (int it = 0;; ++it) {
-        const FusedCtl& K = s_ctl[it & 1];
-        FusedCtl& Knext = s_ctl[(it + 1) & 1];
+        const int par = it & 1;
+        const FusedCtl& K = s_ctl[par];
+        FusedCtl& Knext = s_ctl[par ^ 1];
+        double* const psn = ps == ps_a ? ps_b : ps_a;      // where the new poses go (the same tile without the second one)
+        const FetchLds<BLOCK> fetch{ps, base};
         const int kf = __builtin_amdgcn_readfirstlane(K.flags);
-        const bool k_go = kf & 1, k_latch = kf & 2, k_eol = kf & 4, k_rebuild = kf & 8, k_trace = kf & 16;
+        const bool k_go = kf & 1, k_latch = kf & 2, k_eol = kf & 4, k_rebuild = (kf & 8) || reb_next, k_trace = kf & 16;
         if (!k_go && !k_trace) break;
         int vv = v, vva = va;                  // opaque per-step copies (see k_robot_steps)
         asm volatile("" : "+v"(vv));
@@ -238,13 +264,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
         bool div = false;
         if (e0 != -1) div = wide_bond<BLOCK, MESH>(B, R, bct, ps, rec, e0, tid, modebits, 0, damp_on, st);
         if (e1 != -1) div = wide_bond<BLOCK, MESH>(B, R, bct, ps, rec, e1, tid + BLOCK, modebits, 2, damp_on, st) || div;
-        if (div) s_div = 1;
+        if (div) s_divf[par] = 1;
         VXH_T_MARK(2)
         __syncthreads();                       // (B)
         VXH_T_MARK(3)
-        if (s_div) {                           // Integrate() returns before the voxel loop (VX_Sim.cpp:1777)
+        if (s_divf[par]) {                     // Integrate() returns before the voxel loop (VX_Sim.cpp:1777)
             __syncthreads();
-            if (ctl_thread) { rs.diverged = 1; fused_control_begin(R, rs, step_cap, 0, Knext); s_div = 0; }
+            if (ctl_thread) {
+                rs.diverged = 1; fused_control_begin(R, rs, step_cap, 0, Knext);
+                s_divf[par ^ 1] = 0; s_mv[par ^ 1] = 0ull; s_disp[par ^ 1] = s_disp[par];
+            }
+            reb_next = false;
             __syncthreads();
             continue;
         }
@@ -272,23 +302,50 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
             ang = mkq(ps[4 * BLOCK + la], ps[5 * BLOCK + la], ps[6 * BLOCK + la], ps[7 * BLOCK + la]);
             voxel_update_ang(B, R, Ca, vva, K.time, K.act_sin, K.act_cos, K.prenatal_c, M, am, ang, scale_a, ph_sin, ph_cos, amp_damp);
         }
-        if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
+        if (ctl_thread) { fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); s_divf[par ^ 1] = 0; }   // next step's control, off the critical path
         if (R.flags & RF_SELF_COL) {             // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
             vel2 = wave_max_nonneg(vel2);
-            if ((tid & 63) == 0) atomicMax(&rs.maxvel2_bits, (unsigned long long)__double_as_longlong(vel2));
+            if ((tid & 63) == 0) atomicMax(&s_mv[par], (unsigned long long)__double_as_longlong(vel2));
         }
+        auto store_poses = [&]() {
+            if (valid) { psn[tid] = pos.x; psn[BLOCK + tid] = pos.y; psn[2 * BLOCK + tid] = pos.z; }
+            if (angr) {
+                psn[3 * BLOCK + la] = scale_a;
+                psn[4 * BLOCK + la] = ang.w; psn[5 * BLOCK + la] = ang.x; psn[6 * BLOCK + la] = ang.y; psn[7 * BLOCK + la] = ang.z;
+            }
+        };
+        if (two_tiles) store_poses();          // (into the tile nobody reads)
         VXH_T_MARK(4)
-        __syncthreads();                       // (C) every read of the old poses is done
-        if (valid) { ps[tid] = pos.x; ps[BLOCK + tid] = pos.y; ps[2 * BLOCK + tid] = pos.z; }
-        if (angr) {
-            ps[3 * BLOCK + la] = scale_a;
-            ps[4 * BLOCK + la] = ang.w; ps[5 * BLOCK + la] = ang.x; ps[6 * BLOCK + la] = ang.y; ps[7 * BLOCK + la] = ang.z;
-        }
+        __syncthreads();                       // (X) the voxel phase is complete: max |v|^2 in, the next step's control block written
+        if (!two_tiles) store_poses();         // (every read of the old poses is done)
         VXH_T_MARK(5)
-        if (ctl_thread) { fused_control_horizon(R, rs, Knext); s_div = 0; }
-        __syncthreads();                       // (A) control + every voxel's published pose visible
+        // the collision-horizon update of the NEXT step (step_control_horizon, kernels.hpp), by every thread for itself
+        {
+            const int nf = __builtin_amdgcn_readfirstlane(Knext.flags);
+            bool reb = false;
+            double disp = s_disp[par];
+            if ((nf & 1) && (R.flags & RF_SELF_COL)) {
+                const double mv = vsqrt_nn(__longlong_as_double((long long)s_mv[par]));
+                disp += fabs(vdiv(mv * rs.dt_prev, R.lat));
+                if (!(R.flags & RF_HORIZON_COL) || disp > (R.col_horizon - 1.0) / 2) { reb = true; disp = 0.0; }
+            }
+            reb_next = reb;
+            if (ctl_thread) {
+                s_disp[par ^ 1] = disp; s_mv[par ^ 1] = 0ull;
+                if (reb) { rs.rebuilds += 1; rs.col_tiled = 0; }
+                rs.rebuild_now = reb ? 1 : 0;
+                // the words the control block carries between launches: the displacement sum as of now, and the max |v|^2 of this
+                // step where the next step's update has not consumed it (the launch ends here)
+                rs.max_disp = disp;
+                rs.maxvel2_bits = ((nf & 1) && (R.flags & RF_SELF_COL)) ? 0ull : s_mv[par];
+            }
+        }
+        ps = psn;
+        ++steps_done;
+        if (!two_tiles) __syncthreads();       // (A) every voxel's published pose visible
         VXH_T_MARK(0)
     }
+    (void)steps_done;
     VXH_T_FLUSH
     // ---- back to HBM
     {

@@ -204,11 +204,13 @@ int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long 
  *   "wide"              1 (default) = robots of up to 512 voxels and 1023 bonds are stepped by the wide kernel (one lane per bond, all
  *                       three axes at once, forces summed in the reference's order); 0 = by the resident kernel with its three bond
  *                       rounds (cross-checks).  Like "tiled" a function of the robot alone.
+ *   "wide_two_tiles"    1 (default) = the wide kernel keeps a second pose tile in LDS where the robot's layout leaves room for it and
+ *                       steps with two workgroup barriers instead of three; 0 = one tile (cross-checks).  Same arithmetic, same bits.
  *   "col_cap"           partners a collision row can hold.  0 (default) = every other surface voxel of the robot, i.e. unbounded like
  *                       the reference's lists (CVX_Sim::CreateColBond has no cap); memory: 12-16 bytes x nsurf^2 per colliding robot
  *                       (5 MB for a 10x10x10 robot), touched only as far as rows really grow.  n > 0 bounds the rows at n partners
  *                       (less memory); a robot one of whose rows would need more ends with VXH_ROBOT_COL_OVERFLOW.
- *                       These five belong to the uploaded batch: set them before the first vxh_run / vxh_step or right after
+ *                       These six belong to the uploaded batch: set them before the first vxh_run / vxh_step or right after
  *                       vxh_reset (VXH_ERR_STATE once a step has been taken).  The tiles of a robot wait for each other on the
  *                       device: an engine that tiles must own its GPU (with another process on the same GPU set "tiled" to 0).
  *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 1024).  A launch of a self-colliding population

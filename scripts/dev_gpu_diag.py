@@ -217,6 +217,10 @@ def _warm_up(variant, opts):
         eng.run()
 
 
+KEEP_STATES = False
+LAST_STATES = None
+
+
 def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel_phase=False, phases=False, stiffness=False, selfcol=True):
     """BASELINE configs[3]/[4]: throughput of other workloads (not the bench line)"""
     from collections import OrderedDict
@@ -242,6 +246,8 @@ def timing_cfg(variant, count, shape, sim_time, env, opts, full=False, per_voxel
         c = eng.counters()
         st = sorted(set(eng.result(i).status for i in range(count)))
         print("   broad-phase runs per robot: max %d" % max(eng.result(i).col_rebuilds for i in range(count)), flush=True)
+        global LAST_STATES
+        LAST_STATES = [eng.state(i) for i in range(count)] if KEEP_STATES else None
         if phases:
             eng.clear()
             return
@@ -788,6 +794,27 @@ if __name__ == "__main__" and "drift7" in sys.argv[1:]:
             a = np.array(big)
             print("%s: over %d steps: one-step angvel difference median %.1e max %.1e; vel median %.1e max %.1e; pos median %.1e max %.1e" % (
                 name, nsteps, np.median(a[:, 0]), a[:, 0].max(), np.median(a[:, 1]), a[:, 1].max(), np.median(a[:, 2]), a[:, 2].max()), flush=True)
+
+
+if __name__ == "__main__" and "twotiles" in sys.argv[1:]:
+    # round 3: the wide kernel with and without its second pose tile (option wide_two_tiles): time, and every voxel of every robot bit for bit
+    KEEP_STATES = True
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    for label, args, kw in (("64 x 6^3 walkers", (engine.VOXCAD, 64, (6, 6, 6), 0.1, Env()), {}),
+                            ("64 x 8^3 walkers", (engine.VOXCAD, 64, (8, 8, 8), 0.05, Env()), {}),
+                            ("64 x 8^3 swimmers", (engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.05, env_w), {"per_voxel_phase": True}),
+                            ("512 x 8^3 walkers", (engine.VOXCAD, 512, (8, 8, 8), 0.05, Env()), {}),
+                            ("64 x 5^3 stiffness layers", (engine.VOXCAD, 64, (5, 5, 5), 0.05, Env()), {"stiffness": True})):
+        print(label, flush=True)
+        got = []
+        for two in (1, 0, 1):
+            timing_cfg(*args, {"wide_two_tiles": two}, **kw)
+            got.append(LAST_STATES)
+        same10 = all(np.array_equal(a, b) for a, b in zip(got[0], got[1]))
+        same11 = all(np.array_equal(a, b) for a, b in zip(got[0], got[2]))
+        print("   two tiles against one: %s;  two runs with two tiles: %s" % ("bit-identical" if same10 else "DIFFERENT", "bit-identical" if same11 else "DIFFERENT"), flush=True)
 
 
 if __name__ == "__main__" and sys.argv[1:2] and sys.argv[1] == "cfg4l":      # configs[4] over ~2000 steps, like the bench line's other_configs

@@ -1074,3 +1074,32 @@ def test_one_step_from_the_same_state(eng_mod, golden_dir):
             name, nsteps, worst[0], worst[1], worst[2], flips))
         assert flips <= 2, (name, flips)
         assert worst[1] <= 2e-11 and worst[2] <= 2e-11, (name, worst)
+
+
+def test_the_second_pose_tile_of_the_wide_kernel_changes_no_bit(eng_mod, golden_dir):
+    """Option wide_two_tiles: the wide kernel writes a step's new poses into a second LDS tile and steps with two workgroup barriers
+    instead of three; the collision-horizon update is then evaluated by every thread from ping-pong control words.  Scheduling only:
+    every voxel of walkers, colliding robots, swimmers and growing robots must come out bit for bit as with one tile, at a checkpoint
+    inside the run (launch boundaries in between) and at the end."""
+    names = [("cfg1_00", 0), ("rand6_col", 0), ("grow5", 0), ("stiff5", 0), ("lw_swim6", 1), ("lw_land6", 1)]
+    for variant in (0, 1):
+        mine = [n for n, v in names if v == variant]
+        runs = []
+        for two in (1, 0):
+            with eng_mod.Engine(variant, 0) as eng:
+                eng.set_option("wide", 1)
+                eng.set_option("tiled", 0)
+                eng.set_option("wide_two_tiles", two)
+                eng.set_option("steps_per_launch", 37)
+                for n in mine:
+                    eng.add_vxa_file(os.path.join(golden_dir, "vxa", n + ".vxa"))
+                eng.step(300)
+                mid = [eng.state(i) for i in range(len(mine))]
+                eng.run()
+                runs.append((mid, [eng.state(i) for i in range(len(mine))], [eng.result(i).as_dict() for i in range(len(mine))], eng.counters().dominant_block))
+        assert runs[0][3] == 513                       # (the wide kernel stepped them)
+        for i, n in enumerate(mine):
+            assert np.array_equal(runs[0][0][i], runs[1][0][i]), n
+            assert np.array_equal(runs[0][1][i], runs[1][1][i]), n
+            a, b = runs[0][2][i], runs[1][2][i]
+            assert all(a[k] == b[k] for k in a if k != "reserved"), n
