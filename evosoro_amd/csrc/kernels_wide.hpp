@@ -23,6 +23,7 @@
 //   tabs              class tables (not TABG)
 //   st   [6][BLOCK]   MESH: directional strains
 //   cmask, rc_a1, rc_code   contact rows of colliding robots (rows_to_lds)
+//   ps'  [8][BLOCK]   (two_tiles) second pose tile, at the end: a step's new poses go into the tile nobody reads
 #pragma once
 
 namespace vxh {
