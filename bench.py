@@ -21,7 +21,7 @@ READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed reg
 launch of a self-colliding population carries ~0.07 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
 robots run a ~0.04 ms collision broad-phase; 0.27 and 0.17 ms until round 3), and a call ~0.04 ms on the host.  `--steps 20 --warmup 5`
 (what the round-end driver runs) therefore reports ~1.02e10 voxel-steps/s (~35 us per step; round 2: 7.4e9), the default `--steps 2000`
-~1.16e10 (~30.7 us) -- same kernel, same population; `timed_region` in the line says which case it is.
+~1.17e10 (~30.4 us) -- same kernel, same population; `timed_region` in the line says which case it is.
 
 The JSON line also carries
   roofline      HBM: algorithmic bytes (224*Nvox + 144*Nbond per voxel-step) of the dominant kernel over its
@@ -427,7 +427,7 @@ def main():
                             "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.04 ms per run, ~50 of 512 robots in "
                             "any 20-step launch; 0.27 / 0.17 ms until round 3); a call costs ~0.04 ms on the host.  Per step WITHOUT those: "
                             "~30.4 us.  --steps 20 times ONE 20-step launch (~35 us per step, ~1.02e10 voxel-steps/s); the default "
-                            "--steps 2000 times two launches of up to 1024 steps (~30.7 us, ~1.16e10).  "
+                            "--steps 2000 times two launches of up to 1024 steps (~30.4 us, ~1.17e10).  "
                             "DESIGN.md section 4 'The cost of a launch' and 'Measured (round 3)'"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,
