@@ -963,9 +963,14 @@ void Engine::prepare()
             const int block = fused_variant(M).block;
             if (tiled_ == 2 || !fused_ || block == 0 || (small_population && block >= 768)) cand.push_back(r);
         }
-        // tiles per robot: one bond per lane if the CUs allow it (a step then costs one bond evaluation + one voxel update + the
-        // barrier), fewer when the candidates outnumber the CUs
-        auto k_latency = [&](const RobotModel& M) { return std::max(1, (int)((M.nbond * 5LL / 4 + VXH_TILE_BLOCK - 1) / VXH_TILE_BLOCK)); };
+        // tiles per robot: one bond per lane and one WAVEFRONT of owned voxels per tile if the CUs allow it (a step then costs one bond
+        // evaluation + one voxel update on one wavefront + the barrier), fewer when the candidates outnumber the CUs.  (Until late in
+        // round 3 only the bonds counted: 112 tiles of 71-72 voxels for the 20^3 lattice -- a second, nearly empty wavefront in every
+        // voxel phase -- where 125 tiles of 64 step it in 8.7 instead of 10.3 us; scripts/dev_gpu_diag.py cfg4tiles: 64 tiles 11.2,
+        // 216 tiles 9.1, 250 tiles 8.8.)
+        auto k_latency = [&](const RobotModel& M) {
+            return std::max({1, (int)((M.nbond * 5LL / 4 + VXH_TILE_BLOCK - 1) / VXH_TILE_BLOCK), (M.nvox + 63) / 64});
+        };
         long long sum_lat = 0;
         for (int r : cand) sum_lat += k_latency(robots_[r]);
         struct Planned { int r; TilePlan plan; int tabg; size_t lds; };

@@ -817,6 +817,11 @@ if __name__ == "__main__" and "twotiles" in sys.argv[1:]:
         print("   two tiles against one: %s;  two runs with two tiles: %s" % ("bit-identical" if same10 else "DIFFERENT", "bit-identical" if same11 else "DIFFERENT"), flush=True)
 
 
+if __name__ == "__main__" and sys.argv[1:2] and sys.argv[1] == "cfg4tiles":    # configs[4] by number of tiles
+    for k in (0, 27, 64, 125, 216, 250):
+        timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.13, Env(), {"tiled": 2, "tiles_per_robot": k} if k else {}, full=True)
+
+
 if __name__ == "__main__" and sys.argv[1:2] and sys.argv[1] == "cfg4l":      # configs[4] over ~2000 steps, like the bench line's other_configs
     timing_cfg(engine.VOXCAD, 1, (20, 20, 20), 0.13, Env(), {}, full=True)
 
