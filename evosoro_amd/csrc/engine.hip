@@ -968,9 +968,12 @@ void Engine::prepare()
         // round 3 only the bonds counted: 112 tiles of 71-72 voxels for the 20^3 lattice -- a second, nearly empty wavefront in every
         // voxel phase -- where 125 tiles of 64 step it in 8.7 instead of 10.3 us; scripts/dev_gpu_diag.py cfg4tiles: 64 tiles 11.2,
         // 216 tiles 9.1, 250 tiles 8.8.)
-        auto k_latency = [&](const RobotModel& M) {
-            return std::max({1, (int)((M.nbond * 5LL / 4 + VXH_TILE_BLOCK - 1) / VXH_TILE_BLOCK), (M.nvox + 63) / 64});
-        };
+        auto k_bonds = [&](const RobotModel& M) { return std::max(1, (int)((M.nbond * 5LL / 4 + VXH_TILE_BLOCK - 1) / VXH_TILE_BLOCK)); };
+        auto k_wave = [&](const RobotModel& M) { return std::max(k_bonds(M), (M.nvox + 63) / 64); };
+        long long sum_wave = 0;
+        for (int r : cand) sum_wave += k_wave(robots_[r]);
+        const bool by_wave = sum_wave <= D.n_cu;       // (else the round-2 rule: by bonds, scaled down to the CUs -- 64 robots of 10^3 with tile_small: 14.3 us, against 16.4 with the wavefront rule scaled down)
+        auto k_latency = [&](const RobotModel& M) { return by_wave ? k_wave(M) : k_bonds(M); };
         long long sum_lat = 0;
         for (int r : cand) sum_lat += k_latency(robots_[r]);
         struct Planned { int r; TilePlan plan; int tabg; size_t lds; };
