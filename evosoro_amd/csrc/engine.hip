@@ -430,6 +430,8 @@ void Engine::clear()
         if (h[2103]) fprintf(stderr, "   prologue of the resident kernel, cycle sums of the first thread over all workgroup-launches: tables + first barrier %.3e | state load, zeroing, "
                              "first control %.3e | rows_to_lds %.3e  = (its parts, incl. the calls after broad-phase runs) ordinal -> count loads + barrier %.3e | scan + allotment %.3e | copy + barrier %.3e\n",
                              (double)h[2103], (double)h[2106], (double)h[2113], (double)h[2114], (double)h[2115], (double)h[2116]);
+        if (h[2142]) fprintf(stderr, "   tiled kernel, voxel phase of the first thread of every tile, cycle sums: six-direction sums %.3e | contacts %.3e | voxel update %.3e | pose granules out %.3e\n",
+                             (double)h[2140], (double)h[2141], (double)h[2142], (double)h[2143]);
         if (h[2131]) fprintf(stderr, "   drag, facet pass (first thread, cycle sums): barrier behind the vertices %.3e | facet loop %.3e | barrier %.3e | per-voxel sums %.3e | barrier %.3e\n",
                              (double)h[2130], (double)h[2131], (double)h[2132], (double)h[2133], (double)h[2134]);
         static const char* names[6] = {"ctl+barA", "aux", "bond", "barB", "voxel", "barC+pub"};

@@ -300,12 +300,17 @@ __device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DR
 #define VXH_TT_FLUSH if (B.prof && (threadIdx.x & 63) == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&B.prof[(threadIdx.x >> 6) * 8 + k], tt_acc[k]); }
 // ... and, at step VXH_TS_STEP of a launch, the real-time counter (100 MHz, common to all CUs) at the boundaries of the step, per tile
 #define VXH_TS_STEP 100
+// ... and cycle sums of the parts of the voxel phase, first thread of every tile (slots 2140 ..)
+#define VXH_TV_BEGIN unsigned long long t_tv = __builtin_readcyclecounter();
+#define VXH_TV(slot) { const unsigned long long t_now = __builtin_readcyclecounter(); if (B.prof && tid == 0) atomicAdd(&B.prof[2140 + (slot)], t_now - t_tv); t_tv = t_now; }
 #define VXH_TS(k, who) if (B.prof && it == VXH_TS_STEP && (who) && ti < 256) B.prof[128 + ti * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define VXH_TT_DECL
 #define VXH_TT_MARK(k)
 #define VXH_TT_FLUSH
 #define VXH_TS(k, who)
+#define VXH_TV_BEGIN
+#define VXH_TV(slot)
 #endif
 
 
@@ -635,6 +640,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         for (int attempt = 0;; ++attempt) {
             double vel2 = 0;
             const unsigned tagn = tile_tag(gen, ep, it + 2);
+            VXH_TV_BEGIN
             if (valid) {
                 // the six bond forces in the order of the fused kernel of the robot's size class: up to 768 voxels the bonds in which
                 // the voxel is the negative end first (+X +Y +Z), then those in which it is the positive end; above, +X -X +Y -Y +Z -Z
@@ -647,6 +653,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                     a6[c] = two_tiles ? ((pX + pY) + pZ) + ((nX + nY) + nZ) : ((((pX + nX) + pY) + nY) + pZ) + nZ;
                 }
                 d3 F = mk3(a6[0], a6[1], a6[2]), M = mk3(a6[3], a6[4], a6[5]);
+                VXH_TV(0)
                 VoxState S;
                 S.pos = mk3(ps[tid], ps[np + tid], ps[2 * np + tid]); S.scale = ps[3 * np + tid];
                 S.ang = mkq(ps[4 * np + tid], ps[5 * np + tid], ps[6 * np + tid], ps[7 * np + tid]);
@@ -656,15 +663,18 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                     F = F + (vel * (-R.slow_z)) * C.c_lin;
                     const FetchTile fetch{ps, px, np, tid, codes_live, pose};
                     F = tile_contacts(B, R, fetch, F, S, gv, row, ccnt, roff, rc_code, rc_a1);
+                    VXH_TV(1)
                     vel2 = voxel_update(B, R, C, gv, pose, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, row, 0, false, mk3(0, 0, 0),
                                         pht[tid], pht[no + tid], amp_damp);
                 }
+                VXH_TV(2)
                 lm_new = S.lm; am_new = S.am;
                 // out at once: the neighbours' next bond phase waits for exactly these granules (the pose tile keeps the old pose until
                 // every voxel of the tile has read its contact partners, and until the step is known to stand)
                 p8[0] = S.pos.x; p8[1] = S.pos.y; p8[2] = S.pos.z; p8[3] = S.scale; p8[4] = S.ang.w; p8[5] = S.ang.x; p8[6] = S.ang.y; p8[7] = S.ang.z;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_own, nx, p8[k], tagn);
+                VXH_TV(3)
             }
             if (svc && attempt == 0) {
                 if (speculate) {
