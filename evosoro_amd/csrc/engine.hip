@@ -1204,7 +1204,26 @@ static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool
 // A call in two halves: advance_launch enqueues every kernel of the call and returns; advance_finish waits for the device, reads
 // the control blocks back and does the accounting.  advance() = one after the other; a handle that pipelines a generation over
 // several engines of one device (EngineSet::run) launches them all before it waits for the first.
-void Engine::advance(long long max_rounds) { advance_launch(max_rounds); advance_finish(); }
+void Engine::advance(long long max_rounds)
+{
+    const long long before = rounds_done_;
+    try {
+        advance_launch(max_rounds);
+        advance_finish();
+    } catch (const TileTimeout& e) {
+        // The tiles of a robot are co-resident workgroups that wait for each other: a second process on the GPU can keep some of them
+        // off the chip until the bounded spins give up.  The robots' state of before the call is gone -- but a call that started
+        // from the imported state can simply be made again without the tiled kernel (streaming kernels for what the resident one
+        // cannot take: slower, and the same trajectories to 1e-12 voxel).  A call in the middle of a run cannot: the error stands.
+        if (before != 0 || tiled_ == 0) throw;
+        std::fprintf(stderr, "vxhip: %s -- this batch is stepped again without the tiled kernel\n", e.what());
+        dev_->pending.active = false;
+        tiled_ = 0;
+        prepare();
+        advance_launch(max_rounds);
+        advance_finish();
+    }
+}
 
 void Engine::advance_launch(long long max_rounds)
 {
@@ -1441,9 +1460,11 @@ void Engine::download_control(bool already_copied)
         H.cm_trace.assign((size_t)4 * std::min(S.ntrace, D.trace_cap[r]), 0.0);      // (filled by download())
         for (int k = 0; k < 3; ++k) H.ini_cm[k] = S.ini_cm[k];
         if (S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
-        if (S.status == 5)
-            throw std::runtime_error("HIP: the tiles of robot " + std::to_string(r) + " timed out waiting for each other (is another process "
-                                     "using this GPU? set the engine option tiled = 0 then)");
+        if (S.status == 5 || (inject_tile_timeout_ && !D.tile_launches.empty())) {
+            inject_tile_timeout_ = false;
+            throw TileTimeout("HIP: the tiles of robot " + std::to_string(r) + " timed out waiting for each other (is another process "
+                              "using this GPU? set the engine option tiled = 0 then)");
+        }
         vs += (double)M.nvox * S.steps; bs += (double)M.nbond * S.steps; ab += (224.0 * M.nvox + 144.0 * M.nbond) * S.steps;
         mx = std::max(mx, (long long)S.steps);
     }

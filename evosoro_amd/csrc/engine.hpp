@@ -1,5 +1,7 @@
 // Batched engine: owns the robots of one population shard and their SoA state on ONE HIP device.
 #pragma once
+#include <stdexcept>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <string>
@@ -22,6 +24,10 @@ struct HostState {                      // final/current state of one robot, dow
     int touching = 0, feet = 0;
     std::vector<double> cm_trace;                              // [4*k] (time, x, y, z): SS.CMTraceTime / SS.CMTrace
 };
+
+// the tiles of a robot gave up waiting for each other (VXH_ROBOT_SYNC_TIMEOUT): Engine::advance makes a call that started from the
+// imported state again without the tiled kernel; elsewhere it surfaces as VXH_ERR_HIP
+struct TileTimeout : std::runtime_error { using std::runtime_error::runtime_error; };
 
 class Engine {
 public:
@@ -87,6 +93,7 @@ private:
     int tiled_ = 1;                            // several workgroups per robot (kernels_tiled.hpp): 0 never, 1 when the population is too
                                                // small to fill the CUs one robot each or a robot has more than 1024 voxels, 2 always
     int tiles_per_robot_ = 0;                  // 0 = chosen from the population size; > 0: requested for every tiled robot (tests)
+    bool inject_tile_timeout_ = std::getenv("VXH_INJECT_TILE_TIMEOUT") != nullptr;   // fault injection for tests/test_gpu_tiled.py: the first tiled call reports a timeout
     bool wide_two_tiles_ = true;               // ... with a second pose tile in LDS where it fits (two barriers per step instead of three); 0: cross-checks
     bool wide_ = true;                         // small robots (up to 512 voxels, 1023 bonds) go to the wide kernel (kernels_wide.hpp); 0: resident kernel
     int col_cap_ = 0;                          // partners a contact row can hold; 0 = every other surface voxel (unbounded, like the reference)

@@ -144,3 +144,56 @@ def test_one_tiled_robot_inside_a_large_resident_batch(tmp_path):
     small_alone, _ = run([17])
     assert np.array_equal(batch[0], big_alone[0])
     assert np.array_equal(batch[17], small_alone[0])
+
+
+def test_a_timed_out_tiled_call_is_made_again_without_tiling(tmp_path):
+    """The tiles of a robot are co-resident workgroups that wait for each other; a second process on the GPU can make them give up
+    (VXH_ROBOT_SYNC_TIMEOUT).  A call that started from the imported state is then made again without the tiled kernel instead of
+    failing the generation (Engine::advance); the timeout is injected here (VXH_INJECT_TILE_TIMEOUT: the first tiled call reports
+    one).  The lattice above 1024 voxels must come out as an engine with tiled = 0 steps it, bit for bit, the small robot next to
+    it too.  (A call in the middle of a run cannot be repeated -- the state before it is gone -- and keeps failing with VXH_ERR_HIP.)"""
+    import subprocess, sys, textwrap
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.03, fitness_eval_init_time=0.01)
+    inds = [workloads.make_individual(0, workloads.full_material(11, 3)), workloads.random_robot(1, (6, 6, 6), 51)]
+    paths = []
+    for ind in inds:
+        write_voxelyze_file(sim, Env(), ind, str(tmp_path), "to")
+        paths.append(str(tmp_path / "voxelyzeFiles" / ("to--id_%05i.vxa" % ind.id)))
+    script = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from evosoro_amd import engine as e
+        paths, mode, out = sys.argv[1:3], sys.argv[3], sys.argv[4]
+        with e.Engine(e.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 0 if mode == "untiled" else 1)
+            eng.add_vxa_files(paths)
+            eng.step(200)
+            np.save(out, np.concatenate([eng.state(0).ravel(), eng.state(1).ravel()]))
+            print("kernel of most voxel-steps:", eng.counters().dominant_block)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    prog = tmp_path / "run.py"
+    prog.write_text(script)
+
+    def run(mode, inject):
+        env = dict(os.environ)
+        env.pop("VXH_INJECT_TILE_TIMEOUT", None)
+        env.pop("VXH_ENGINE_OPTIONS", None)
+        if inject:
+            env["VXH_INJECT_TILE_TIMEOUT"] = "1"
+        out = str(tmp_path / (mode + ("_inj" if inject else "") + ".npy"))
+        proc = subprocess.run([sys.executable, str(prog)] + paths + [mode, out], env=env, capture_output=True, timeout=600)
+        return proc, (np.load(out) if os.path.exists(out) else None)
+
+    ref_proc, ref = run("untiled", False)
+    assert ref_proc.returncode == 0, ref_proc.stderr.decode()[-2000:]
+    tiled_proc, tiled = run("tiled", False)
+    assert tiled_proc.returncode == 0 and b"stepped again" not in tiled_proc.stderr
+    assert not np.array_equal(tiled, ref) and np.abs(tiled - ref).max() < 1e-9       # (the tiled kernel really ran: same trajectory, other last bits)
+    inj_proc, inj = run("tiled", True)
+    assert inj_proc.returncode == 0, inj_proc.stderr.decode()[-2000:]
+    assert b"stepped again without the tiled kernel" in inj_proc.stderr
+    assert np.array_equal(inj, ref)
