@@ -287,6 +287,12 @@ def main():
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_launcher(args.gpus)       # (does not return)
+    # ONE JSON line on stdout, nothing else: libraries that write to the C stdout of their own accord (RCCL prints a five-line version
+    # banner per rank on this image, buffered until the process ends -- i.e. BEHIND the JSON line) are pointed at stderr; the line itself
+    # goes to the descriptor stdout was (the ranks a launcher started inherit the launcher's).
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,6 +312,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     barrier = dist.barrier if distributed else None
+    if distributed and not share_gpu and os.environ.get("VXH_BENCH_HOST_BARRIER", "1") == "1":
+        # the barriers that bracket the timed region go over a host-side (gloo) group: an RCCL barrier is a kernel + a stream wait on
+        # every rank, and the first engine launch behind one came out ~70 us late (1-rank RCCL run on this image: 0.77 against
+        # 0.69 ms for the 20-step region) -- a cost of the measurement, not of the path, which has no collective inside the region
+        try:
+            host_group = dist.new_group(backend="gloo")
+            barrier = lambda: dist.barrier(group=host_group)
+        except Exception as exc:             # (no usable host interface for gloo: the RCCL barrier it is)
+            sys.stderr.write("bench.py: host-side barrier group unavailable (%s); using the RCCL barrier\n" % exc)
 
     shape = (args.lattice,) * 3
     n_local = args.robots_per_gpu
@@ -455,7 +470,7 @@ def main():
                 ]
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(shape)
-            print(json.dumps(out))
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     finally:
         if distributed:
             dist.barrier()
