@@ -1216,7 +1216,7 @@ void Engine::advance(long long max_rounds)
         // from the imported state can simply be made again without the tiled kernel (streaming kernels for what the resident one
         // cannot take: slower, and the same trajectories to 1e-12 voxel).  A call in the middle of a run cannot: the error stands.
         if (before != 0 || tiled_ == 0) throw;
-        std::fprintf(stderr, "vxhip: %s -- this batch is stepped again without the tiled kernel\n", e.what());
+        std::fprintf(stderr, "vxhip: %s -- this batch is stepped again without the tiled kernel, which stays off for this engine\n", e.what());
         dev_->pending.active = false;
         tiled_ = 0;
         prepare();
