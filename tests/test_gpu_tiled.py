@@ -197,3 +197,40 @@ def test_a_timed_out_tiled_call_is_made_again_without_tiling(tmp_path):
     assert inj_proc.returncode == 0, inj_proc.stderr.decode()[-2000:]
     assert b"stepped again without the tiled kernel" in inj_proc.stderr
     assert np.array_equal(inj, ref)
+
+
+def test_one_step_of_the_full_20_cube_from_the_same_state(tmp_path):
+    """BASELINE configs[4] at its full size on the tiled kernel (125 tiles of 64 voxels with the engine's own tile count): what ONE step
+    of the engine and of the oracle differ by when both start from the same state (tests/test_gpu_parity.py
+    test_one_step_from_the_same_state explains the instrument), over the first 300 steps of the 8000-voxel lattice settling on the floor
+    with self-collision on."""
+    from evosoro_amd import engine as eng_mod, workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.05, fitness_eval_init_time=0.01)
+    write_voxelyze_file(sim, Env(), workloads.make_individual(0, workloads.full_material(20, 1)), str(tmp_path), "c4")
+    path = str(tmp_path / "voxelyzeFiles" / "c4--id_00000.vxa")
+    model = vo.parse_vxa(path, 0)
+    lat = model["lattice_dim"]
+    osim = vo.OracleSim(model)
+    worst = [0.0, 0.0, 0.0]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 1); eng.set_option("tiles_per_robot", 0)
+        eng.add_vxa_file(path)
+        prev = osim.state()
+        for step in range(1, 301):
+            eng.step(1)
+            got = eng.state(0)
+            osim.set_state(prev)
+            osim.step(1)
+            want = osim.state()
+            d = np.abs(got - want)
+            worst = [max(worst[0], d[:, :3].max() / lat),
+                     max(worst[1], d[:, 8:11].max() / max(1e-300, np.abs(want[:, 8:11]).max())),
+                     max(worst[2], d[:, 11:14].max() / max(1e-300, np.abs(want[:, 11:14]).max()))]
+            prev = got
+        assert eng.counters().dominant_block == 1                 # (k_tile_steps stepped it)
+    print("20^3 lattice, one step from the same state, worst over 300 steps: %.1e voxel, velocity %.1e, angular velocity %.1e" % tuple(worst))
+    assert worst[0] <= 5e-14 and worst[1] <= 2e-11 and worst[2] <= 2e-11, worst
