@@ -1045,7 +1045,8 @@ def test_one_step_from_the_same_state(eng_mod, golden_dir):
     was a formula difference of 1.2e-12 voxel per step in exactly this number (kernels.hpp RotInv) that 7806-step trajectories within
     1e-10 voxel had not shown."""
     from oracle import vxoracle as vo
-    for name, variant, nsteps in (("lw_hexapus", 1, 400), ("bench10_0", 0, 400), ("lw_swim6", 1, 300), ("grow5", 0, 400), ("rand6_col", 0, 400), ("lw_stiff5", 1, 300)):
+    for name, variant, nsteps in (("lw_hexapus", 1, 400), ("bench10_0", 0, 400), ("lw_swim6", 1, 300), ("grow5", 0, 400), ("rand6_col", 0, 400), ("lw_stiff5", 1, 300),
+                                  ("cfg1_00", 0, 300), ("cfg3_00", 1, 300)):      # (the last two: robots of BASELINE configs[1] and [3] at their full size)
         path = os.path.join(golden_dir, "vxa", name + ".vxa")
         model = vo.parse_vxa(path, variant)
         lat = model["lattice_dim"]
