@@ -234,3 +234,35 @@ def test_one_step_of_the_full_20_cube_from_the_same_state(tmp_path):
         assert eng.counters().dominant_block == 1                 # (k_tile_steps stepped it)
     print("20^3 lattice, one step from the same state, worst over 300 steps: %.1e voxel, velocity %.1e, angular velocity %.1e" % tuple(worst))
     assert worst[0] <= 5e-14 and worst[1] <= 2e-11 and worst[2] <= 2e-11, worst
+
+
+def test_whole_run_of_the_full_20_cube(tmp_path):
+    """... and the whole evaluation of that lattice (781 steps, IniCM latch, stop condition, result record) against the oracle: every
+    voxel within 1e-9 voxel at the end, the record's distances to 1e-12 relative."""
+    from evosoro_amd import engine as eng_mod, workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.05, fitness_eval_init_time=0.01)
+    write_voxelyze_file(sim, Env(), workloads.make_individual(0, workloads.full_material(20, 1)), str(tmp_path), "c4")
+    path = str(tmp_path / "voxelyzeFiles" / "c4--id_00000.vxa")
+    model = vo.parse_vxa(path, 0)
+    lat = model["lattice_dim"]
+    osim = vo.OracleSim(model)
+    osim.step(-1)
+    info, want_res = osim.info(), osim.result()
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 1); eng.set_option("tiles_per_robot", 0)
+        eng.add_vxa_file(path)
+        eng.run()
+        res = eng.result(0)
+        got = eng.state(0)
+        assert eng.counters().dominant_block == 1
+    assert res.status == eng_mod.ROBOT_FINISHED and res.steps == info.steps and res.col_rebuilds == info.col_rebuilds
+    err = np.abs(got[:, :3] - osim.state()[:, :3]).max() / lat
+    print("20^3 lattice, whole run of %d steps: largest voxel position error %.1e voxel" % (res.steps, err))
+    assert err <= 1e-9, err
+    for f in ("norm_final_dist", "final_dist", "anterior_dist", "posterior_dist"):
+        a, b = getattr(res, f), getattr(want_res, f)
+        assert abs(a - b) <= 1e-12 * max(1.0, abs(b)) + 1e-15, (f, a, b)
