@@ -188,7 +188,65 @@ def measured_compute(kernel):
     if kernel.split("<")[0] not in c.get("kernel", "") or kernel.split("<")[-1].split(",")[0] not in c.get("kernel", ""):
         return None
     c["source"] = os.path.relpath(files[-1], REPO)
+    c["live"] = False          # SQ counters of a committed rocprofv3 profile of this command, not of this very run
     return c
+
+
+def measured_parity():
+    """The other half of BASELINE's metric ("CoM-displacement err vs CPU"): the newest committed parity ledger
+    (tests/test_gpu_ledger.py -> profiles/r*_parity_auto.json): every golden case run to its stop condition on the engine, error of the
+    final centre of mass against the reference binary's, in voxels.  A record of the last GPU test run, not of this bench run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_parity_auto.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        led = json.load(f)
+    rows = led.get("rows", [])
+    strict_rows = [r for r in rows if r.get("strict_1e-9")]
+    return {"cases": led.get("cases"), "strict_1e-9": led.get("strict_1e-9"), "within_1e-12": led.get("within_1e-12"),
+            "within_tolerance": led.get("within_tolerance"),
+            "worst_err_vox": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in rows] or [None]),
+            "worst_err_vox_of_the_strict_cases": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in strict_rows] or [None]),
+            "bench_robot_err_vox": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in rows if r["case"].startswith("bench10")] or [None]),
+            "quantity": "max over x, y, z of |final centre of mass - reference binary's| (and IniCM) after the whole evaluation, voxels",
+            "source": os.path.relpath(files[-1], REPO), "live": False}
+
+
+_TRACE = None
+
+
+def trace_mark(what, t0, t1, rank):
+    if _TRACE:
+        with open(_TRACE, "a") as f:
+            f.write(json.dumps({"rank": rank, "op": what, "group": "-", "t0": t0, "t1": t1}) + "\n")
+
+
+def trace_collectives(dist, ctl, rank):
+    """VXH_BENCH_TRACE=<file prefix>: every collective this process issues is logged with its group and wall-clock span, and so are the
+    timed regions (tests/test_bench_cli.py: no collective of the default group -- RCCL on a GPU node -- may overlap a timed region on
+    any rank).  Off by default; wraps the torch.distributed entry points bench.py and evosoro_amd.parallel use."""
+    global _TRACE
+    prefix = os.environ.get("VXH_BENCH_TRACE")
+    if not prefix:
+        return
+    _TRACE = "%s.rank%d.jsonl" % (prefix, rank)
+
+    def wrap(name):
+        inner = getattr(dist, name)
+
+        def traced(*a, **k):
+            t0 = time.time()
+            try:
+                return inner(*a, **k)
+            finally:
+                g = k.get("group")
+                with open(_TRACE, "a") as f:
+                    f.write(json.dumps({"rank": rank, "op": name, "group": "ctl" if (g is not None and g is ctl) else "default", "t0": t0, "t1": time.time()}) + "\n")
+        setattr(dist, name, traced)
+    for name in ("barrier", "all_reduce", "broadcast_object_list", "all_gather_into_tensor", "all_gather", "broadcast", "gather", "all_gather_object"):
+        if hasattr(dist, name):
+            wrap(name)
 
 
 def relaunch_under_launcher(n_gpus):
@@ -219,10 +277,12 @@ def timed_steps(eng, steps, barrier=None):
     if barrier:
         barrier()
     torch.cuda.synchronize()
+    w0 = time.time()
     t0 = time.perf_counter()
     eng.step(steps)                      # (returns after the engine's own stream synchronisation)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    trace_mark("timed_region", w0, time.time(), int(os.environ.get("RANK", "0")))
     if barrier:
         barrier()
     return elapsed
@@ -262,6 +322,75 @@ def side_config(engine, name, variant, count, shape, env, device, steps, full=Fa
                     "kernel": kernel_name(c1.dominant_block),
                     "roofline_frac": alg / c1.dominant_seconds / 1e9 / HBM_PEAK_GBS if c1.dominant_seconds > 0 else None,
                     "large_angle_bonds": large / max(1, total)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def mixed_generation(engine, device, count=512, lattice=10, sim_time=0.5, init_time=0.05):
+    """A realistic generation (SURVEY.md section 7 "Heterogeneous robots in one batch", evosoro examples/basic.py:114-127): `count`
+    robots on a lattice^3 grid whose fill is uniform on 30-100 %, every second one without bone -- its softest-material time step is
+    ten times the others', so it needs a tenth of the steps for the same simulated time -- evaluated TO COMPLETION by one vxh_run.
+    Robots of several size classes (kernel variants, launch groups on their own streams) that stop at very different step counts:
+    the case the headline population (one variant, one step count) does not exercise.  Reported: voxel-steps/s of the whole run over
+    the GPU's own time for it and over the wall clock of the call, and the TAIL EFFICIENCY = that rate over the rate the same engine
+    reaches on the same population while every robot is still stepping (a window of `steady` steps right after InitCmTime of the
+    fastest-stepping robots): what the run loses to launch groups draining at different times, to robots that stop in the middle
+    of a launch, and to the part of the run in which only the long robots are left."""
+    import numpy as np
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    tmp = tempfile.mkdtemp(prefix="vxbench_mixed_")
+    try:
+        os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+        sim = Sim(self_collisions_enabled=True, dt_frac=0.9, simulation_time=sim_time, fitness_eval_init_time=init_time)
+        rng = np.random.RandomState(4242)
+        paths = []
+        for i in range(count):
+            fill = rng.uniform(0.3, 1.0)
+            mat = workloads.random_material((lattice,) * 3, 7000 + i, p_empty=1.0 - fill)
+            if i % 2:
+                mat = np.where(mat == 2, 1, mat)          # no bone: fat instead
+            write_voxelyze_file(sim, Env(), workloads.make_individual(i, mat), tmp, "g")
+            paths.append(os.path.join(tmp, "voxelyzeFiles", "g--id_%05i.vxa" % i))
+        steady = 256
+        with engine.Engine(engine.VOXCAD, device) as eng:
+            eng.add_vxa_files(paths)
+            dims = [eng.dims(i) for i in range(count)]
+            pre = int(max(init_time / d["dt"] for d in dims)) + 32
+            assert pre + steady < min(d["planned_steps"] for d in dims)
+            eng.step(pre)
+            c0 = eng.counters()
+            timed_steps(eng, steady)
+            c1 = eng.counters()
+            rate_steady = (c1.voxel_steps - c0.voxel_steps) / (c1.kernel_seconds - c0.kernel_seconds)
+        with engine.Engine(engine.VOXCAD, device) as eng:
+            eng.add_vxa_files(paths)
+            import torch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.run()
+            wall = time.perf_counter() - t0
+            c = eng.counters()
+            finished = sum(1 for i in range(count) if eng.result(i).status == engine.ROBOT_FINISHED)
+        # which kernel steps a robot is a function of the robot alone (engine.hip fused_variant): up to 512 voxels and 1023 bonds
+        # k_robot_wide<512>, else k_robot_steps<512 / 768 / 1024> by voxel count
+        blocks = {}
+        for d in dims:
+            k = ("k_robot_wide<512>" if (d["nvox"] <= 512 and d["nbond"] <= 1023) else
+                 "k_robot_steps<%d>" % (512 if d["nvox"] <= 512 else (768 if d["nvox"] <= 768 else 1024)))
+            blocks[k] = blocks.get(k, 0) + 1
+        nv = np.array([d["nvox"] for d in dims]); st = np.array([d["planned_steps"] for d in dims])
+        return {"workload": "mixed generation: %d random %d^3 robots, fill uniform 30-100 %%, every second one without bone (10x fewer steps), "
+                            "self-collision on, %.2f s simulated, vxh_run to completion" % (count, lattice, sim_time),
+                "value": c.voxel_steps / c.kernel_seconds, "unit": "voxel-timesteps/s", "value_wall": c.voxel_steps / wall,
+                "voxel_steps": c.voxel_steps, "gpu_seconds": c.kernel_seconds, "wall_seconds": wall, "launches": int(c.launches),
+                "steady_rate": rate_steady, "tail_efficiency": (c.voxel_steps / c.kernel_seconds) / rate_steady,
+                "robots_finished": finished, "voxels_min_mean_max": [int(nv.min()), float(nv.mean()), int(nv.max())],
+                "steps_min_max": [int(st.min()), int(st.max())], "kernels": blocks,
+                "note": "value = sum(nvox x steps) / GPU time of the whole run (first event to last); value_wall = over the wall clock of the "
+                        "vxh_run call incl. batch assembly and upload; tail_efficiency = value / steady_rate, steady_rate = the same engine on "
+                        "the same population over %d steps in which every robot still steps" % steady}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -311,16 +440,27 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    barrier = dist.barrier if distributed else None
-    if distributed and not share_gpu and os.environ.get("VXH_BENCH_HOST_BARRIER", "1") == "1":
-        # the barriers that bracket the timed region go over a host-side (gloo) group: an RCCL barrier is a kernel + a stream wait on
-        # every rank, and the first engine launch behind one came out ~70 us late (1-rank RCCL run on this image: 0.77 against
-        # 0.69 ms for the 20-step region) -- a cost of the measurement, not of the path, which has no collective inside the region
-        try:
-            host_group = dist.new_group(backend="gloo")
-            barrier = lambda: dist.barrier(group=host_group)
-        except Exception as exc:             # (no usable host interface for gloo: the RCCL barrier it is)
-            sys.stderr.write("bench.py: host-side barrier group unavailable (%s); using the RCCL barrier\n" % exc)
+    # CONTROL PLANE vs DATA PLANE.  Everything that merely coordinates the ranks -- the barriers that bracket the timed regions, the
+    # max / sum of the per-rank clocks, the file list of the strong run, the waits around the multi_handle run -- goes over a
+    # HOST-side (gloo) group, `ctl`.  An RCCL collective is a kernel plus a stream wait on every rank: an RCCL barrier in front of
+    # a timed region delayed the engine's first launch by ~70 us (1-rank RCCL run on this image: 0.77 against 0.69 ms for the
+    # 20-step region), and an RCCL barrier other ranks sit in while rank 0 times the multi_handle route SPINS ON THEIR GPUs -- the
+    # very devices rank 0 is measuring (round-3 review).  The default (RCCL) group is used for exactly one thing, the path's own
+    # collective: the fitness gather, outside every timed region.  With VXH_BENCH_HOST_BARRIER=0, or when no host interface for
+    # gloo exists, `ctl` falls back to the default group and the line says so (`control_plane`).
+    ctl = None                                # process group of the control plane (None: the default group)
+    control_plane = "single process"
+    if distributed:
+        control_plane = "the default group (%s)" % ("gloo" if share_gpu else "RCCL: no host-side group")
+        if os.environ.get("VXH_BENCH_HOST_BARRIER", "1") == "1":
+            try:
+                ctl = dist.new_group(backend="gloo")
+                control_plane = "gloo host group; the default group (%s) carries the fitness gather only" % ("gloo" if share_gpu else "RCCL")
+            except Exception as exc:             # (no usable host interface for gloo: the default group it is)
+                sys.stderr.write("bench.py: host-side control group unavailable (%s); using the default group\n" % exc)
+        trace_collectives(dist, ctl, rank)
+    ctl_on_host = distributed and (share_gpu or ctl is not None)
+    barrier = (lambda: dist.barrier(group=ctl)) if distributed else None
 
     shape = (args.lattice,) * 3
     n_local = args.robots_per_gpu
@@ -346,9 +486,9 @@ def main():
     def reduce_stats(elapsed, local_vs):
         if not distributed:
             return elapsed, local_vs
-        stats = torch.tensor([elapsed, local_vs], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-        tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        stats = torch.tensor([elapsed, local_vs], dtype=torch.float64, device="cpu" if ctl_on_host else "cuda")
+        tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
+        tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM, group=ctl)
         return float(tmax[0]), float(tsum[1])
 
     tmp = tempfile.mkdtemp(prefix="vxbench_r%d_" % rank)
@@ -373,7 +513,7 @@ def main():
         if world > 1:
             # BASELINE configs[2] as stated: ONE population of 512, partitioned over the ranks by cost (LPT on voxels x steps)
             shared = [make_population(os.path.join(tmp, "strong"), n_local, 0, shape, sim_time, INIT_CM_TIME) if rank == 0 else None]
-            dist.broadcast_object_list(shared, src=0)        # (one node: rank 0's files are visible to every rank)
+            dist.broadcast_object_list(shared, src=0, group=ctl)   # (one node: rank 0's files are visible to every rank)
             all_paths = shared[0]
             costs = [engine.inspect_vxa(p).nvox for p in all_paths]          # (every robot takes the same number of steps here)
             mine = parallel.shard_by_cost(costs, world)[rank]
@@ -389,7 +529,9 @@ def main():
         if world > 1:
             # the other N-GPU route: ONE process, one handle over the N devices (vxh_create_multi: the C ABI partitions the population
             # by cost, one host thread per device, results stay in host memory -- no collective).  Rank 0 steps N x 512 robots through
-            # it while the other ranks wait at the barrier below; same timing protocol.
+            # it while the other ranks wait at the HOST-side barrier below (their engines are closed, their GPUs idle: a rank
+            # waiting in an RCCL barrier would keep a spinning kernel on the device being measured); same timing protocol.
+            barrier()                          # every rank has closed its engines
             if rank == 0:
                 hp = []
                 for k in range(world):
@@ -401,13 +543,15 @@ def main():
                 h_nvox = sum(d["nvox"] for d in hd)
                 heng.step((int(max(INIT_CM_TIME / d["dt"] for d in hd)) + 32) + max(args.warmup, 1))
                 h0 = heng.counters()
+                hw0 = time.time()
                 h_elapsed = timed_steps(heng, args.steps)
+                trace_mark("multi_handle_region", hw0, time.time(), rank)
                 h1 = heng.counters()
                 assert abs((h1.voxel_steps - h0.voxel_steps) - float(h_nvox) * args.steps) < 0.5
                 handle = {"scaling": "weak", "route": "one process, vxh_create_multi over devices %s" % devices, "value": h_nvox * args.steps / h_elapsed,
                           "unit": "voxel-timesteps/s", "ms_per_step": h_elapsed / args.steps * 1e3, "robots": len(hp)}
                 heng.close()
-            dist.barrier()
+            barrier()
 
         if rank == 0:
             dom_seconds = c1.dominant_seconds
@@ -446,7 +590,11 @@ def main():
                             "DESIGN.md section 4 'The cost of a launch' and 'Measured (round 3)'"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,
+                "control_plane": control_plane,
             }
+            par = measured_parity()
+            if par:
+                out["parity"] = par
             out["roofline"].update(measured_traffic(n_local, args.lattice))
             if strong:
                 out["strong"] = strong
@@ -467,13 +615,17 @@ def main():
                                 64, (8, 8, 8), env_w, local_rank, 1024, phase=True, init_time=0.005),
                     side_config(engine, "configs[4]: one full 20x20x20 lattice, self-collision on", engine.VOXCAD, 1, (20, 20, 20), Env(),
                                 local_rank, 2048, full=True, init_time=0.005),
+                    # the resident kernel's largest variant: a real 10^3 population (fill 30-100 %) puts its fuller robots here
+                    side_config(engine, "512 dense 10x10x10 robots (1000 voxels each), self-collision on", engine.VOXCAD, 512, (10, 10, 10), Env(),
+                                local_rank, 512, full=True, init_time=0.01),
+                    mixed_generation(engine, local_rank),
                 ]
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(shape)
             os.write(json_fd, (json.dumps(out) + "\n").encode())
     finally:
         if distributed:
-            dist.barrier()
+            barrier()
         shutil.rmtree(tmp, ignore_errors=True)
         if distributed:
             dist.destroy_process_group()

@@ -218,6 +218,17 @@ int vxh_robot_dims(const vxh_engine* e, int robot, int* nvox, int* nbond, double
     return VXH_OK;
 }
 
+int vxh_voxel_actuation(const vxh_engine* e, int robot, int voxel, double* temp_amplitude, double* temp_period, double* phase_offset)
+{
+    if (bad_robot(e, robot)) return VXH_ERR_ARG;
+    const vxh::RobotModel& m = e->impl->robot(robot);
+    if (voxel < 0 || voxel >= m.nvox) return VXH_ERR_ARG;
+    if (temp_amplitude) *temp_amplitude = (double)(float)m.vxa.temp_amplitude;
+    if (temp_period) *temp_period = (double)(float)m.vxa.temp_period;
+    if (phase_offset) *phase_offset = (double)m.phase_offset[(size_t)voxel];
+    return VXH_OK;
+}
+
 int vxh_run(vxh_engine* e) { return guarded(e, [&] { e->impl->run(); }); }
 int vxh_step(vxh_engine* e, long long nsteps) { return guarded(e, [&] { e->impl->step(nsteps); }); }
 int vxh_reset(vxh_engine* e) { return guarded(e, [&] { e->impl->reset(); }); }

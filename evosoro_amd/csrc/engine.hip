@@ -378,6 +378,14 @@ std::vector<RobotModel> Engine::take_robots()
     return out;
 }
 
+void Engine::set_tiling_allowed(bool on)
+{
+    if (on == tiling_allowed_) return;
+    if (prepared_ && rounds_done_ > 0) throw std::logic_error("the kernel choice of a batch that has stepped cannot change");
+    tiling_allowed_ = on;
+    prepared_ = false;
+}
+
 void Engine::give_robots(std::vector<RobotModel>&& models)
 {
     for (auto& m : models) robots_.push_back(std::move(m));
@@ -501,6 +509,10 @@ void Engine::set_option(const std::string& key, double value)
     else if (key == "steps_per_launch") steps_per_launch_ = (int)value;
     else if (key == "graph_steps") { graph_steps_ = (int)value; drop_graph(); }
     else {
+        const double now = key == "wide" ? (double)wide_ : key == "wide_two_tiles" ? (double)wide_two_tiles_ : key == "col_cap" ? (double)col_cap_ :
+                           key == "tiled" ? (double)tiled_ : key == "tile_small" ? (double)tile_small_ : (double)tiles_per_robot_;
+        const double want = (key == "wide" || key == "wide_two_tiles" || key == "tile_small") ? (double)(value != 0) : (double)(int)value;
+        if (now == want) return;              // (unchanged: the assembled batch stays)
         prepared_ = false;                    // (the batch is assembled again at the next run)
         if (key == "wide") wide_ = value != 0;
         else if (key == "wide_two_tiles") wide_two_tiles_ = value != 0;
@@ -624,15 +636,31 @@ void Engine::prepare()
     std::vector<int> vtab_off(nr + 1, 0), btab_off(nr + 1, 0), wl_off(nr + 1, 0);
     std::vector<long long> excl_off(nr + 1, 0), col_off(nr + 1, 0);
     std::vector<int> col_cap(nr, 0);
+    // contact rows: as long as the physics makes them -- a surface voxel can list every other one (CreateColBond, VX_Sim.cpp:753-769,
+    // has no cap) -- unless the option col_cap bounds them; 12-16 bytes per entry, untouched beyond the partners a row really has.
+    // That is nsurf^2 entries of address space per robot (75 MB for a 20^3 lattice, 1.5 GB for 512 robots of 10^3: nothing on this
+    // device), but it grows with the FOURTH power of a lattice's edge: when the uncapped rows of a batch would take more than a third of
+    // the device's free memory (a lattice of 100^3 and beyond) every robot's rows are cut to an equal share of that third, never
+    // below 64, and the engine says so -- a row that then overflows gives its robot VXH_ROBOT_COL_OVERFLOW, as with a col_cap of the
+    // user's.  (Round 3 allocated nsurf^2 whatever the size and ran out of memory in this function for lattices it used to step.)
+    long long row_limit = 0x7fffffff;
+    if (col_cap_ <= 0) {
+        double want = 0, rows = 0;
+        for (int r = 0; r < nr; ++r) if (robots_[r].vxa.self_col_enabled) { want += 16.0 * (double)robots_[r].nsurf * (double)std::max(1, robots_[r].nsurf - 1); rows += robots_[r].nsurf; }
+        size_t free_b = 0, total_b = 0;
+        if (want > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > (double)free_b / 3.0) {
+            row_limit = std::max<long long>(64, (long long)((double)free_b / 3.0 / 16.0 / std::max(1.0, rows)));
+            std::fprintf(stderr, "vxhip: the contact rows of this batch would take %.1f GB uncapped (device memory free: %.1f GB); rows are cut to %lld partners "
+                                 "(option col_cap sets the length; a robot whose row overflows ends with status COL_OVERFLOW)\n", want / 1e9, (double)free_b / 1e9, row_limit);
+        }
+    }
     for (int r = 0; r < nr; ++r) {
         const RobotModel& M = robots_[r];
         if (M.vox_classes.size() > 32767 || M.bond_classes.size() > 32767) throw std::runtime_error("too many distinct voxel/bond classes in one robot");
         vtab_off[r + 1] = vtab_off[r] + (int)M.vox_classes.size();
         btab_off[r + 1] = btab_off[r] + (int)M.bond_classes.size();
         excl_off[r + 1] = excl_off[r] + (M.vxa.self_col_enabled ? (long long)M.nsurf * ((M.nsurf + 63) / 64) : 0);
-        // contact rows: as long as the physics makes them -- a surface voxel can list every other one (CreateColBond, VX_Sim.cpp:753-769,
-        // has no cap) -- unless the option col_cap bounds them; 12-16 bytes per entry, untouched beyond the partners a row really has
-        col_cap[r] = M.vxa.self_col_enabled ? std::max(1, col_cap_ > 0 ? std::min(col_cap_, M.nsurf - 1) : M.nsurf - 1) : 0;
+        col_cap[r] = M.vxa.self_col_enabled ? std::max(1, col_cap_ > 0 ? std::min(col_cap_, M.nsurf - 1) : (int)std::min<long long>(row_limit, M.nsurf - 1)) : 0;
         col_off[r + 1] = col_off[r] + (long long)col_cap[r] * (M.vxa.self_col_enabled ? M.nsurf : 0);
         wl_off[r + 1] = wl_off[r] + (wide_listed(M) ? M.nbond : 0);
     }
@@ -943,7 +971,8 @@ void Engine::prepare()
     std::vector<DTile> h_tiles;
     std::vector<int> tile_vox, tile_bond, tile_bcls, tile_bslot, xslot(nv, 0);
     int nx_total = 0;
-    if (tiled_ > 0) {
+    const int tiled_now = tiling_allowed_ ? tiled_ : 0;
+    if (tiled_now > 0) {
         const size_t lds_cap = 160 * 1024 - VXH_TILE_STATIC_LDS;
         int n_work = 0;
         for (int r = 0; r < nr; ++r) if (robots_[r].nvox > 0) ++n_work;
@@ -963,7 +992,7 @@ void Engine::prepare()
             const RobotModel& M = robots_[r];
             if (M.nvox == 0 || M.nmv > 0) continue;                   // (robots with the land_water surface mesh: resident / streaming kernels)
             const int block = fused_variant(M).block;
-            if (tiled_ == 2 || !fused_ || block == 0 || (small_population && block >= 768)) cand.push_back(r);
+            if (tiled_now == 2 || !fused_ || block == 0 || (small_population && block >= 768)) cand.push_back(r);
         }
         // tiles per robot: one bond per lane and one WAVEFRONT of owned voxels per tile if the CUs allow it (a step then costs one bond
         // evaluation + one voxel update on one wavefront + the barrier), fewer when the candidates outnumber the CUs.  (Until late in

@@ -64,6 +64,11 @@ public:
     int device() const { return device_id_; }
     // EngineSet moves robots between the engines of a handle (host-side models only; the batch is rebuilt on the next run)
     std::vector<RobotModel> take_robots();
+    // The handle's veto on the multi-workgroup kernel, apart from the user's option `tiled`: two engines of ONE handle on ONE device
+    // must not both run it (the tiles of a robot wait for each other).  Takes effect at the next batch assembly; the option keeps
+    // its value and acts again when the veto is lifted (EngineSet::gather / clear).
+    void set_tiling_allowed(bool on);
+    void add_run_seconds(double s) { counters_.run_seconds += s; }
     void give_robots(std::vector<RobotModel>&& models);
     void drop_graph();
 
@@ -90,6 +95,7 @@ private:
     // ends with its slowest workgroup: DESIGN.md "The cost of a launch"); a whole evaluation of the bench population (7806 steps),
     // us per step by launch length: 256: 31.2 | 512: 30.7 | 1024: 30.6 | 2048: 30.6 | 8192 (one launch): 30.3.  (256 until late in round 2.)
     int steps_per_launch_ = 1024;
+    bool tiling_allowed_ = true;               // the handle's veto (set_tiling_allowed): several engines of one handle share this device
     int tiled_ = 1;                            // several workgroups per robot (kernels_tiled.hpp): 0 never, 1 when the population is too
                                                // small to fill the CUs one robot each or a robot has more than 1024 voxels, 2 always
     int tiles_per_robot_ = 0;                  // 0 = chosen from the population size; > 0: requested for every tiled robot (tests)
@@ -134,6 +140,7 @@ private:
     void distribute();      // ... and out to the devices (before a run)
     void each(const std::function<void(Engine&)>& body);   // on every engine that holds robots, concurrently; rethrows the first failure
     void no_tiling_if_shared();   // several engines of the handle on one device are about to hold robots: no multi-workgroup kernel
+    void tiling_allowed_again();  // ... the robots are back on one engine
     bool repeated_ = false;       // the device list names a device more than once
     void flush_pending();   // build what a pipelining handle has only checked so far (any reader or addition before the run)
     std::vector<std::unique_ptr<Engine>> engines_;

@@ -1,5 +1,6 @@
 // EngineSet: the engines behind one C-ABI handle (engine.hpp).  Host-only code.
 #include <algorithm>
+#include <chrono>
 #include <exception>
 #include <iterator>
 #include <stdexcept>
@@ -21,11 +22,15 @@ EngineSet::EngineSet(int variant, const std::vector<int>& device_ids)
     pipelined_ = device_ids.size() > 1 && sorted.front() == sorted.back();
 }
 
+// The veto is the handle's, not the user's option: it lasts while several engines of a repeated device hold robots and is lifted when
+// the robots are back on one engine (gather, clear), so a later generation with a lattice above 1024 voxels -- stepped by ONE engine
+// -- gets the tiled kernel again, and a `tiled` / `tile_small` value the user set is never overwritten.
 void EngineSet::no_tiling_if_shared()
 {
     if (repeated_ && engines_.size() > 1)
-        for (auto& e : engines_) e->set_option("tiled", 0);
+        for (auto& e : engines_) e->set_tiling_allowed(false);
 }
+void EngineSet::tiling_allowed_again() { for (auto& e : engines_) e->set_tiling_allowed(true); }
 
 void EngineSet::flush_pending()
 {
@@ -46,6 +51,7 @@ void EngineSet::gather()
     engines_[0]->give_robots(std::move(all));
     where_.clear();
     distributed_ = false;
+    tiling_allowed_again();
 }
 
 void EngineSet::distribute()
@@ -132,9 +138,20 @@ void EngineSet::run()
         bool large = false;
         for (const auto& m : all) { size_t occ = 0; for (unsigned char c : m.structure) occ += c != 0; large = large || occ > 1024; }
         const int K = large ? 1 : (int)engines_.size();
-        if (!large) no_tiling_if_shared();
+        const auto t0 = std::chrono::steady_clock::now();
         int launched = 0;
         try {
+            if (K == 1) {
+                // one engine owns the device: its own run(), i.e. with the tiled kernel and with the fall-back of a tile timeout
+                // (Engine::advance: the batch is stepped again without that kernel), and its own accounting of the run's wall time
+                tiling_allowed_again();
+                engines_[0]->append(engines_[0]->build_models(std::move(all)));
+                for (int i = 0; i < n; ++i) where_[i] = {0, i};
+                distributed_ = true;
+                engines_[0]->run();
+                return;
+            }
+            no_tiling_if_shared();            // (no multi-workgroup kernel from here on: nothing below can time out on a tile)
             for (int k = 0; k < K; ++k) {
                 const int lo = (int)((long long)n * k / K), hi = (int)((long long)n * (k + 1) / K);
                 if (hi <= lo) continue;
@@ -144,13 +161,18 @@ void EngineSet::run()
                 engines_[k]->run_launch();
                 launched = k + 1;
             }
-        } catch (...) {
-            for (int k = 0; k < launched; ++k) { try { engines_[k]->run_finish(); } catch (...) {} }
             distributed_ = true;
+            for (int k = 0; k < K; ++k) engines_[k]->run_finish();
+        } catch (...) {
+            // A chunk could not be built, uploaded or stepped.  The models of the chunks behind it were never built and those in front
+            // hold a run that is not the generation's: the handle is left EMPTY (vxh_num_robots 0, every reader refuses the index)
+            // rather than with indices that silently point at the wrong robot; the caller sees the error and hands the generation over again.
+            for (int k = 0; k < launched; ++k) { try { engines_[k]->run_finish(); } catch (...) {} }
+            clear();
             throw;
         }
-        distributed_ = true;
-        for (int k = 0; k < K; ++k) engines_[k]->run_finish();
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int k = 0; k < K; ++k) engines_[k]->add_run_seconds(wall);      // (counters(): the slowest engine's = the run's)
         return;
     }
     flush_pending();
@@ -159,7 +181,7 @@ void EngineSet::run()
 }
 void EngineSet::step(long long n) { flush_pending(); distribute(); each([n](Engine& e) { e.step(n); }); }
 void EngineSet::reset() { flush_pending(); distribute(); each([](Engine& e) { e.reset(); }); }      // (distribute first: not the whole population on device 0)
-void EngineSet::clear() { for (auto& e : engines_) e->clear(); where_.clear(); pending_.clear(); distributed_ = false; }
+void EngineSet::clear() { for (auto& e : engines_) e->clear(); where_.clear(); pending_.clear(); distributed_ = false; tiling_allowed_again(); }
 
 // (readers distribute first, like run(): after an addition, or a reset, the engine that holds the robot says what is missing)
 void EngineSet::result(int robot, vxh_result* out)

@@ -253,16 +253,24 @@ __device__ __forceinline__ double wave_minmax(double v)
 // acos is ill-conditioned near n.x = 1 (d theta = d n.x / sin theta), so the reference's own value moves by up to 1e-12
 // (relative) under a 1-ulp change of `from`; the identity form agrees with it to 8e-13 max / 4e-15 median over bend angles
 // of 1..35 degrees (DESIGN.md "Numerics") at a quarter of the instructions.  The theta > PI - 1e-7 cut is kept on n.x.
-__device__ __forceinline__ dq from_angle_to_pos_x(d3 from)
+// Round 4 (instruction diet): the function also returns |from| -- the large-angle branch of CalcLinForce needs the bond's length
+// (Pos2.x = |x2 - x1| - NomDistance, VXS_BondInternal.cpp:104) and this normalisation needs 1 / |from|: one refined v_rsq_f64 gives
+// both (len = L2 * rsqrt(L2), <= 1.5 ulp, where the reference takes a correctly rounded sqrt of the un-rotated difference: a relative
+// 2e-16 on a length whose elongation is 1e-4 .. 1e-1 of it); and the SmallAngle test |y/x|, |z/x| < SMALL_ANGLE_RAD is made on the
+// cross-multiplied form |y|, |z| < SMALL_ANGLE_RAD |x| (x == 0: false, like the reference's inf / NaN quotients), so that the
+// reciprocal of x is only formed for the lanes that take that branch.
+__device__ __forceinline__ dq from_angle_to_pos_x(d3 from, double& len)
 {
-    if (from.x == 0 && from.y == 0 && from.z == 0) return mkq(1, 0, 0, 0);
-    const double rx = vrcp(from.x);           // one reciprocal for y/x and z/x (x == 0: both tests fail, like with inf/NaN quotients)
-    const double yox = from.y * rx, zox = from.z * rx;
-    if (yox < VXH_SMALL_ANGLE_RAD && yox > -VXH_SMALL_ANGLE_RAD && zox < VXH_SMALL_ANGLE_RAD && zox > -VXH_SMALL_ANGLE_RAD) {
-        double y = 0.5 * zox, z = -0.5 * yox;
+    const double L2 = from.x * from.x + from.y * from.y + from.z * from.z;
+    if (from.x == 0 && from.y == 0 && from.z == 0) { len = 0.0; return mkq(1, 0, 0, 0); }
+    const double li = vrsqrt(L2);             // NormalizeFast: from * (1 / |from|)
+    len = L2 * li;
+    const double ax = VXH_SMALL_ANGLE_RAD * fabs(from.x);
+    if (fabs(from.y) < ax && fabs(from.z) < ax) {
+        const double rx = vrcp(from.x);
+        const double y = 0.5 * (from.z * rx), z = -0.5 * (from.y * rx);
         return mkq(1 + 0.5 * (-y * y - z * z), 0, y, z);
     }
-    const double li = vrsqrt(from.x * from.x + from.y * from.y + from.z * from.z);   // NormalizeFast: from * (1 / |from|)
     const d3 n = from * li;
     if (n.x < -0.999999999999995) return mkq(0, 0, 1, 0);     // cos(PI - DISCARD_ANGLE_RAD)
     const double s = 0.5 + 0.5 * n.x, ri = vrsqrt(s);         // c = sqrt(s), 1 / (2 c) = ri / 2
@@ -278,16 +286,49 @@ __device__ __forceinline__ dq from_angle_to_pos_x(d3 from)
 #pragma clang fp contract(off)
 __device__ __forceinline__ double one_minus_square(double w) { const double ww = w * w; return 1.0 - ww; }
 #pragma clang fp contract(fast)
+// Round 4 (instruction diet).  f = 2 * (angle / sin(angle/2) / 2) in three branches:
+//   sl < SLTHRESH   the reference's sqrt((2 - 2w) / sl) as (2 - 2w) * rsqrt((2 - 2w) * sl), sl = 1 - fl(w w) with the reference's own
+//                   rounding of w w (one_minus_square above: for a small rotation that rounding is a relative 1e-12 of sl, and the
+//                   engine must make the same "error");
+//   else, w >= 0.5  (every bond that is not folded back on itself)  acos(w) = 2 asin(s), s = sqrt(z), z = (1 - w)/2, asin(s) = s (1 + z P(z))
+//                   with vacos' polynomial; and sqrt(sl) = sqrt((1 - w)(1 + w)) = s sqrt(2 + 2w), so that
+//                       acos(w) / sqrt(sl) = (2 + 2 z P(z)) * rsqrt(2 + 2w)
+//                   -- ONE refined v_rsq_f64 of a well-conditioned argument where acos-then-divide takes a sqrt and a rsqrt (-14 vector
+//                   instructions per call, two calls per large-angle bond).  It does not go through sl, hence not through the
+//                   rounding of w w: on this branch sl > 2.4e-3, that rounding is a relative < 2.5e-14 of the result.
+//   else            acos(w) * rsqrt(sl) as before (never taken by a sane bond; kept for the function's contract).
+// The factor 2 of the rotation vector is folded into f (exact).
+__device__ __forceinline__ double rotvec_factor(double w, double slthresh)
+{
+    const double sl = one_minus_square(w);
+    if (sl <= 0) return 0.0;                   // (sl > 0 from here: |w| < 1, the reference's clamp of w to 1 cannot act)
+    if (sl < slthresh) {
+        const double a = __builtin_fma(w, -2.0, 2.0), a2 = __builtin_fma(w, -4.0, 4.0);
+        return a2 * vrsqrt(a * sl);
+    }
+    if (w >= 0.5) {
+        const double z = __builtin_fma(w, -0.5, 0.5);
+        double p = sconst(0.028169218060881414);
+        p = __builtin_fma(p, z, sconst(-0.010749050339697808));
+        p = __builtin_fma(p, z, sconst(0.01603551434914882));
+        p = __builtin_fma(p, z, sconst(0.0078029494773533175));
+        p = __builtin_fma(p, z, sconst(0.011875494382636922));
+        p = __builtin_fma(p, z, sconst(0.013929652902326633));
+        p = __builtin_fma(p, z, sconst(0.017355259955786323));
+        p = __builtin_fma(p, z, sconst(0.02237204763174451));
+        p = __builtin_fma(p, z, sconst(0.03038194736709848));
+        p = __builtin_fma(p, z, sconst(0.044642857103423646));
+        p = __builtin_fma(p, z, sconst(0.07500000000020764));
+        p = __builtin_fma(p, z, sconst(0.1666666666666665));
+        p *= z;
+        return __builtin_fma(p, 4.0, 4.0) * vrsqrt(__builtin_fma(w, 2.0, 2.0));
+    }
+    return 2.0 * vacos(w) * vrsqrt(sl);
+}
 __device__ __forceinline__ d3 to_rotvec(dq q, double slthresh)
 {
-    double sl = one_minus_square(q.w);
-    if (sl <= 0) return mk3(0, 0, 0);
-    double wc = q.w > 1 ? 1 : q.w;
-    // sqrt((2 - 2w) / sl) = (2 - 2w) * rsqrt((2 - 2w) * sl)  and  acos(w) / sqrt(sl) = acos(w) * rsqrt(sl): one refined v_rsq_f64
-    // each instead of a division and a square root (sl > 0 here, hence w < 1 and 2 - 2w > 0)
-    const double a = 2 - 2 * wc;
-    double f = (sl < slthresh) ? a * vrsqrt(a * sl) : vacos(wc) * vrsqrt(sl);
-    return mk3(2.0 * q.x * f, 2.0 * q.y * f, 2.0 * q.z * f);
+    const double f = rotvec_factor(q.w, slthresh);
+    return mk3(q.x * f, q.y * f, q.z * f);
 }
 
 // Contact rows (DBatch::col_partner / col_a1 / col_code): robot r owns the block [col_begin, col_begin + col_cap * nsurf), entry k of
@@ -336,7 +377,9 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
 {
     BondOut o;
     d3 rel = rotinv(a1, xrel);
-    dq new2 = qmul(conj(a1), a2);
+    // Angle2 in voxel 1's frame, conj(a1) a2 (NewAng2): its w now, for the mode test; the vector part only where it is used, in the
+    // small-angle branch (a wavefront of large-angle bonds skips those 12 operations)
+    const double new2w = a1.w * a2.w + a1.x * a2.x + a1.y * a2.y + a1.z * a2.z;
 
     // small/large-angle switch with hysteresis (VXS_BondInternal.cpp:72-77).  SmallTurn = (|z|+|y|)/x and
     // ExtendPerc = x/NomDistance are only ever compared with constants, so the comparisons are made on the
@@ -350,23 +393,30 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
         else if (rel.x < 0) { turn_lt = true; turn_gt = false; }
         else { turn_lt = false; turn_gt = t > 0; }
         const bool ext_lt = rel.x < VXH_SA_BOND_EXT_PERC * nom_dist, ext_gt = rel.x > (VXH_HYST * VXH_SA_BOND_EXT_PERC) * nom_dist;
-        if (!small && new2.w > B.small_angle_w && turn_lt && ext_lt) { small = true; changed = true; }
-        else if (small && (!(new2.w > B.smallish_angle_w) || turn_gt || ext_gt)) { small = false; changed = true; }
+        if (!small && new2w > B.small_angle_w && turn_lt && ext_lt) { small = true; changed = true; }
+        else if (small && (!(new2w > B.smallish_angle_w) || turn_gt || ext_gt)) { small = false; changed = true; }
     }
 
-    d3 pos2, ang1;
+    // Angle1 is (0, y, z) in both modes: zero in the small one, and the rotation vector of FromAngleToPosX's quaternion, whose x is
+    // an exact zero, in the large one -- the x component is left out of everything below (0 - a == -a, a - 0 == a: the same bits)
+    d3 pos2;
+    double ang1y, ang1z;
     dq rot, qb2;                               // qb2: Angle2 in the bond frame
     if (small) {
-        ang1 = mk3(0, 0, 0);
-        qb2 = new2;
+        ang1y = 0; ang1z = 0;
+        qb2 = mkq(new2w, a1.w * a2.x - a1.x * a2.w - a1.y * a2.z + a1.z * a2.y,
+                         a1.w * a2.y + a1.x * a2.z - a1.y * a2.w - a1.z * a2.x,
+                         a1.w * a2.z - a1.x * a2.y + a1.y * a2.x - a1.z * a2.w);      // qmul(conj(a1), a2)
         pos2 = mk3(rel.x - nom_dist, rel.y, rel.z);
         rot = conj(a1);
     } else {
-        dq align = from_angle_to_pos_x(rel);
+        double len;
+        const dq align = from_angle_to_pos_x(rel, len);
         rot = qmul_x0(align, conj(a1));
-        pos2 = mk3(vsqrt(len2(xrel)) - nom_dist, 0, 0);
-        ang1 = to_rotvec(align, B.slthresh_acos2sqrt);
-        qb2 = qmul(rot, a2);               // (re-associated as align (conj(a1) a2), with the product that is there already: 8 operations fewer, no gain measured, not kept)
+        pos2 = mk3(len - nom_dist, 0, 0);
+        const double f1 = rotvec_factor(align.w, B.slthresh_acos2sqrt);
+        ang1y = align.y * f1; ang1z = align.z * f1;
+        qb2 = qmul(rot, a2);               // (re-associated as align (conj(a1) a2): needs all of conj(a1) a2, 12 operations more than it saves)
     }
     const d3 ang2 = to_rotvec(qb2, B.slthresh_acos2sqrt);   // one instance for both modes: a mixed wave runs it once
 
@@ -378,10 +428,11 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
     o.diverged = pos2.x > C.L100;              // strain > 100, VX_Sim.cpp:1775
 
     // beam equations (VXS_BondInternal.cpp:128-153)
-    d3 f1 = mk3(C.kf_L * pos2.x, C.b1 * pos2.y - C.b2 * (ang1.z + ang2.z), C.b1 * pos2.z + C.b2 * (ang1.y + ang2.y));
+    d3 f1 = mk3(C.kf_L * pos2.x, C.b1 * pos2.y - C.b2 * (ang1z + ang2.z), C.b1 * pos2.z + C.b2 * (ang1y + ang2.y));
     d3 f2 = -f1;
-    d3 m1 = mk3(C.a2 * (ang1.x - ang2.x), C.b2 * pos2.z + C.b3 * (2 * ang1.y + ang2.y), -C.b2 * pos2.y + C.b3 * (2 * ang1.z + ang2.z));
-    d3 m2 = mk3(C.a2 * (ang2.x - ang1.x), C.b2 * pos2.z + C.b3 * (ang1.y + 2 * ang2.y), -C.b2 * pos2.y + C.b3 * (ang1.z + 2 * ang2.z));
+    const double tors = C.a2 * ang2.x;         // a2 (Angle2.x - Angle1.x); Moment1.x is its negative
+    d3 m1 = mk3(-tors, C.b2 * pos2.z + C.b3 * (2 * ang1y + ang2.y), -C.b2 * pos2.y + C.b3 * (2 * ang1z + ang2.z));
+    d3 m2 = mk3(tors, C.b2 * pos2.z + C.b3 * (ang1y + 2 * ang2.y), -C.b2 * pos2.y + C.b3 * (ang1z + 2 * ang2.z));
 
     // velocity damping from the finite-differenced bond-frame pose (AddDampForces :310-346); skipped on the step the
     // mode flips, and the history is only refreshed when it runs
@@ -389,19 +440,20 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
         if (damp_on) {
             const bool hl = (H.flags & 2u) != 0;        // expand the stored history (see DBatch::hist)
             const d3 hpos2 = mk3(H.p0, hl ? 0.0 : H.p1, hl ? 0.0 : H.p2);
-            const d3 hang1 = mk3(0.0, hl ? H.p1 : 0.0, hl ? H.p2 : 0.0);
+            const double hang1y = hl ? H.p1 : 0.0, hang1z = hl ? H.p2 : 0.0;
             const d3 hang2 = mk3(H.g0, H.g1, H.g2);
             // differences of the bond-frame pose; 1/dt and BondDampingZ/2 are inside the d* constants (DBondClass)
-            const d3 v = pos2 - hpos2, w1 = ang1 - hang1, w2 = ang2 - hang2;
-            f1 = f1 + mk3(C.dA1 * v.x, C.dB1 * v.y - C.dF1 * (w1.z + w2.z), C.dB1 * v.z + C.dF1 * (w1.y + w2.y));
+            const d3 v = pos2 - hpos2, w2 = ang2 - hang2;
+            const double w1y = ang1y - hang1y, w1z = ang1z - hang1z;      // (w1.x == 0)
+            f1 = f1 + mk3(C.dA1 * v.x, C.dB1 * v.y - C.dF1 * (w1z + w2.z), C.dB1 * v.z + C.dF1 * (w1y + w2.y));
             if (!C.homogeneous)
-                f2 = f2 + mk3(-C.dA2 * v.x, -C.dB2 * v.y + C.dF2 * (w1.z + w2.z), -C.dB2 * v.z - C.dF2 * (w1.y + w2.y));
-            m1 = m1 + mk3(-C.dT1 * (w2.x - w1.x), C.dG1 * v.z + C.dH1 * (2 * w1.y + w2.y), -C.dG1 * v.y + C.dH1 * (2 * w1.z + w2.z));
-            m2 = m2 + mk3(C.dT2 * (w2.x - w1.x), C.dG2 * v.z + C.dH2 * (w1.y + 2 * w2.y), -C.dG2 * v.y + C.dH2 * (w1.z + 2 * w2.z));
+                f2 = f2 + mk3(-C.dA2 * v.x, -C.dB2 * v.y + C.dF2 * (w1z + w2.z), -C.dB2 * v.z - C.dF2 * (w1y + w2.y));
+            m1 = m1 + mk3(-C.dT1 * w2.x, C.dG1 * v.z + C.dH1 * (2 * w1y + w2.y), -C.dG1 * v.y + C.dH1 * (2 * w1z + w2.z));
+            m2 = m2 + mk3(C.dT2 * w2.x, C.dG2 * v.z + C.dH2 * (w1y + 2 * w2.y), -C.dG2 * v.y + C.dH2 * (w1z + 2 * w2.z));
         }
         // _LastPos2 / _LastAngle1 / _LastAngle2 in the layout of the mode that produced them (ang1 == 0 in small mode;
         // pos2.y == pos2.z == ang1.x == 0 in large mode)
-        H.p0 = pos2.x; H.p1 = small ? pos2.y : ang1.y; H.p2 = small ? pos2.z : ang1.z;
+        H.p0 = pos2.x; H.p1 = small ? pos2.y : ang1y; H.p2 = small ? pos2.z : ang1z;
         H.g0 = ang2.x; H.g1 = ang2.y; H.g2 = ang2.z;
         H.flags = (small ? 1u : 2u);
         H.store_hist = true;

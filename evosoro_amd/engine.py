@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_inspect_constants", "vxh_inspect_angle_excess", "vxh_get_angle_excess", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_create_multi", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_inspect_constants", "vxh_inspect_angle_excess", "vxh_get_angle_excess", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_create_multi", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims", "vxh_voxel_actuation",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_cm_trace", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version", "vxh_device_count"]
@@ -124,6 +124,7 @@ def load_library():
     lib.vxh_add_robots.argtypes = [P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(VxhRobotArrays), I, I, ctypes.POINTER(I)]
     lib.vxh_num_robots.argtypes = [P]
     lib.vxh_robot_dims.argtypes = [P, I, ctypes.POINTER(I), ctypes.POINTER(I), ctypes.POINTER(D), ctypes.POINTER(LL)]
+    lib.vxh_voxel_actuation.argtypes = [P, I, I, ctypes.POINTER(D), ctypes.POINTER(D), ctypes.POINTER(D)]
     lib.vxh_run.argtypes = [P]
     lib.vxh_step.argtypes = [P, LL]
     lib.vxh_reset.argtypes = [P]
@@ -307,6 +308,12 @@ class Engine(object):
         self._check(self._lib.vxh_robot_dims(self._h, robot, ctypes.byref(nvox), ctypes.byref(nbond),
                                              ctypes.byref(dt), ctypes.byref(steps)))
         return {"nvox": nvox.value, "nbond": nbond.value, "dt": dt.value, "planned_steps": steps.value}
+
+    def voxel_actuation(self, robot, voxel):
+        """(TempAmplitude, TempPeriod, phaseOffset) of one voxel as the reference's float members hold them (what `voxelyze -p` prints)"""
+        a, p, ph = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.vxh_voxel_actuation(self._h, robot, voxel, ctypes.byref(a), ctypes.byref(p), ctypes.byref(ph)))
+        return a.value, p.value, ph.value
 
     def run(self):
         self._check(self._lib.vxh_run(self._h))

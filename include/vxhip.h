@@ -174,6 +174,10 @@ int  vxh_add_robots(vxh_engine* e, const char* template_vxa, size_t template_len
 int  vxh_num_robots(const vxh_engine* e);
 int  vxh_robot_dims(const vxh_engine* e, int robot, int* nvox, int* nbond, double* dt, long long* planned_steps);
 
+/* Actuation parameters of one voxel as the reference holds them -- the float members CVXS_Voxel::TempAmplitude / TempPeriod /
+ * phaseOffset (VXS_Voxel.h:92-111, assigned in CVX_Sim::ResetSimulation, VX_Sim.cpp:880-990) widened to double: what `voxelyze -p`
+ * prints for Vox[0] every 100 steps (voxelyzeMain/main.cpp:99-101). */
+int  vxh_voxel_actuation(const vxh_engine* e, int robot, int voxel, double* temp_amplitude, double* temp_period, double* phase_offset);
 int  vxh_run(vxh_engine* e);                         /* every robot to its own stop condition */
 int  vxh_step(vxh_engine* e, long long nsteps);      /* at most nsteps more TimeStep()s per robot */
 int  vxh_reset(vxh_engine* e);                       /* back to the imported state (ResetSimulation) */

@@ -953,6 +953,12 @@ void vxo_get_bond_table(const vxo_sim* s, int* v1, int* v2, int* axis)
     for (int i = 0; i < s->nbond; i++) { v1[i] = s->bond[i].v1; v2[i] = s->bond[i].v2; axis[i] = s->bond[i].axis; }
 }
 
+/* instrument: the SmallAngle flag of every bond (1 = small-angle branch of CalcLinForce), in bond-table order */
+void vxo_get_bond_modes(const vxo_sim* s, int* small)
+{
+    for (int i = 0; i < s->nbond; i++) small[i] = s->bond[i].small_angle;
+}
+
 /* the constants Import leaves on every voxel (SetMaterial, VX_Voxel.cpp:94-128) and bond (UpdateConstants, VX_Bond.cpp:95-173), for the
  * bit-for-bit comparison with the product's host model (tests/test_capi.py): 12 doubles per voxel, 23 per bond */
 void vxo_get_constants(const vxo_sim* s, double* vox12n, double* bond23n)

@@ -85,6 +85,7 @@ long     vxo_step(vxo_sim* s, long max_steps);    /* main loop; returns steps ta
 void     vxo_get_info(const vxo_sim* s, vxo_info* out);
 void     vxo_get_state(const vxo_sim* s, double* out14n); /* per voxel: pos3, quat wxyz, scale, vel3, angvel3 */
 void     vxo_get_bond_table(const vxo_sim* s, int* vox1, int* vox2, int* axis);
+void     vxo_get_bond_modes(const vxo_sim* s, int* small);      /* instrument: SmallAngle flag per bond */
 void     vxo_get_result(const vxo_sim* s, vxo_result* out);
 void     vxo_get_constants(const vxo_sim* s, double* vox12n, double* bond23n); /* per voxel / per bond constants of Import (see vx_oracle.c) */
 void     vxo_jitter(vxo_sim* s, unsigned seed);   /* test instrument: every position component one ulp up or down (see vx_oracle.c) */

@@ -95,6 +95,7 @@ def lib(half_angle=False):
         _lib.vxo_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(VxoInfo)]
         _lib.vxo_get_state.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_bond_table.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.vxo_get_bond_modes.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_get_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib.vxo_jitter.argtypes = [ctypes.c_void_p, ctypes.c_uint]
         if hasattr(_lib, "vxo_set_state"):
@@ -330,6 +331,12 @@ class OracleSim(object):
         v1, v2, ax = (np.zeros(n, dtype=np.int32) for _ in range(3))
         self._lib.vxo_get_bond_table(self._h, v1.ctypes.data, v2.ctypes.data, ax.ctypes.data)
         return v1, v2, ax
+
+    def bond_modes(self):
+        """instrument: 1 where the bond is in the small-angle branch, in bond-table order"""
+        out = np.zeros(self.info().nbond, dtype=np.int32)
+        self._lib.vxo_get_bond_modes(self._h, out.ctypes.data)
+        return out
 
     def step_jittered(self, n, seed=1):
         """n steps, every position component moved by one ulp (up or down, pseudo-random) before each of them: the twin run that

@@ -36,6 +36,35 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_on_the_stub():
     assert out["multi_handle"]["robots"] == 6 and out["multi_handle"]["value"] > 0
 
 
+def test_no_default_group_collective_overlaps_a_timed_region(tmp_path):
+    """The N > 1 run, traced (VXH_BENCH_TRACE): on a GPU node the default group is RCCL, whose collectives are kernels that spin on
+    the device until every rank has arrived -- so no collective of the DEFAULT group may be in flight, on any rank, while any rank
+    (or rank 0's handle over all the devices) is inside a timed region; whatever coordinates the ranks around those regions must go
+    over the host-side control group.  And the default group must carry the fitness gather and nothing else."""
+    prefix = str(tmp_path / "trace")
+    proc = _run([sys.executable, os.path.join(REPO, "tests", "bench_stub_runner.py"), "--gpus", "2"] + SMALL,
+                {"VXH_BENCH_SHARE_GPU": "1", "VXH_BENCH_TRACE": prefix})
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    out = _line(proc)
+    assert "gloo host group" in out["control_plane"]
+    events = []
+    for rank in (0, 1):
+        with open("%s.rank%d.jsonl" % (prefix, rank)) as f:
+            events += [json.loads(ln) for ln in f if ln.strip()]
+    regions = [e for e in events if e["op"] in ("timed_region", "multi_handle_region")]
+    assert len([e for e in regions if e["op"] == "timed_region"]) >= 5      # weak + strong on both ranks, the handle's on rank 0
+    assert len([e for e in regions if e["op"] == "multi_handle_region"]) == 1
+    default_ops = [e for e in events if e["group"] == "default"]
+    assert default_ops and set(e["op"] for e in default_ops) == {"all_gather_into_tensor"}, sorted(set(e["op"] for e in default_ops))
+    for r in regions:
+        for e in default_ops:
+            assert e["t1"] <= r["t0"] or e["t0"] >= r["t1"], ("a default-group collective overlaps a timed region", e, r)
+    # ... and the ranks that wait while rank 0 times the handle wait in a control-group barrier that spans it
+    handle = [e for e in regions if e["op"] == "multi_handle_region"][0]
+    waits = [e for e in events if e["rank"] == 1 and e["op"] == "barrier" and e["group"] == "ctl" and e["t0"] <= handle["t0"] and e["t1"] >= handle["t1"]]
+    assert waits, "rank 1 did not sit in a host-side barrier during the multi_handle measurement"
+
+
 def test_gpus_more_than_visible_fails_loudly():
     proc = _run([sys.executable, os.path.join(REPO, "tests", "bench_stub_runner.py"), "--gpus", "4"] + SMALL, {"VXH_STUB_GPUS": "1"})
     assert proc.returncode != 0

@@ -140,6 +140,32 @@ def test_cli_writes_reference_xml(eng_mod, golden_dir, tmp_path):
         assert [l for l in got_lines if "NormFinalDist" in l] == [l for l in want_lines if "NormFinalDist" in l]
 
 
+def test_cli_progress_output_is_the_references(eng_mod, golden_dir, tmp_path):
+    """`voxelyze -f x.vxa -p`, the reference CLI's only diagnostic (voxelyzeMain/main.cpp:60-63,92-104,128): the import message, then
+    every 100 steps Time / |CM| / Vox[0] scale, TempAmp, TempPer, phaseOffset, then "Ended at:".  Compared line by line with what the
+    reference binary printed for the same file (tests/golden/expected/soft5_init0.p.txt, written by make_golden.py): text lines equal,
+    numbers equal to the six significant digits the reference prints (a last-digit difference of a printed number is allowed: the
+    engine is within 1e-12 voxel, but a value may sit on a rounding boundary of the print)."""
+    import subprocess
+    os.makedirs(tmp_path / "golden_run" / "fitnessFiles")
+    proc = subprocess.run([eng_mod.CLI_PATH, "-f", os.path.join(golden_dir, "vxa", "soft5_init0.vxa"), "-p"], cwd=tmp_path, timeout=600,
+                          stdout=subprocess.PIPE)
+    assert proc.returncode == 1
+    got = proc.stdout.decode().splitlines()
+    want = open(os.path.join(golden_dir, "expected", "soft5_init0.p.txt")).read().splitlines()
+    assert len(got) == len(want), (len(got), len(want), got[:12])
+    assert sum(1 for ln in want if ln.startswith("Time: ")) == 8 and want[-1].startswith("Ended at: ")
+    for g, w in zip(got, want):
+        if ": " in w and w.split(": ")[0] in ("Time", "CM", "Vox[0]  Scale", "Vox[0]  TempAmp", "Vox[0]  TempPer", "Vox[0]  phaseOffset", "Ended at"):
+            assert g.split(": ")[0] == w.split(": ")[0], (g, w)
+            a, b = float(g.split(": ")[1]), float(w.split(": ")[1])
+            assert abs(a - b) <= 1.5e-6 * max(abs(b), 1e-300), (g, w)
+        else:
+            assert g == w, (g, w)
+    assert os.path.exists(tmp_path / "golden_run" / "fitnessFiles" / "softbotsOutput--id_00003.xml") or \
+        len(os.listdir(tmp_path / "golden_run" / "fitnessFiles")) == 1
+
+
 def test_options_changed_between_runs_of_one_engine(eng_mod, golden_dir):
     """A captured step graph holds the kernel arguments of the moment of capture: switching the stepping kernels on ONE engine
     between runs (streaming with a graph -> resident -> streaming again) must leave nothing stale behind -- the streaming runs
@@ -1046,7 +1072,8 @@ def test_one_step_from_the_same_state(eng_mod, golden_dir):
     1e-10 voxel had not shown."""
     from oracle import vxoracle as vo
     for name, variant, nsteps in (("lw_hexapus", 1, 400), ("bench10_0", 0, 400), ("lw_swim6", 1, 300), ("grow5", 0, 400), ("rand6_col", 0, 400), ("lw_stiff5", 1, 300),
-                                  ("cfg1_00", 0, 300), ("cfg3_00", 1, 300)):      # (the last two: robots of BASELINE configs[1] and [3] at their full size)
+                                  ("cfg1_00", 0, 300), ("cfg3_00", 1, 300),       # (robots of BASELINE configs[1] and [3] at their full size)
+                                  ("phase4", 0, 742)):      # the chaotic robot, its whole run: whole trajectories of it are only held to 20 x its own spread (0.06 voxel); one step from the same state is not chaotic
         path = os.path.join(golden_dir, "vxa", name + ".vxa")
         model = vo.parse_vxa(path, variant)
         lat = model["lattice_dim"]

@@ -168,3 +168,27 @@ def test_the_test_instruments_leave_the_algorithm_alone(golden_dir):
         # mode on one side, a 1e-10-voxel event; everywhere else the noise stays noise)
         noise = np.array(noise)
         assert 0 < np.median(noise) <= 1e-14 and (noise > 5e-14).sum() <= 12, (name, np.median(noise), noise.max(), (noise > 5e-14).sum())
+
+
+def test_oracle_on_the_full_20_cube_equals_the_reference_binary(golden_dir, tmp_path):
+    """BASELINE configs[4] at its full size (8000 voxels, 22 800 bonds, self-collision on, the whole 781-step evaluation): the final state
+    of the C restatement hashes to what the reference binary's final state hashed to (tests/golden/make_cfg4_pin.py ->
+    expected/cfg4_full20.json: SHA-256 of the [8000, 14] doubles, IniCM and CurCM as hex floats) -- bit-exact, like every other pin of
+    the oracle.  The GPU tests of the tiled kernel (tests/test_gpu_tiled.py) compare with the oracle at this size; this closes the
+    chain to the reference."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_cfg4_pin", os.path.join(golden_dir, "make_cfg4_pin.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(golden_dir, "expected", "cfg4_full20.json")) as f:
+        pin = json.load(f)
+    vxa = gen.cfg4_vxa(str(tmp_path))
+    assert gen.vxa_digest(vxa) == pin["vxa_sha256"]      # the same input (environment, materials, structure)
+    sim = vo.OracleSim.from_vxa(vxa)
+    sim.step(-1)
+    info = sim.info()
+    assert (info.nvox, info.nbond, info.steps) == (pin["nvox"], pin["nbond"], pin["total_steps"])
+    assert [float(x).hex() for x in info.ini_cm] == pin["ini_cm_hex"]
+    assert [float(x).hex() for x in info.cur_cm] == pin["cur_cm_hex"]
+    assert gen.state_digest(sim.state()) == pin["final_state_sha256"]
