@@ -7,6 +7,8 @@ namespace vxh {
 // one palette), read through the scalar/L1 caches instead of streaming ~170 B of constants per bond
 struct DVoxClass {
     double mass, mass_inv, inertia_inv, c_lin, c_ang, E, k_floor, u_static, u_dynamic, cte, nom_size;
+    double prenatal_k;   // (float)nom_size / nom_size - 1: the factor of the _voxcad PreNatal term (VXS_Voxel.cpp:236-246: initialVoxelSize is a float
+                         // member), a constant of the class -- the kernels used to divide for it per voxel and step
     int mat, pad;
 };
 struct DBondClass {

@@ -681,6 +681,7 @@ void Engine::prepare()
             d.mass = c.mass; d.mass_inv = c.mass_inv; d.inertia_inv = c.inertia_inv; d.c_lin = c.c_lin; d.c_ang = c.c_ang;
             d.E = c.E; d.k_floor = c.k_floor; d.u_static = c.u_static; d.u_dynamic = c.u_dynamic; d.cte = c.cte;
             d.nom_size = c.nom_size; d.mat = c.mat;
+            d.prenatal_k = ((double)(float)c.nom_size / c.nom_size) - 1;
             vtab[vtab_begin + i] = d;
         }
         for (size_t i = 0; i < M.bond_classes.size(); ++i) {
@@ -1241,15 +1242,20 @@ void Engine::advance(long long max_rounds)
         advance_finish();
     } catch (const TileTimeout& e) {
         // The tiles of a robot are co-resident workgroups that wait for each other: a second process on the GPU can keep some of them
-        // off the chip until the bounded spins give up.  The robots' state of before the call is gone -- but a call that started
-        // from the imported state can simply be made again without the tiled kernel (streaming kernels for what the resident one
-        // cannot take: slower, and the same trajectories to 1e-12 voxel).  A call in the middle of a run cannot: the error stands.
-        if (before != 0 || tiled_ == 0) throw;
-        std::fprintf(stderr, "vxhip: %s -- this batch is stepped again without the tiled kernel, which stays off for this engine\n", e.what());
+        // off the chip until the bounded spins give up.  The robots' state of before the call is gone -- but the evaluation is a
+        // deterministic function of the imported state, which the engine still holds: the batch is assembled again without the tiled
+        // kernel (streaming kernels for what the resident one cannot take: slower, the same trajectories to 1e-12 voxel) and stepped
+        // from the start up to where this call was to end -- a call in the middle of a run too (round 4; until then only a call that
+        // started from the imported state was made again, and with several `voxelyze` processes on one GPU, the reference's own
+        // launch pattern, this is the path that is hit).  The tiled kernel stays off for this engine.
+        if (tiled_ == 0 || !tiling_allowed_) throw;
+        std::fprintf(stderr, "vxhip: %s -- this batch is stepped again%s without the tiled kernel, which stays off for this engine\n", e.what(),
+                     before != 0 ? " from its imported state" : "");
         dev_->pending.active = false;
         tiled_ = 0;
         prepare();
-        advance_launch(max_rounds);
+        const long long huge = 0x7fffffffffffffffLL / 4;
+        advance_launch(max_rounds >= huge - before ? huge : before + max_rounds);
         advance_finish();
     }
 }
@@ -1489,8 +1495,7 @@ void Engine::download_control(bool already_copied)
         H.cm_trace.assign((size_t)4 * std::min(S.ntrace, D.trace_cap[r]), 0.0);      // (filled by download())
         for (int k = 0; k < 3; ++k) H.ini_cm[k] = S.ini_cm[k];
         if (S.col_overflow) H.status = VXH_ROBOT_COL_OVERFLOW;
-        if (S.status == 5 || (inject_tile_timeout_ && !D.tile_launches.empty())) {
-            inject_tile_timeout_ = false;
+        if (S.status == 5 || (r == 0 && inject_tile_timeout_ > 0 && !D.tile_launches.empty() && --inject_tile_timeout_ == 0)) {
             throw TileTimeout("HIP: the tiles of robot " + std::to_string(r) + " timed out waiting for each other (is another process "
                               "using this GPU? set the engine option tiled = 0 then)");
         }

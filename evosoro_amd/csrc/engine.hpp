@@ -1,5 +1,6 @@
 // Batched engine: owns the robots of one population shard and their SoA state on ONE HIP device.
 #pragma once
+#include <algorithm>
 #include <stdexcept>
 #include <cstdlib>
 #include <functional>
@@ -99,7 +100,8 @@ private:
     int tiled_ = 1;                            // several workgroups per robot (kernels_tiled.hpp): 0 never, 1 when the population is too
                                                // small to fill the CUs one robot each or a robot has more than 1024 voxels, 2 always
     int tiles_per_robot_ = 0;                  // 0 = chosen from the population size; > 0: requested for every tiled robot (tests)
-    bool inject_tile_timeout_ = std::getenv("VXH_INJECT_TILE_TIMEOUT") != nullptr;   // fault injection for tests/test_gpu_tiled.py: the first tiled call reports a timeout
+    // fault injection for tests/test_gpu_tiled.py: VXH_INJECT_TILE_TIMEOUT=n, the n-th tiled call of the engine reports a timeout (1 = the first)
+    int inject_tile_timeout_ = std::getenv("VXH_INJECT_TILE_TIMEOUT") ? std::max(1, std::atoi(std::getenv("VXH_INJECT_TILE_TIMEOUT"))) : 0;
     bool wide_two_tiles_ = true;               // ... with a second pose tile in LDS where it fits (two barriers per step instead of three); 0: cross-checks
     bool wide_ = true;                         // small robots (up to 512 voxels, 1023 bonds) go to the wide kernel (kernels_wide.hpp); 0: resident kernel
     int col_cap_ = 0;                          // partners a contact row can hold; 0 = every other surface voxel (unbounded, like the reference)

@@ -130,14 +130,16 @@ __device__ __forceinline__ double vsqrt(double x)
     d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
 }
-// 1 / sqrt(x), x > 0 normal: v_rsq_f64 + two Newton steps (<= 1 ulp)
+// 1 / sqrt(x), x > 0 normal: v_rsq_f64 + ONE third-order step, <= 1 ulp.  With e = 1 - x y0^2 the exact value is y0 / sqrt(1 - e) =
+// y0 (1 + e/2 + 3 e^2/8 + 5 e^3/16 + ...); v_rsq_f64 is good to 2^-23 (|e| <= 2^-22), so the series cut after e^2 is off by 2^-68
+// and what is left is rounding: half an ulp from the product x y0 inside e, half from the final fused multiply-add.  (Until round
+// 4 a second, second-order step followed: four more instructions per call, five to six calls per large-angle bond, for the last
+// quarter of an ulp.)
 __device__ __forceinline__ double vrsqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
     double e = __builtin_fma(-x * y, y, 1.0);
-    y = __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);      // y (1 + e/2 + 3 e^2/8)
-    e = __builtin_fma(-x * y, y, 1.0);
-    return __builtin_fma(y * e, 0.5, y);
+    return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);      // y (1 + e/2 + 3 e^2/8)
 }
 __device__ __forceinline__ double vsqrt_nn(double x) { const double s = vsqrt(x); return x == 0 ? 0.0 : s; }
 __device__ __forceinline__ double vrcp(double b)
@@ -189,28 +191,32 @@ __device__ __forceinline__ double vacos(double x)
     return 1.5707963267948966 - (x + __builtin_fma(x, p, -6.123233995736766e-17));
 }
 
-// max of a non-negative double over the 64 lanes of a (fully active) wavefront, returned in every lane: four DPP row shifts, two
-// row broadcasts (VALU speed; a shuffle through the LDS crossbar costs ten times as much per stage, an LDS atomic on one address
-// serialises its 64 lanes)
+// max of a non-negative double over the 64 lanes of a (fully active) wavefront, returned in every lane.  Non-negative doubles order
+// like their bit patterns read as unsigned 64-bit integers, i.e. lexicographically by (high word, low word): the maximum of the
+// high words first (v_max_u32 takes a DPP source: ONE instruction per stage -- four row shifts, two row broadcasts), then the
+// maximum of the low words among the lanes that hold that high word.  14 vector instructions where the FP64 compare-and-select
+// version (v_max_f64 is VOP3: no DPP) took 36; same bits.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_max_stage(double v)
+__device__ __forceinline__ unsigned dpp_umax_stage(unsigned v)
 {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
-    const double o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));     // 0.0 where no lane feeds this one
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);     // 0 where no lane feeds this one
     return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v)
+{
+    v = dpp_umax_stage<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_umax_stage<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_umax_stage<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_umax_stage<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row of 16 holds the row's maximum
+    v = dpp_umax_stage<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_umax_stage<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ double wave_max_nonneg(double v)
 {
-    v = dpp_max_stage<0x111, 0xf>(v);      // row_shr:1
-    v = dpp_max_stage<0x112, 0xf>(v);      // row_shr:2
-    v = dpp_max_stage<0x114, 0xf>(v);      // row_shr:4
-    v = dpp_max_stage<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row of 16 holds the row's maximum
-    v = dpp_max_stage<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
-    v = dpp_max_stage<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    const unsigned hi = wave_umax((unsigned)(b >> 32));
+    const unsigned lo = wave_umax((unsigned)(b >> 32) == hi ? (unsigned)b : 0u);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
@@ -740,7 +746,7 @@ __device__ __forceinline__ void voxel_update_ang(const DBatch& B, const DRobot& 
         if (new_scale < scale && new_scale < min_scale) new_scale = scale;
         if (new_scale > scale && new_scale > max_scale) new_scale = scale;
     } else if (!(flags & RF_LW)) {
-        const double prenatal = prenatal_c * (((float)C.nom_size / C.nom_size) - 1);
+        const double prenatal = prenatal_c * C.prenatal_k;       // prenatal_c * ((float)nom / nom - 1), the quotient formed at import (same rounding)
         double ctrl = 0;
         if ((flags & RF_TEMP) && t >= R.init_cm_time)
             ctrl = (double)amp_damp * ((double)R.temp_amplitude * act) * C.cte;

@@ -47,8 +47,9 @@ enum vxh_variant { VXH_VOXCAD = 0, VXH_VOXCAD_LAND_WATER = 1 };
  * forever and evosoro times it out (evaluation.py:107-119). */
 enum vxh_robot_status { VXH_ROBOT_PENDING = 0, VXH_ROBOT_FINISHED = 1, VXH_ROBOT_DIVERGED = 2, VXH_ROBOT_EMPTY = 3,
                         VXH_ROBOT_COL_OVERFLOW = 4,
-                        VXH_ROBOT_SYNC_TIMEOUT = 5 /* device side only: a vxh_run / vxh_step that started from the imported state is made again without
-                                                      the tiled kernel, one in the middle of a run fails with VXH_ERR_HIP */ };
+                        VXH_ROBOT_SYNC_TIMEOUT = 5 /* device side only, never reported: the call is made again without the tiled kernel -- the
+                                                      batch is stepped from its imported state up to where the call was to end (also
+                                                      a call in the middle of a run: the evaluation is deterministic) */ };
 
 typedef struct vxh_result {
     int status;            /* vxh_robot_status */

@@ -18,15 +18,27 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 
 
-def cfg4_vxa(tmp):
-    """the configs[4] robot exactly as the GPU tests and bench.py build it (workloads.full_material(20, 1), 0.05 s, InitCmTime 0.01)"""
+def cfg4_vxa(tmp, run_directory=None, ident=0):
+    """the configs[4] robot exactly as the GPU tests and bench.py build it (workloads.full_material(20, 1), 0.05 s, InitCmTime 0.01);
+    run_directory: what the file names inside the .vxa start with (default: tmp itself)"""
     from evosoro_amd import workloads
     from evosoro_amd.base import Sim, Env
     from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
-    os.makedirs(os.path.join(tmp, "voxelyzeFiles"), exist_ok=True)
     sim = Sim(dt_frac=0.9, simulation_time=0.05, fitness_eval_init_time=0.01)
-    write_voxelyze_file(sim, Env(), workloads.make_individual(0, workloads.full_material(20, 1)), tmp, "c4")
-    return os.path.join(tmp, "voxelyzeFiles", "c4--id_00000.vxa")
+    ind = workloads.make_individual(ident, workloads.full_material(20, 1))
+    if run_directory is None:
+        os.makedirs(os.path.join(tmp, "voxelyzeFiles"), exist_ok=True)
+        write_voxelyze_file(sim, Env(), ind, tmp, "c4")
+        return os.path.join(tmp, "voxelyzeFiles", "c4--id_%05i.vxa" % ident)
+    here = os.getcwd()
+    os.chdir(tmp)
+    try:
+        for d in ("voxelyzeFiles", "fitnessFiles"):
+            os.makedirs(os.path.join(run_directory, d), exist_ok=True)
+        write_voxelyze_file(sim, Env(), ind, run_directory, "c4")
+    finally:
+        os.chdir(here)
+    return os.path.join(tmp, run_directory, "voxelyzeFiles", "c4--id_%05i.vxa" % ident)
 
 
 def vxa_digest(path):
@@ -62,6 +74,16 @@ def main():
     with open(os.path.join(HERE, "expected", "cfg4_full20.json"), "w") as f:
         json.dump(pin, f, indent=1)
     print(json.dumps(pin, indent=1))
+    # the same robot as a golden CASE for the command-line tests (tests/test_gpu_cli.py: a lattice above 1024 voxels among the
+    # concurrent `voxelyze -f` processes): the .vxa with the goldens' relative run directory and the result XML the reference
+    # binary writes for it
+    import shutil
+    ref = os.path.join(REPO, "oracle", "_ref", "voxelyze_ref")
+    with tempfile.TemporaryDirectory() as tmp:
+        vxa = cfg4_vxa(tmp, run_directory="golden_run", ident=900)
+        subprocess.run(["timeout", "1800", ref, "-f", vxa], check=False, cwd=tmp, stdout=subprocess.DEVNULL)
+        shutil.copy(vxa, os.path.join(HERE, "vxa", "cfg4_full20.vxa"))
+        shutil.copy(os.path.join(tmp, "golden_run", "fitnessFiles", "softbotsOutput--id_00900.xml"), os.path.join(HERE, "expected", "cfg4_full20.xml"))
 
 
 if __name__ == "__main__":

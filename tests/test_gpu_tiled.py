@@ -151,7 +151,9 @@ def test_a_timed_out_tiled_call_is_made_again_without_tiling(tmp_path):
     (VXH_ROBOT_SYNC_TIMEOUT).  A call that started from the imported state is then made again without the tiled kernel instead of
     failing the generation (Engine::advance); the timeout is injected here (VXH_INJECT_TILE_TIMEOUT: the first tiled call reports
     one).  The lattice above 1024 voxels must come out as an engine with tiled = 0 steps it, bit for bit, the small robot next to
-    it too.  (A call in the middle of a run cannot be repeated -- the state before it is gone -- and keeps failing with VXH_ERR_HIP.)"""
+    it too.  Round 4: a call in the MIDDLE of a run is repeated as well -- the state before it is gone, but the evaluation is a
+    deterministic function of the imported state, so the batch is stepped again from there up to where the call was to end
+    (VXH_INJECT_TILE_TIMEOUT=2: the second tiled call, i.e. steps 101-200, reports the timeout)."""
     import subprocess, sys, textwrap
     from evosoro_amd import workloads
     from evosoro_amd.base import Sim, Env
@@ -171,7 +173,10 @@ def test_a_timed_out_tiled_call_is_made_again_without_tiling(tmp_path):
         with e.Engine(e.VOXCAD, 0) as eng:
             eng.set_option("tiled", 0 if mode == "untiled" else 1)
             eng.add_vxa_files(paths)
-            eng.step(200)
+            if mode.endswith("2"):
+                eng.step(100); eng.step(100)
+            else:
+                eng.step(200)
             np.save(out, np.concatenate([eng.state(0).ravel(), eng.state(1).ravel()]))
             print("kernel of most voxel-steps:", eng.counters().dominant_block)
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -183,7 +188,7 @@ def test_a_timed_out_tiled_call_is_made_again_without_tiling(tmp_path):
         env.pop("VXH_INJECT_TILE_TIMEOUT", None)
         env.pop("VXH_ENGINE_OPTIONS", None)
         if inject:
-            env["VXH_INJECT_TILE_TIMEOUT"] = "1"
+            env["VXH_INJECT_TILE_TIMEOUT"] = "2" if mode.endswith("2") else "1"
         out = str(tmp_path / (mode + ("_inj" if inject else "") + ".npy"))
         proc = subprocess.run([sys.executable, str(prog)] + paths + [mode, out], env=env, capture_output=True, timeout=600)
         return proc, (np.load(out) if os.path.exists(out) else None)
@@ -197,6 +202,10 @@ def test_a_timed_out_tiled_call_is_made_again_without_tiling(tmp_path):
     assert inj_proc.returncode == 0, inj_proc.stderr.decode()[-2000:]
     assert b"stepped again without the tiled kernel" in inj_proc.stderr
     assert np.array_equal(inj, ref)
+    mid_proc, mid = run("tiled2", True)           # the timeout in the second of two calls
+    assert mid_proc.returncode == 0, mid_proc.stderr.decode()[-2000:]
+    assert b"stepped again from its imported state without the tiled kernel" in mid_proc.stderr
+    assert np.array_equal(mid, ref)
 
 
 def test_one_step_of_the_full_20_cube_from_the_same_state(tmp_path):
