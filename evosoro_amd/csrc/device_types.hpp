@@ -29,7 +29,8 @@ enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_ST
                   RF_DEV = 256, RF_DEV_SIZE = 512 /* Initial- or FinalVoxelSize */, RF_DEV_FSIZE = 1024, RF_DEV_FPHASE = 2048, RF_DEV_FTAD = 4096 };
 
 struct DRobot {               // constant per robot
-    int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr, pad0;
+    int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr;
+    int sched_begin;          // resident kernel: this robot's bond schedule in DBatch::bsched ([3][workgroup size] entries, see there)
     long long excl_begin;     // first word of this robot's exclusion rows in DBatch::excl
     int vert_begin, nmv;      // surface-mesh vertices of this robot (land_water robots)
     int facet_begin, nfacet;  // its facets in DBatch::facet_vox / facet_vert
@@ -137,6 +138,10 @@ struct DBatch {
                                       // negative-end voxel | local positive-end voxel << 9 | axis << 18 | bond class << 20
     const int* wgather;               // [2][nv] wide kernel: the records of the voxel's six bonds (+X -X +Y -Y +Z -Z, 10 bits each, three
                                       // per word; DRobot::wzidx where the voxel has no bond in that direction)
+    const int* bsched;                // resident kernel (kernels_fused.hpp): per robot [3][BLOCK] packed bond entries (negative-end voxel | positive-end
+                                      // voxel << 10 | class << 20, -1 = none): what thread t evaluates in the X, Y and Z slot of a step.  X and Z: the
+                                      // t-th bond of the axis (compacted lists); Y: whole 64-bond chunks dealt to the wavefronts so that X and Y TOGETHER
+                                      // load the four SIMDs evenly (two accumulator tiles: X and Y are evaluated without a barrier between them)
     const int* blist;                 // [3*nv] fused path: per robot and axis the COMPACTED list of its bonds, entry t of axis a at
                                       // [a*nv + vox_begin + t] = local negative-end voxel | local positive-end voxel << 10 |
                                       // bond class << 20, -1 past the end of the list

@@ -605,6 +605,11 @@ void Engine::prepare()
     std::vector<unsigned short> vclass(nv, 0);
     std::vector<short> bclass((size_t)3 * nv, -1);
     std::vector<int> blist((size_t)3 * nv, -1);
+    // bond schedules of the resident kernel: [3][block] per robot, block = the workgroup size of the robot's size class
+    auto resident_block = [](int n) { return n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024)); };
+    std::vector<int> sched_off(nr + 1, 0);
+    for (int r = 0; r < nr; ++r) sched_off[r + 1] = sched_off[r] + ((robots_[r].nvox > 0 && robots_[r].nvox <= 1024) ? 3 * resident_block(robots_[r].nvox) : 0);
+    std::vector<int> bsched(std::max(sched_off[nr], 1), -1);
     std::vector<int> wgather((size_t)2 * nv, 0);
     std::vector<float> amp_damp(nv, 1.f);
     std::vector<double> act_sb(nv, 0.0), act_cb(nv, 1.0);
@@ -723,6 +728,43 @@ void Engine::prepare()
                 }
             }
         DRobot& R = D.h_robot[r];
+        R.sched_begin = sched_off[r];
+        if (M.nvox > 0 && M.nvox <= 1024 && M.bond_classes.size() <= 4095) {
+            // The resident kernel's bond schedule.  X and Z: bond j of the axis' compacted list to thread j.  Y: the kernel variants
+            // with two accumulator tiles (up to 768 threads) evaluate X and Y without a barrier between them -- an accumulator entry
+            // gets at most one X and one Y contribution per tile, both added to zero with LDS atomics, and a + b == b + a, so the sums
+            // are those of the barrier-separated rounds bit for bit -- and a wavefront's bond is a latency-bound chain (a lone
+            // wavefront issues a dependent FP64 instruction every ~7 cycles, three that share a SIMD one every ~4): the 64-bond
+            // chunks of Y are dealt to the wavefronts that X leaves idle, least-loaded SIMD first (wavefront w runs on SIMD w mod 4),
+            // so that X + Y occupy every SIMD with three to four chunk executions spread over its three wavefronts instead of
+            // two rounds of two.  The 1024-thread variant (one tile, two barrier-separated sub-steps per round) keeps Y in list order.
+            const int block = resident_block(M.nvox), nw = block / 64;
+            int* sx = &bsched[sched_off[r]], *sy = sx + block, *sz = sy + block;
+            std::vector<int> list[3];
+            for (int a = 0; a < 3; ++a)
+                for (int v = 0; v < M.nvox; ++v) {
+                    const int c = M.bond_class[(size_t)v * 3 + a];
+                    if (c >= 0) list[a].push_back((int)((unsigned)v | ((unsigned)M.nbr[(size_t)v * 6 + 2 * a] << 10) | ((unsigned)c << 20)));
+                }
+            for (size_t j = 0; j < list[0].size(); ++j) sx[j] = list[0][j];
+            for (size_t j = 0; j < list[2].size(); ++j) sz[j] = list[2][j];
+            if (block == 1024) { for (size_t j = 0; j < list[1].size(); ++j) sy[j] = list[1][j]; }
+            else {
+                const int nchx = ((int)list[0].size() + 63) / 64, nchy = ((int)list[1].size() + 63) / 64;
+                std::vector<int> simd_load(4, 0), wave_load(nw, 0), has_y(nw, 0);
+                for (int w = 0; w < nchx; ++w) { ++simd_load[w % 4]; ++wave_load[w]; }
+                for (int c = 0; c < nchy; ++c) {
+                    int best = -1;
+                    for (int w = 0; w < nw; ++w) {
+                        if (has_y[w]) continue;
+                        if (best < 0 || simd_load[w % 4] < simd_load[best % 4] ||
+                            (simd_load[w % 4] == simd_load[best % 4] && wave_load[w] < wave_load[best])) best = w;
+                    }
+                    has_y[best] = 1; ++simd_load[best % 4]; ++wave_load[best];
+                    for (int k = 0; k < 64 && (size_t)(64 * c + k) < list[1].size(); ++k) sy[64 * best + k] = list[1][(size_t)64 * c + k];
+                }
+            }
+        }
         R.wl_begin = wl_off[r]; R.wnbond = 0; R.wzidx = 0; R.wregion = 0;
         if (wide_listed(M)) {
             // wide kernel: all bonds in one list, axis after axis; a bond's place in it is the number of its record, and every voxel
@@ -861,6 +903,7 @@ void Engine::prepare()
     B.bclass = D.upload(bclass);
     B.nbr = D.upload(nbr);
     B.blist = D.upload(blist);
+    B.bsched = D.upload(bsched);
     B.wlist = D.upload(wlist);
     B.wgather = D.upload(wgather);
     B.act_sb = D.upload(act_sb);

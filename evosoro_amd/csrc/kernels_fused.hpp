@@ -743,10 +743,10 @@ __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, co
     if (has) {
         o = fused_bond<A, BLOCK, MESH>(B, R, bct, ps, entry, modebits, damp_on, st, st_stride);
         div = div || o.diverged;
-        fused_accumulate<BLOCK, A == 0>(acc, entry & 1023, o.f1, o.m1);
+        fused_accumulate<BLOCK, A == 0 && NACC == 1>(acc, entry & 1023, o.f1, o.m1);     // (plain stores only where a barrier orders them before every addition)
     }
     if constexpr (NACC == 1) __syncthreads();
-    if (has) fused_accumulate<BLOCK, A == 0 && NACC == 2>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
+    if (has) fused_accumulate<BLOCK, false>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
 }
 
 // Contact forces of my voxel (the head of voxel_update: same arithmetic, same order), in two passes over the wavefront's segment
@@ -907,13 +907,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #endif
     // ---- this thread's voxel (momenta -> registers, pose -> LDS, accumulators zeroed) and its three bonds
     const DVoxClass& C = vct[valid ? B.vclass[v] : 0];
-    int entry[3];                             // my bond of each axis round (DBatch::blist), -1 = none
+    int entry[3];                             // my bond of the X, Y and Z slot of a step (DBatch::bsched), -1 = none
     unsigned modebits = 0;                    // 2 bits per bond: SmallAngle, history layout (DBatch::hist)
     float amp_damp = 1.f;
     d3 lm = mk3(0, 0, 0), am = mk3(0, 0, 0);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        entry[a] = valid ? B.blist[(unsigned)a * nv + v] : -1;
+        entry[a] = B.bsched[R.sched_begin + a * BLOCK + tid];      // (also threads without a voxel: the Y chunks are dealt to the idle wavefronts)
         if (entry[a] != -1) modebits |= (unsigned)(B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] & 3) << (2 * a);
     }
     if (valid) {
@@ -1069,10 +1069,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         const bool damp_on = (kf & 32) != 0;
         VXH_T_MARK(1)
 
-        // ---- bond phase: three axis rounds over the compacted bond lists
+        // ---- bond phase.  Two accumulator tiles: the X and Y slots back to back, no barrier between them (every accumulator entry
+        // gets at most one X and one Y contribution, both ADDED to the zero the voxel phase left: a + b == b + a, the sums are those of
+        // barrier-separated rounds bit for bit; the Y chunks sit on the wavefronts X leaves idle: DBatch::bsched), barrier, the Z slot
+        // on top.  One tile (1024 threads): three rounds, each in two barrier-separated sub-steps.
         bool div = false;
         fused_round<0, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[0], modebits, damp_on, div, st, st_stride);
-        __syncthreads();
+        if constexpr (NACC == 1) __syncthreads();
         fused_round<1, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[1], modebits, damp_on, div, st, st_stride);
         __syncthreads();
         fused_round<2, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[2], modebits, damp_on, div, st, st_stride);

@@ -849,3 +849,73 @@ if __name__ == "__main__" and "satcheck" in sys.argv[1:]:
             timing_cfg(engine.VOXCAD, 2048, (6, 6, 6), 0.05, Env(), opts)
             timing_cfg(engine.VOXCAD, 512, (8, 8, 8), 0.05, Env(), opts)
             timing_cfg(engine.VOXCAD_LAND_WATER, 512, (8, 8, 8), 0.05, env_w, opts, per_voxel_phase=True)
+
+
+if __name__ == "__main__" and "cli30" in sys.argv[1:]:
+    # Round 4: a generation of evosoro's basic.py shape (pop 30, 6x6x6, 0.5 s simulated... here the bench robots' defaults) through the
+    # COMMAND LINE the way evosoro/tools/evaluation.py:59-90 drives it -- one `voxelyze -f` process per robot, all at once -- wall clock
+    # from the first Popen to the last exit: the reference binary on the host cores, our binary with every process stepping its own
+    # robot (VXH_BROKER=0), and our binary through the broker (first generation = incl. starting the broker and the HIP runtime).
+    import subprocess
+    import json as _json
+    pop = int(os.environ.get("VXH_CLI_POP", "30"))
+    out = {"pop": pop, "shape": [6, 6, 6]}
+    ref = os.path.join(REPO, "oracle", "_ref", "voxelyze_ref")
+
+    def generation(binary, env_extra, tag, rep):
+        work = tempfile.mkdtemp(prefix="cli30_%s%d_" % (tag, rep))
+        for d in ("voxelyzeFiles", "fitnessFiles", "tempFiles"):
+            os.makedirs(os.path.join(work, "run", d))
+        sim = Sim(self_collisions_enabled=True, dt_frac=0.9, simulation_time=0.5, fitness_eval_init_time=0.1)
+        here = os.getcwd()
+        os.chdir(work)
+        files = []
+        for i in range(pop):
+            ind = workloads.random_robot(i, (6, 6, 6), 1000 * rep + i)
+            write_voxelyze_file(sim, Env(), ind, "run", "g")
+            files.append(os.path.join("run", "voxelyzeFiles", "g--id_%05i.vxa" % i))
+        os.chdir(here)
+        env = dict(os.environ, **env_extra)
+        t0 = time.time()
+        procs = [subprocess.Popen([binary, "-f", f], cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for f in files]
+        for p in procs:
+            p.wait()
+        wall = time.time() - t0
+        done = len([f for f in os.listdir(os.path.join(work, "run", "fitnessFiles")) if f.endswith(".xml")])
+        return wall, done, [p.returncode for p in procs].count(1)
+
+    sock = os.path.join(tempfile.mkdtemp(), "b.sock")
+    for tag, binary, env_extra, reps in (("reference_cpu", ref, {}, 2), ("direct", engine.CLI_PATH, {"VXH_BROKER": "0"}, 2),
+                                         ("broker", engine.CLI_PATH, {"VXH_BROKER_SOCKET": sock, "VXH_BROKER_IDLE_S": "20"}, 3)):
+        if not os.path.exists(binary):
+            continue
+        rows = []
+        for rep in range(reps):
+            wall, done, ok = generation(binary, env_extra, tag, rep)
+            rows.append({"wall_s": wall, "result_files": done, "exit_1": ok})
+            print("%-14s generation %d: %.3f s, %d result files, %d processes returned 1" % (tag, rep, wall, done, ok), flush=True)
+        out[tag] = rows
+    subprocess.run([engine.CLI_PATH, "--broker-quit"], env=dict(os.environ, VXH_BROKER_SOCKET=sock), stdout=subprocess.DEVNULL)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "r04_cli_generation_pop%d.json" % pop), "w") as f:
+        _json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__" and "statehash" in sys.argv[1:]:
+    # a digest of every voxel's state of 48 bench robots (10^3, self-collision) + 16 dense 9^3 ones after 700 steps: two builds of the
+    # library that claim the same arithmetic in another schedule must print the same line (scripts/ab_lib.py <lib> statehash)
+    import hashlib
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    sim = Sim(self_collisions_enabled=True, dt_frac=0.9, simulation_time=0.2, fitness_eval_init_time=0.01)
+    with engine.Engine(engine.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 0)
+        inds = [workloads.random_robot(i, (10, 10, 10), i) for i in range(48)] + [workloads.make_individual(100 + i, workloads.full_material(9, 1 + i)) for i in range(16)]
+        for ind in inds:
+            write_voxelyze_file(sim, Env(), ind, tmp, "h")
+            eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "h--id_%05i.vxa" % ind.id))
+        eng.step(300); eng.step(400)
+        h = hashlib.sha256()
+        for i in range(len(inds)):
+            h.update(np.ascontiguousarray(eng.state(i)).tobytes())
+        print("%s statehash %s (%d robots, 700 steps, kernel of most voxel-steps %d)" % (os.path.basename(engine.LIB_PATH), h.hexdigest()[:24], len(inds), eng.counters().dominant_block), flush=True)
