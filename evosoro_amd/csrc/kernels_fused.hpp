@@ -1146,7 +1146,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
                                 SLIM ? B.act_sb[vv] : pht[tid], SLIM ? B.act_cb[vv] : pht[BLOCK + tid], amp_damp);
             lm = S.lm; am = S.am;
         }
-        if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);   // next step's control, off the critical path
+        // next step's control, off the critical path.  (Round 4, measured and taken out again: the same call issued earlier -- next to the
+        // X / Y chunks with one Y chunk fewer on this wavefront, 25.2 -> 26.0 us per step: that slot is issue-bound on every SIMD; or
+        // during the Z slot, which leaves this wavefront idle, 25.3 -> 25.45: the developer timers show this wavefront last at barrier
+        // (C), but the voxel wavefronts sharing its SIMD finish at the same time with or without it.)
+        if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);
         if ((R.flags & RF_SELF_COL) && !VXH_DBG(2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
             vel2 = wave_max_nonneg(vel2);       // (DPP: VALU speed)
             if ((tid & 63) == 0) atomicMax(&rs.maxvel2_bits, (unsigned long long)__double_as_longlong(vel2));
