@@ -1073,6 +1073,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // gets at most one X and one Y contribution, both ADDED to the zero the voxel phase left: a + b == b + a, the sums are those of
         // barrier-separated rounds bit for bit; the Y chunks sit on the wavefronts X leaves idle: DBatch::bsched), barrier, the Z slot
         // on top.  One tile (1024 threads): three rounds, each in two barrier-separated sub-steps.
+        // (Measured and not kept, round 4: Z EVALUATED in the same barrier-free stretch, its chunks dealt like Y's -- 21 chunks on 12
+        // wavefronts, 6 / 5 / 5 / 5 per SIMD -- and its twelve outputs held in registers across the barrier that orders them behind
+        // X + Y: the held outputs raise the peak of the bond's register need, 28 -> 124 B of scratch, 25.5 -> 25.9 us per step.)
         bool div = false;
         fused_round<0, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[0], modebits, damp_on, div, st, st_stride);
         if constexpr (NACC == 1) __syncthreads();
