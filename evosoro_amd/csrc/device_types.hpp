@@ -28,6 +28,8 @@ enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_ST
                   // _voxcad development (VXS_Voxel.cpp:236-328): any layer present / which ones
                   RF_DEV = 256, RF_DEV_SIZE = 512 /* Initial- or FinalVoxelSize */, RF_DEV_FSIZE = 1024, RF_DEV_FPHASE = 2048, RF_DEV_FTAD = 4096 };
 
+enum { VXH_RIMG_CAP = 2048 };     // entries of a saved contact-row image (the LDS pool holds at most 24 KB / 12 B)
+
 struct DRobot {               // constant per robot
     int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr;
     int sched_begin;          // resident kernel: this robot's bond schedule in DBatch::bsched ([3][workgroup size] entries, see there)
@@ -44,7 +46,9 @@ struct DRobot {               // constant per robot
     int trace_begin, trace_cap;   // this robot's entries of DBatch::trace
     float temp_amplitude, temp_period;
     long long col_begin;          // first entry of this robot's block of contact rows in DBatch::col_partner / col_a1 / col_code
-    int col_cap, pad1;            // partners a row can hold.  Default nsurf - 1: every other surface voxel, i.e. unbounded like the
+    int col_cap;
+    int img_index;                // resident kernel: this robot's slot in DBatch::rimg_* (the saved LDS image of its contact rows), -1 = none
+                                  // col_cap: partners a row can hold.  Default nsurf - 1: every other surface voxel, i.e. unbounded like the
                                   // reference's lists (CreateColBond, VX_Sim.cpp:753-769); engine option col_cap sets a smaller one
     // wide kernel (kernels_wide.hpp): the robot's combined bond list in DBatch::wlist and its length, the record number that stays zero (what the
     // missing directions of a voxel point at), doubles of LDS its bond records / scratch take
@@ -58,9 +62,12 @@ struct DRobotState {          // mutable per robot
     double act_sin, act_cos;      // streaming path: sincos of the actuation phase of the current step (actuation_sincos)
     unsigned long long maxvel2_bits;
     int steps, status, cm_init, active, diverged, col_overflow, rebuild_now, rebuilds;
+    int rows_img, pad_rs;         // resident kernel: DBatch::rimg_* hold the LDS image of this robot's contact rows as the last launch left it
     int col_tiled, ntrace;        // the contact rows were built by the tiled kernel (DBatch::col_code / tile_xh are valid for them) ; points
                                   // of the centre-of-mass trace recorded so far (SS.CMTrace, VX_Sim.cpp:1537-1547)
     double last_trace_time;
+    double act_time;              // resident / wide / tiled kernels: act_sin / act_cos are those of this simulated time (stashed at the end of a launch
+                                  // for the first step of the next one; -1: nothing stashed)
 };
 
 // Tiled path (kernels_tiled.hpp): a robot cut into `ntiles` tiles, one workgroup each.  A tile OWNS n_own voxels (it
@@ -170,6 +177,10 @@ struct DBatch {
     const unsigned long long* excl;   // CalcNearby exclusion as bit rows: per robot nsurf rows of excl_wpr 64-bit words,
                                       // bit j of row i set when surface voxels i and j are within the hop horizon
     int* col_cnt;                     // [total surface voxels]
+    // resident kernel: the workgroup's LDS copy of a robot's contact rows (rows_to_lds: pair codes, pair stiffnesses, the wavefronts'
+    // segments, every thread's row descriptor), saved whenever it is built and streamed back at the start of the next launch -- one
+    // round trip of coalesced loads instead of ordinal -> count -> scan -> rows, three dependent round trips and three barriers
+    int* rimg_code; double* rimg_a1; int* rimg_seg; int* rimg_rowd;     // [n_img * VXH_RIMG_CAP] x 2, [n_img * 64], [nv]
     int col_rows, pad2;               // total surface voxels of colliding robots
     int* col_partner;                 // per robot a block [col_cap][nsurf] (partner-major; kernels.hpp col_at) of global voxel slots
     double* col_a1;                   // same shape: linear stiffness a1 of that collision bond

@@ -641,6 +641,8 @@ void Engine::prepare()
     std::vector<int> vtab_off(nr + 1, 0), btab_off(nr + 1, 0), wl_off(nr + 1, 0);
     std::vector<long long> excl_off(nr + 1, 0), col_off(nr + 1, 0);
     std::vector<int> col_cap(nr, 0);
+    std::vector<int> img_idx(nr, -1);          // slot of the robot's saved contact-row image (DBatch::rimg_*), colliding robots of up to 1024 voxels
+    { int n_img = 0; for (int r = 0; r < nr; ++r) if (robots_[r].vxa.self_col_enabled && robots_[r].nvox > 0 && robots_[r].nvox <= 1024) img_idx[r] = n_img++; }
     // contact rows: as long as the physics makes them -- a surface voxel can list every other one (CreateColBond, VX_Sim.cpp:753-769,
     // has no cap) -- unless the option col_cap bounds them; 12-16 bytes per entry, untouched beyond the partners a row really has.
     // That is nsurf^2 entries of address space per robot (75 MB for a 20^3 lattice, 1.5 GB for 512 robots of 10^3: nothing on this
@@ -729,6 +731,7 @@ void Engine::prepare()
             }
         DRobot& R = D.h_robot[r];
         R.sched_begin = sched_off[r];
+        R.img_index = img_idx[r];
         if (M.nvox > 0 && M.nvox <= 1024 && M.bond_classes.size() <= 4095) {
             // The resident kernel's bond schedule.  X and Z: bond j of the axis' compacted list to thread j.  Y: the kernel variants
             // with two accumulator tiles (up to 768 threads) evaluate X and Y without a barrier between them -- an accumulator entry
@@ -868,6 +871,7 @@ void Engine::prepare()
         DRobotState& S = rstate[r];
         std::memset(&S, 0, sizeof(S));
         S.max_disp = (double)FLT_MAX;      // ClearAll, VX_Sim.cpp:369: forces a collision-list build on the first step
+        S.act_time = -1.0;
         S.status = M.nvox == 0 ? 3 : 0;
     };
     {
@@ -944,6 +948,14 @@ void Engine::prepare()
     B.trace = D.alloc_zero<double>((size_t)std::max(D.total_trace, 1) * 4);
     B.col_rows = std::max(ns, 1);
     B.col_cnt = D.alloc_zero<int>(std::max(ns, 1));
+    {   // saved LDS images of the contact rows (resident kernel): one slot per colliding robot of up to 1024 voxels
+        int n_img = 0;
+        for (int r = 0; r < nr; ++r) if (img_idx[r] >= 0) ++n_img;
+        B.rimg_code = D.alloc_raw<int>((size_t)std::max(n_img, 1) * VXH_RIMG_CAP);
+        B.rimg_a1 = D.alloc_raw<double>((size_t)std::max(n_img, 1) * VXH_RIMG_CAP);
+        B.rimg_seg = D.alloc_zero<int>((size_t)std::max(n_img, 1) * 64);
+        B.rimg_rowd = D.alloc_zero<int>((size_t)nv);
+    }
     B.col_partner = D.alloc_raw<int>((size_t)std::max<long long>(col_off[nr], 1));     // (entries beyond col_cnt are never read)
     B.col_a1 = D.alloc_raw<double>((size_t)std::max<long long>(col_off[nr], 1));
     hs.mark("allocations + uploads");

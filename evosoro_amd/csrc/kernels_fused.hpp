@@ -27,7 +27,7 @@
 
 namespace vxh {
 
-enum { VXH_FUSED_STATIC_LDS = 448 };      // upper bound of the kernel's static __shared__ variables
+enum { VXH_FUSED_STATIC_LDS = 480 };      // upper bound of the kernel's static __shared__ variables
 
 // developer instrumentation (scripts/dev_gpu_diag.py phases; library built with -DVXH_PHASE_TIMING): per-wave cycle sums
 // of the phases of a step
@@ -823,7 +823,17 @@ __device__ __forceinline__ void fused_control_begin(const DRobot& R, DRobotState
     K.flags = (c.go ? 1 : 0) | (c.latch ? 2 : 0) | (c.eol ? 4 : 0) | (c.trace ? 16 : 0) | (K.damp_on ? 32 : 0);
     K.prenatal_c = actuation_prenatal_c(R, rs.cur_time);
     K.act_sin = K.act_cos = 0;
-    if (c.go) actuation_sincos(R, rs.cur_time, K.act_sin, K.act_cos);
+    // sincos of the actuation phase: a chain of ~200 dependent FP64 instructions on one lane.  During a launch it hides behind the
+    // voxel phase; at the START of a launch the whole workgroup waits for it (the prologue's first control, ~5 k cycles per robot).
+    // So the call that ends a launch (go = 0 with the robot still pending) computes the values of the time the next launch will start
+    // at and leaves them in the control block; the same function of the same argument, hence the same bits.
+    if (c.go) {
+        if (rs.act_time == rs.cur_time) { K.act_sin = rs.act_sin; K.act_cos = rs.act_cos; }
+        else actuation_sincos(R, rs.cur_time, K.act_sin, K.act_cos);
+    } else if (rs.status == 0) {
+        actuation_sincos(R, rs.cur_time, rs.act_sin, rs.act_cos);
+        rs.act_time = rs.cur_time;
+    }
 }
 __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K, double dt_prev)
 {
@@ -934,7 +944,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // lanes start in the copy and how many pairs they hold (-1: they did not fit, that wavefront reads its rows from memory).
     // Refreshed after every broad-phase run.  (every thread calls: barriers inside)
     int rowd = 0;
-    auto rows_to_lds = [&]() {
+    auto rows_to_lds = [&](bool at_launch) {
         rowd = 0;
         if (!(R.flags & RF_SELF_COL)) return;
         // (see opaque_tid.  The 1024-thread variant uses the kernel's own index: with a local `tid` re-read from threadIdx.x here -- the
@@ -948,6 +958,21 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #else
 #define VXH_R2L_MARK(slot)
 #endif
+        const int img = R.img_index;
+        constexpr int NW = BLOCK / 64;
+        if (at_launch && img >= 0 && rs.rows_img != 0 && !VXH_DBG(1)) {
+            // the copy as the previous launch left it (DBatch::rimg_*): one round trip of coalesced loads.  The rows only change in a
+            // broad-phase run, and every run ends in the save below.
+            const int* const seg = B.rimg_seg + (size_t)img * 64;
+            const int used = __builtin_amdgcn_readfirstlane(seg[2 * NW]);
+            if (valid) rowd = B.rimg_rowd[v];
+            if (tid_r < 2 * NW) s_seg[tid_r] = seg[tid_r];
+            for (int k = tid_r; k < used; k += BLOCK) { rc_code[k] = B.rimg_code[(size_t)img * VXH_RIMG_CAP + k]; rc_a1[k] = B.rimg_a1[(size_t)img * VXH_RIMG_CAP + k]; }
+            if (pool_cap > 0) cmask[tid_r] = 0;
+            __syncthreads();
+            VXH_R2L_MARK(2116)
+            return;
+        }
         int row = -1;
         if (valid) { const int so = B.surf_ord[v]; if (so >= 0) row = R.surf_begin + so; }
         const int ccnt = (row >= 0 && !VXH_DBG(1)) ? B.col_cnt[row] : 0;
@@ -964,8 +989,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // depend on who got there first, the two paths need not round alike
         if (lane == 0) s_seg[2 * (tid_r >> 6) + 1] = wave_total;
         __syncthreads();
-        int wave_base = 0;
-        for (int w = 0; w < (tid_r >> 6); ++w) wave_base += s_seg[2 * w + 1];
+        int wave_base = 0, all_total = 0;
+        for (int w = 0; w < NW; ++w) { const int t = s_seg[2 * w + 1]; if (w < (tid_r >> 6)) wave_base += t; all_total += t; }
         __syncthreads();                      // (s_seg is rewritten below)
         VXH_R2L_MARK(2115)     // scan, totals, two barriers, prefix over the wavefronts
         const bool fits = wave_base + wave_total <= pool_cap;
@@ -988,6 +1013,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         }
         __syncthreads();
         VXH_R2L_MARK(2116)     // the copy itself, last barrier
+        if (img >= 0 && !VXH_DBG(1)) {
+            // save the copy for the next launches (stores only: nothing waits for them)
+            const int used = min(min(all_total, pool_cap), (int)VXH_RIMG_CAP);
+            int* const seg = B.rimg_seg + (size_t)img * 64;
+            if (valid) B.rimg_rowd[v] = rowd;
+            if (tid_r < 2 * NW) seg[tid_r] = s_seg[tid_r];
+            if (tid_r == 0) { seg[2 * NW] = used; rs.rows_img = (all_total <= VXH_RIMG_CAP || pool_cap <= VXH_RIMG_CAP) ? 1 : 0; }
+            for (int k = tid_r; k < used; k += BLOCK) { B.rimg_code[(size_t)img * VXH_RIMG_CAP + k] = rc_code[k]; B.rimg_a1[(size_t)img * VXH_RIMG_CAP + k] = rc_a1[k]; }
+        }
     };
 
     // the control thread sits in the LAST wave: the one with the fewest (often no) voxels, so its serial work hides
@@ -997,7 +1031,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #ifdef VXH_PHASE_TIMING
     { const unsigned long long t_now = __builtin_readcyclecounter(); if (!MESH && B.prof && tid == 0) atomicAdd(&B.prof[2106], t_now - t_pro); t_pro = t_now; }   // state load, zeroing, control
 #endif
-    rows_to_lds();
+    rows_to_lds(true);
 #ifdef VXH_PHASE_TIMING
     { const unsigned long long t_now = __builtin_readcyclecounter(); if (!MESH && B.prof && tid == 0) atomicAdd(&B.prof[2113], t_now - t_pro); t_pro = t_now; }   // rows_to_lds as a whole
 #endif
@@ -1052,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
                 __syncthreads();
             }
 #endif
-            rows_to_lds();
+            rows_to_lds(false);
 #pragma unroll
             for (int k = 1; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;      // the scratch of the broad-phase (plane 0: below)
             scratch_used = true;

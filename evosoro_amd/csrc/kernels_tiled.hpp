@@ -786,7 +786,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             DRobotState& g = B.rstate[r];
             g.cur_time = out.cur_time; g.dt_prev = out.dt_prev; g.max_disp = out.max_disp;
             g.ini_cm[0] = out.ini_cm[0]; g.ini_cm[1] = out.ini_cm[1]; g.ini_cm[2] = out.ini_cm[2];
-            g.eol_post_y = out.eol_post_y; g.act_sin = out.act_sin; g.act_cos = out.act_cos; g.maxvel2_bits = out.maxvel2_bits;
+            g.eol_post_y = out.eol_post_y; g.act_sin = out.act_sin; g.act_cos = out.act_cos; g.act_time = out.act_time; g.maxvel2_bits = out.maxvel2_bits;
             g.steps = out.steps; g.status = out.status; g.cm_init = out.cm_init; g.active = out.active; g.diverged = out.diverged;
             g.rebuild_now = out.rebuild_now; g.rebuilds = out.rebuilds; g.col_tiled = out.col_tiled; g.ntrace = out.ntrace; g.last_trace_time = out.last_trace_time;
         }

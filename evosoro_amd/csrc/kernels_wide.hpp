@@ -28,7 +28,7 @@
 
 namespace vxh {
 
-enum { VXH_WIDE_REC = 13, VXH_WIDE_STATIC_LDS = 448 };
+enum { VXH_WIDE_REC = 13, VXH_WIDE_STATIC_LDS = 480 };
 
 // bond `entry` of the combined list: poses from the pose tile, history from / to HBM (L2), outputs into record `slot`
 template <int BLOCK, bool MESH>
