@@ -76,7 +76,7 @@ struct Engine::Device {
     int max_nvox = 0;                     // largest robot of the batch (selects the fused block size)
     // tiled path: the robots cut into tiles, packed into launches that fit the chip (all tiles of a robot in one launch)
     struct TileLaunch {
-        int tabg = 0, count = 0;
+        int tabg = 0, mesh = 0, count = 0;   // template arguments of k_tile_steps (mesh: land_water robots, whose strains are part of the state)
         const int* list = nullptr;        // tile ids
         size_t lds = 0;
         std::vector<int> tile_ids, robots;
@@ -1046,7 +1046,10 @@ void Engine::prepare()
         std::vector<int> cand;
         for (int r = 0; r < nr; ++r) {
             const RobotModel& M = robots_[r];
-            if (M.nvox == 0 || M.nmv > 0) continue;                   // (robots with the land_water surface mesh: resident / streaming kernels)
+            // land_water robots in a FLUID are not tiled: their drag needs the deformable surface mesh, whose vertices average the corners of
+            // up to seven voxels, across tile boundaries (resident / streaming kernels); on land they are (round 4: the tiles keep the
+            // directional strains the RobotVolume tags need)
+            if (M.nvox == 0 || (M.nmv > 0 && variant_ == 1 && M.vxa.fluid_env)) continue;
             const int block = fused_variant(M).block;
             if (tiled_now == 2 || !fused_ || block == 0 || (small_population && block >= 768)) cand.push_back(r);
         }
@@ -1063,7 +1066,7 @@ void Engine::prepare()
         auto k_latency = [&](const RobotModel& M) { return by_wave ? k_wave(M) : k_bonds(M); };
         long long sum_lat = 0;
         for (int r : cand) sum_lat += k_latency(robots_[r]);
-        struct Planned { int r; TilePlan plan; int tabg; size_t lds; };
+        struct Planned { int r; TilePlan plan; int tabg; size_t lds; int mesh; };
         std::vector<Planned> planned;
         for (int r : cand) {
             const RobotModel& M = robots_[r];
@@ -1078,23 +1081,24 @@ void Engine::prepare()
                 for (const auto& t : P.tiles)
                     lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles).total * 8);
                 if (P.k > VXH_TILE_MAX_TILES) break;                  // (left to the other kernels)
-                if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds}); break; }
+                if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds, M.nmv > 0 ? 1 : 0}); break; }
                 if (k >= M.nvox / 8) break;                           // cannot be tiled: left to the other kernels
                 k = std::min(std::max(k + 1, k * 5 / 4 + 1), std::max(1, M.nvox / 8));
             }
         }
         // launches: all tiles of a robot in one launch, a launch no larger than what the chip keeps resident (the tiles of a
         // robot wait for each other); 226 vector registers: at most two workgroups per CU
-        for (int tabg = 0; tabg < 2; ++tabg) {
+        for (int kind = 0; kind < 4; ++kind) {
+            const int tabg = kind & 1, mesh = kind >> 1;
             Device::TileLaunch cur;
-            cur.tabg = tabg;
+            cur.tabg = tabg; cur.mesh = mesh;
             auto capacity = [&](size_t lds) { return (long long)D.n_cu * std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)(lds + VXH_TILE_STATIC_LDS))); };
             for (auto& q : planned) {
-                if (q.tabg != tabg) continue;
+                if (q.tabg != tabg || q.mesh != mesh) continue;
                 const int k = q.plan.k;
                 if (k > capacity(q.lds)) continue;                    // more tiles than the chip holds: not tiled
                 const size_t lds = std::max(cur.lds, q.lds);
-                if (cur.count > 0 && cur.count + k > capacity(lds)) { D.tile_launches.push_back(cur); cur = Device::TileLaunch(); cur.tabg = tabg; }
+                if (cur.count > 0 && cur.count + k > capacity(lds)) { D.tile_launches.push_back(cur); cur = Device::TileLaunch(); cur.tabg = tabg; cur.mesh = mesh; }
                 cur.lds = std::max(cur.lds, q.lds);
                 const int tile0 = (int)h_tiles.size(), base = D.vox_begin[q.r];
                 for (int t = 0; t < k; ++t) {
@@ -1250,12 +1254,12 @@ static void launch_variant(const DBatch& B, const int* list, int count, size_t l
     hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
 }
 
-template <bool TABG>
+template <bool TABG, bool MESH>
 static void launch_tiles(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
 {
     static size_t granted[64] = {};
-    grant_dynamic_lds((const void*)k_tile_steps<TABG>, granted, lds);
-    hipLaunchKernelGGL((k_tile_steps<TABG>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
+    grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH>, granted, lds);
+    hipLaunchKernelGGL((k_tile_steps<TABG, MESH>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
 }
 
 template <bool FLUID, bool TABG>
@@ -1379,8 +1383,10 @@ void Engine::advance_launch(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters)
             for (const auto& L : D.tile_launches) {
                 ++tile_gen_;
-                if (L.tabg) launch_tiles<true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
-                else launch_tiles<false>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                if (L.mesh) { if (L.tabg) launch_tiles<true, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                              else launch_tiles<false, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_); }
+                else if (L.tabg) launch_tiles<true, false>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                else launch_tiles<false, false>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
                 ++launches; ++tile_launch_count;
             }
         HIP_OK(hipEventRecord(D.tile_t1, D.tile_stream));

@@ -1,4 +1,4 @@
-// Tiled path of the batched Voxelyze stepper: k_tile_steps<TABG>, SEVERAL workgroups per robot, all of them resident for a
+// Tiled path of the batched Voxelyze stepper: k_tile_steps<TABG, MESH>, SEVERAL workgroups per robot, all of them resident for a
 // whole launch of many time steps (included at the end of kernels.hpp).  By default it steps the robots the one-workgroup-per-
 // robot kernel (kernels_fused.hpp) cannot take: lattices of more than 1024 voxels (BASELINE configs[4], one 20x20x20 robot).
 // With the option tile_small also small populations of large robots (measured to pay only there: engine.hip).  Loop being tiled:
@@ -314,7 +314,7 @@ __device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DR
 #endif
 
 
-template <bool TABG>
+template <bool TABG, bool MESH>
 __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const DRobot* __restrict__ robots, const DTile* __restrict__ tiles,
                                                                  const int* __restrict__ tile_list, long long step_cap, int iters, unsigned gen)
 {
@@ -343,6 +343,8 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     double* const pl = lds + L.o_pl;          // [6 directions][6][no] bond force / minus bond moment on every owned voxel
     double* const hl = lds + L.o_hl;          // [6][nbp] bond history
     double* const pht = lds + L.o_pht;        // [2][no] sin / cos of the actuation phase offsets
+    double* const sl = lds + L.o_sl;          // [6][no] land_water robots: the directional strains of my voxels (CurStrainV1/V2 of their bonds, SetStrainDir)
+    constexpr bool mesh = MESH;               // land_water robots (on land: robots in a fluid are not tiled): the strains are part of their state
     double* const sc = lds + L.o_sc;          // scratch of latch / broad-phase
     double* const px = lds + L.o_px;          // [4][VXH_TILE_XH] position + scale of the mirrored contact partners
     double* const rc_a1 = lds + L.o_rc;       // [VXH_TILE_ROWPOOL] the tile's contact rows: pair stiffnesses ...
@@ -400,6 +402,10 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         if (R.flags & RF_SELF_COL) { my_ord = B.surf_ord[gv]; if (my_ord >= 0) row = R.surf_begin + my_ord; }
         amp_damp = B.amp_damp[gv];
         pht[tid] = B.act_sb[gv]; pht[no + tid] = B.act_cb[gv];
+        if constexpr (mesh) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sl[k * no + tid] = B.strain[(unsigned)k * nv + (unsigned)gv];
+        }
         lm = mk3(LINMOM(0, gv), LINMOM(1, gv), LINMOM(2, gv));
         am = mk3(ANGMOM(0, gv), ANGMOM(1, gv), ANGMOM(2, gv));
         const double q8[8] = {POS(b0, 0, gv), POS(b0, 1, gv), POS(b0, 2, gv), SCALE(b0, gv), QUAT(0, gv), QUAT(1, gv), QUAT(2, gv), QUAT(3, gv)};
@@ -591,6 +597,11 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 if (H.store_hist) { hl[b] = H.p0; hl[nbp + b] = H.p1; hl[2 * nbp + b] = H.p2; hl[3 * nbp + b] = H.g0; hl[4 * nbp + b] = H.g1; hl[5 * nbp + b] = H.g2; }
                 hf[b] = (int)H.flags;
                 div = div || o.diverged;
+                if constexpr (mesh) {        // SetStrainDir (VXS_BondInternal.cpp:300-304): +axis side of voxel 1, -axis side of voxel 2; a bond that crosses a
+                                   // tile boundary is evaluated by both tiles, each keeps the strain of its own end
+                    if (l1 < n_own) sl[axis * no + l1] = o.strain1;
+                    if (l2 < n_own) sl[(3 + axis) * no + l2] = o.strain2;
+                }
                 if (l1 < n_own) {
                     double* e1 = pl + (2 * axis) * 6 * no + l1;
                     e1[0] = o.f1.x; e1[no] = o.f1.y; e1[2 * no] = o.f1.z; e1[3 * no] = -o.m1.x; e1[4 * no] = -o.m1.y; e1[5 * no] = -o.m1.z;
@@ -771,6 +782,10 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         QUAT(0, gv) = ps[4 * np + tid]; QUAT(1, gv) = ps[5 * np + tid]; QUAT(2, gv) = ps[6 * np + tid]; QUAT(3, gv) = ps[7 * np + tid];
         LINMOM(0, gv) = lm.x; LINMOM(1, gv) = lm.y; LINMOM(2, gv) = lm.z;
         ANGMOM(0, gv) = am.x; ANGMOM(1, gv) = am.y; ANGMOM(2, gv) = am.z;
+        if constexpr (mesh) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) B.strain[(unsigned)k * nv + (unsigned)gv] = sl[k * no + tid];
+        }
     }
     for (int b = tid; b < nb; b += NT) {
         if ((bent[b] & 1023) >= n_own) continue;                  // a bond is written back by the tile that owns its negative end

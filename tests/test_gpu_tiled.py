@@ -275,3 +275,52 @@ def test_whole_run_of_the_full_20_cube(tmp_path):
     for f in ("norm_final_dist", "final_dist", "anterior_dist", "posterior_dist"):
         a, b = getattr(res, f), getattr(want_res, f)
         assert abs(a - b) <= 1e-12 * max(1.0, abs(b)) + 1e-15, (f, a, b)
+
+
+def test_a_land_water_lattice_above_1024_voxels_on_land_is_tiled(tmp_path):
+    """Round 4: _voxcad_land_water robots ON LAND (no fluid: no drag mesh to average across tile boundaries) are taken by the tiled kernel;
+    its tiles keep the directional strains of their voxels (SetStrainDir), which the RobotVolume tags are computed from.  A full 11^3
+    lattice (1331 voxels) with a per-voxel phase offset, next to a small walker: against the oracle step by step; the whole evaluation
+    against an engine with tiled = 0 (streaming kernels: the round-3 path of such a robot): every voxel within 1e-9 voxel, the volume
+    tags -- functions of poses AND strains -- within 1e-9 relative, and the tiled kernel did step it."""
+    from collections import OrderedDict
+    from evosoro_amd import engine as eng_mod, workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    from oracle import vxoracle as vo
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.03, fitness_eval_init_time=0.005)
+    big = workloads.make_individual(0, workloads.full_material(11, 1),
+                                    OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(59).uniform(-1, 1, size=(11, 11, 11)), 3))]))
+    small = workloads.swimmer(1, (6, 6, 6), 77)
+    paths = []
+    for ind in (big, small):
+        write_voxelyze_file(sim, Env(), ind, str(tmp_path), "lw")
+        paths.append(str(tmp_path / "voxelyzeFiles" / ("lw--id_%05i.vxa" % ind.id)))
+    sims = [vo.OracleSim.from_vxa(p, variant=1) for p in paths]
+    lat = sims[0].model["lattice_dim"]
+    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+        eng.set_option("tiled", 1); eng.set_option("tiles_per_robot", 0)      # (the engine's defaults, whatever kernel path the run is parametrised with)
+        eng.add_vxa_files(paths)
+        assert eng.dims(0)["nvox"] == 1331
+        for upto in (1, 3, 40, 200):
+            eng.step(upto - sims[0].info().steps)
+            for i, o in enumerate(sims):
+                o.step(upto - o.info().steps)
+                err = np.abs(eng.state(i)[:, :3] - o.state()[:, :3]).max() / lat
+                assert err < 1e-9, (i, upto, err)
+        assert eng.counters().dominant_block == 1                  # k_tile_steps did most of the work (the 1331-voxel lattice)
+        eng.run()
+        tiled_state, tiled_res = eng.state(0), eng.result(0)
+    with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
+        eng.set_option("tiled", 0)
+        eng.add_vxa_files(paths)
+        eng.run()
+        assert eng.counters().dominant_block == 0                  # streaming kernels
+        ref_state, ref_res = eng.state(0), eng.result(0)
+    assert tiled_res.status == eng_mod.ROBOT_FINISHED and tiled_res.steps == ref_res.steps
+    assert np.abs(tiled_state[:, :3] - ref_state[:, :3]).max() / lat < 1e-9
+    for f in ("robot_volume_start", "robot_volume_end", "norm_abs_disp"):
+        a, b = getattr(tiled_res, f), getattr(ref_res, f)
+        assert b > 0 and abs(a - b) <= 1e-9 * abs(b), (f, a, b)
+    assert abs(tiled_res.robot_volume_end - tiled_res.robot_volume_start) > 1e-6 * tiled_res.robot_volume_start      # the strains did reach the host: a deformed mesh
