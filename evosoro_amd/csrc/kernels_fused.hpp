@@ -743,9 +743,11 @@ __device__ __forceinline__ void fused_round(const DBatch& B, const DRobot& R, co
     if (has) {
         o = fused_bond<A, BLOCK, MESH>(B, R, bct, ps, entry, modebits, damp_on, st, st_stride);
         div = div || o.diverged;
-        fused_accumulate<BLOCK, A == 0 && NACC == 1>(acc, entry & 1023, o.f1, o.m1);     // (plain stores only where a barrier orders them before every addition)
+        fused_accumulate<BLOCK, false>(acc, entry & 1023, o.f1, o.m1);
     }
-    if constexpr (NACC == 1) __syncthreads();
+    // one tile: an entry gets Force1 of the voxel's +A bond and Force2 of its -A bond.  In the X round both are ADDED to the zero the
+    // voxel phase left and commute exactly; from Y on the second must follow the first (the reference's +A -A order): a barrier
+    if constexpr (NACC == 1 && A != 0) __syncthreads();
     if (has) fused_accumulate<BLOCK, false>(acc + (NACC - 1) * 6 * BLOCK, (entry >> 10) & 1023, o.f2, o.m2);
 }
 

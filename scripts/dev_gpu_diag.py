@@ -902,7 +902,7 @@ if __name__ == "__main__" and "cli30" in sys.argv[1:]:
 
 
 if __name__ == "__main__" and "statehash" in sys.argv[1:]:
-    # a digest of every voxel's state of 48 bench robots (10^3, self-collision) + 16 dense 9^3 ones after 700 steps: two builds of the
+    # a digest of every voxel's state of 48 bench robots (10^3, self-collision) + 16 dense 9^3 + 8 dense 10^3 ones after 700 steps: two builds of the
     # library that claim the same arithmetic in another schedule must print the same line (scripts/ab_lib.py <lib> statehash)
     import hashlib
     tmp = tempfile.mkdtemp()
@@ -910,7 +910,8 @@ if __name__ == "__main__" and "statehash" in sys.argv[1:]:
     sim = Sim(self_collisions_enabled=True, dt_frac=0.9, simulation_time=0.2, fitness_eval_init_time=0.01)
     with engine.Engine(engine.VOXCAD, 0) as eng:
         eng.set_option("tiled", 0)
-        inds = [workloads.random_robot(i, (10, 10, 10), i) for i in range(48)] + [workloads.make_individual(100 + i, workloads.full_material(9, 1 + i)) for i in range(16)]
+        inds = ([workloads.random_robot(i, (10, 10, 10), i) for i in range(48)] + [workloads.make_individual(100 + i, workloads.full_material(9, 1 + i)) for i in range(16)]
+                + [workloads.make_individual(200 + i, workloads.full_material(10, 1 + i)) for i in range(8)])      # (the last: the 1024-thread variant)
         for ind in inds:
             write_voxelyze_file(sim, Env(), ind, tmp, "h")
             eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "h--id_%05i.vxa" % ind.id))
