@@ -150,9 +150,6 @@ struct DBatch {
                                       // voxel << 10 | class << 20, -1 = none): what thread t evaluates in the X, Y and Z slot of a step.  X and Z: the
                                       // t-th bond of the axis (compacted lists); Y: whole 64-bond chunks dealt to the wavefronts so that X and Y TOGETHER
                                       // load the four SIMDs evenly (two accumulator tiles: X and Y are evaluated without a barrier between them)
-    const int* blist;                 // [3*nv] fused path: per robot and axis the COMPACTED list of its bonds, entry t of axis a at
-                                      // [a*nv + vox_begin + t] = local negative-end voxel | local positive-end voxel << 10 |
-                                      // bond class << 20, -1 past the end of the list
     const double* act_sb;             // [nv] sin / cos of 2 pi' * PhaseOffset of the voxel (pi' = 3.1415926f)
     const double* act_cb;
     const float* amp_damp;            // [nv]

@@ -604,7 +604,6 @@ void Engine::prepare()
     std::vector<unsigned long long> excl;
     std::vector<unsigned short> vclass(nv, 0);
     std::vector<short> bclass((size_t)3 * nv, -1);
-    std::vector<int> blist((size_t)3 * nv, -1);
     // bond schedules of the resident kernel: [3][block] per robot, block = the workgroup size of the robot's size class
     auto resident_block = [](int n) { return n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024)); };
     std::vector<int> sched_off(nr + 1, 0);
@@ -721,14 +720,6 @@ void Engine::prepare()
             for (int d = 0; d < 6; ++d) { int o = M.nbr[(size_t)v * 6 + d]; nbr[(size_t)d * nv + g] = o < 0 ? -1 : base + o; }
             for (int a = 0; a < 3; ++a) { int c = M.bond_class[(size_t)v * 3 + a]; bclass[(size_t)a * nv + g] = c < 0 ? (short)-1 : (short)c; }
         }
-        if (M.nvox <= 1024 && M.bond_classes.size() <= 4095)
-            for (int a = 0; a < 3; ++a) {
-                int t = 0;
-                for (int v = 0; v < M.nvox; ++v) {
-                    const int c = M.bond_class[(size_t)v * 3 + a];
-                    if (c >= 0) blist[(size_t)a * nv + base + t++] = (int)((unsigned)v | ((unsigned)M.nbr[(size_t)v * 6 + 2 * a] << 10) | ((unsigned)c << 20));
-                }
-            }
         DRobot& R = D.h_robot[r];
         R.sched_begin = sched_off[r];
         R.img_index = img_idx[r];
@@ -906,7 +897,6 @@ void Engine::prepare()
     B.vclass = D.upload(vclass);
     B.bclass = D.upload(bclass);
     B.nbr = D.upload(nbr);
-    B.blist = D.upload(blist);
     B.bsched = D.upload(bsched);
     B.wlist = D.upload(wlist);
     B.wgather = D.upload(wgather);

@@ -6,7 +6,7 @@
 // A step has two kinds of work items mapped onto the same threads:
 //   voxels  thread t owns voxel t: its momenta stay in registers for the whole launch, its pose is published in LDS;
 //   bonds   three rounds, one per axis; in round A thread t owns the t-th bond of that axis (per-robot COMPACTED bond
-//           lists, DBatch::blist), so a sparse robot keeps only ceil(bonds_A / 64) wavefronts busy per round instead
+//           lists, dealt to the threads by DBatch::bsched), so a sparse robot keeps only ceil(bonds_A / 64) wavefronts busy per round instead
 //           of one lane per voxel whether it has that bond or not.  The axis is a compile-time constant per round.
 // Dynamic LDS layout (doubles):
 //   ps   [8][BLOCK]        pose tile: pos x y z, scale, quaternion w x y z of every voxel (read by bonds, contact forces,
@@ -675,7 +675,7 @@ __device__ __forceinline__ d3 fused_drag(const DBatch& B, const DRobot& R, const
     return drag;
 }
 
-// Bond t of axis A (packed entry of DBatch::blist: negative-end voxel | positive-end voxel << 10 | class << 20):
+// A bond of axis A (packed entry of DBatch::bsched: negative-end voxel | positive-end voxel << 10 | class << 20):
 // both poses from the pose tile, history from/to HBM.  Returns the outputs; the caller adds them to the accumulators.
 template <int A, int BLOCK, bool MESH>
 __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, const DBondClass* bct, const double* ps, int entry,
