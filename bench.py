@@ -326,7 +326,7 @@ def side_config(engine, name, variant, count, shape, env, device, steps, full=Fa
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def mixed_generation(engine, device, count=512, lattice=10, sim_time=0.5, init_time=0.05):
+def mixed_generation(engine, device, count=512, lattice=10, sim_time=0.5, init_time=0.05, options=None):
     """A realistic generation (SURVEY.md section 7 "Heterogeneous robots in one batch", evosoro examples/basic.py:114-127): `count`
     robots on a lattice^3 grid whose fill is uniform on 30-100 %, every second one without bone -- its softest-material time step is
     ten times the others', so it needs a tenth of the steps for the same simulated time -- evaluated TO COMPLETION by one vxh_run.
@@ -365,6 +365,8 @@ def mixed_generation(engine, device, count=512, lattice=10, sim_time=0.5, init_t
             c1 = eng.counters()
             rate_steady = (c1.voxel_steps - c0.voxel_steps) / (c1.kernel_seconds - c0.kernel_seconds)
         with engine.Engine(engine.VOXCAD, device) as eng:
+            for key, val in (options or {}).items():
+                eng.set_option(key, val)
             eng.add_vxa_files(paths)
             import torch
             torch.cuda.synchronize()

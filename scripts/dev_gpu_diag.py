@@ -920,3 +920,14 @@ if __name__ == "__main__" and "statehash" in sys.argv[1:]:
         for i in range(len(inds)):
             h.update(np.ascontiguousarray(eng.state(i)).tobytes())
         print("%s statehash %s (%d robots, 700 steps, kernel of most voxel-steps %d)" % (os.path.basename(engine.LIB_PATH), h.hexdigest()[:24], len(inds), eng.counters().dominant_block), flush=True)
+
+
+if __name__ == "__main__" and "mixedlaunch" in sys.argv[1:]:
+    # the mixed generation of bench.py (three size classes, two step counts) run to completion with launches of different lengths:
+    # how much of its time is CUs idling behind the slowest robot of a launch group?
+    sys.path.insert(0, REPO)
+    import bench
+    for L in (128, 256, 512, 1024, 4096):
+        r = bench.mixed_generation(engine, 0, options={"steps_per_launch": L})
+        print("steps_per_launch %5d: %.3e voxel-steps/s over the GPU's time (%.1f ms, %d launches), wall %.1f ms" % (
+            L, r["value"], 1e3 * r["gpu_seconds"], r["launches"], 1e3 * r["wall_seconds"]), flush=True)
