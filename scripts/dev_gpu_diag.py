@@ -926,6 +926,8 @@ if __name__ == "__main__" and "mixedlaunch" in sys.argv[1:]:
     # the mixed generation of bench.py (three size classes, two step counts) run to completion with launches of different lengths:
     # how much of its time is CUs idling behind the slowest robot of a launch group?
     sys.path.insert(0, REPO)
+    import torch
+    torch.cuda.init()          # (torch's HIP runtime first, as in bench.py: initialised after the engine's it finds no device)
     import bench
     for L in (128, 256, 512, 1024, 4096):
         r = bench.mixed_generation(engine, 0, options={"steps_per_launch": L})
