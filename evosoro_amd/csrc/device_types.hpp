@@ -165,6 +165,9 @@ struct DBatch {
     // _LastPos2 xyz (small layout) or _LastPos2.x, _LastAngle1.y, _LastAngle1.z (large layout), planes 3..5
     // _LastAngle2.  Flag byte: bit 0 = SmallAngle, bit 1 = history is in the large layout.
     double* hist;
+    double* hist_aos;                 // resident kernel (kernels_fused.hpp): the same six doubles per bond slot as ONE 48-byte record, [3 * nv][6] --
+                                      // three 16-byte loads / stores per bond instead of six 8-byte ones (its lanes walk compacted bond lists: the planes
+                                      // of `hist` are not read coalesced anyway).  A robot's history lives in the array of the kernel that steps it.
     unsigned char* small_angle;
     // streaming path only: bond outputs of the current step, 12 planes of 3*nv: F1, M1, F2, M2
     double* bout;

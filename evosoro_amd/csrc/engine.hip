@@ -913,6 +913,7 @@ void Engine::prepare()
         B.vs = vs;
     }
     B.hist = D.alloc_zero<double>((size_t)6 * 3 * nv);
+    B.hist_aos = D.alloc_zero<double>((size_t)6 * 3 * nv);
     B.small_angle = D.upload(small);
     B.bout = D.alloc_zero<double>((size_t)12 * 3 * nv);
     B.surf = D.upload(surf);

@@ -686,9 +686,10 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
                                               // loop they cost 36 scalar registers and come back as v_readlane spills
     const int l1 = entry & 1023, l2 = (entry >> 10) & 1023;
     const unsigned voff = (unsigned)(R.vox_begin + l1) * 8u;
-    BondHist H;                               // history first: the only HBM/L2 round trip of the bond
-    H.p0 = ld_plane(B.hist, 0 * 3 + A, nv, voff); H.p1 = ld_plane(B.hist, 1 * 3 + A, nv, voff); H.p2 = ld_plane(B.hist, 2 * 3 + A, nv, voff);
-    H.g0 = ld_plane(B.hist, 3 * 3 + A, nv, voff); H.g1 = ld_plane(B.hist, 4 * 3 + A, nv, voff); H.g2 = ld_plane(B.hist, 5 * 3 + A, nv, voff);
+    BondHist H;                               // history first: the only HBM/L2 round trip of the bond; one 48-byte record, three 16-byte loads
+    double2* const hrec = (double2*)(B.hist_aos + ((size_t)((unsigned)A * nv) + (unsigned)(R.vox_begin + l1)) * 6);
+    (void)voff;
+    { const double2 h0 = hrec[0], h1 = hrec[1], h2 = hrec[2]; H.p0 = h0.x; H.p1 = h0.y; H.p2 = h1.x; H.g0 = h1.y; H.g1 = h2.x; H.g2 = h2.y; }
     H.flags = (modebits >> (2 * A)) & 3u;
     H.store_hist = false;
     const d3 p1 = mk3(ps[l1], ps[BLOCK + l1], ps[2 * BLOCK + l1]);
@@ -698,10 +699,7 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
     const double s2 = ps[3 * BLOCK + l2];
     const dq q2 = mkq(ps[4 * BLOCK + l2], ps[5 * BLOCK + l2], ps[6 * BLOCK + l2], ps[7 * BLOCK + l2]);
     BondOut o = bond_compute<A>(B, bct[(unsigned)entry >> 20], H, p1, q1, s1, p2, q2, s2, damp_on);
-    if (H.store_hist) {
-        st_plane(B.hist, 0 * 3 + A, nv, voff, H.p0); st_plane(B.hist, 1 * 3 + A, nv, voff, H.p1); st_plane(B.hist, 2 * 3 + A, nv, voff, H.p2);
-        st_plane(B.hist, 3 * 3 + A, nv, voff, H.g0); st_plane(B.hist, 4 * 3 + A, nv, voff, H.g1); st_plane(B.hist, 5 * 3 + A, nv, voff, H.g2);
-    }
+    if (H.store_hist) { hrec[0] = make_double2(H.p0, H.p1); hrec[1] = make_double2(H.p2, H.g0); hrec[2] = make_double2(H.g1, H.g2); }
     modebits = (modebits & ~(3u << (2 * A))) | (H.flags << (2 * A));
     if constexpr (MESH) {                     // SetStrainDir (VXS_BondInternal.cpp:300-304): +A side of voxel 1, -A side of voxel 2
         st[(unsigned)A * st_stride + l1] = o.strain1;
