@@ -38,10 +38,9 @@ __device__ __forceinline__ bool wide_bond(const DBatch& B, const DRobot& R, cons
     unsigned nv = B.nv;
     asm volatile("" : "+s"(nv));              // (plane addresses rebuilt per bond by the scalar unit, see fused_bond)
     const int l1 = entry & 511, l2 = (entry >> 9) & 511, axis = (entry >> 18) & 3;
-    const unsigned voff = ((unsigned)axis * nv + (unsigned)(R.vox_begin + l1)) * 8u;     // canonical slot axis * nv + negative-end voxel
-    BondHist H;
-    H.p0 = ld_plane(B.hist, 0, nv, voff); H.p1 = ld_plane(B.hist, 3, nv, voff); H.p2 = ld_plane(B.hist, 6, nv, voff);
-    H.g0 = ld_plane(B.hist, 9, nv, voff); H.g1 = ld_plane(B.hist, 12, nv, voff); H.g2 = ld_plane(B.hist, 15, nv, voff);
+    BondHist H;                               // one 48-byte record per bond slot (DBatch::hist_aos), as in the resident kernel
+    double2* const hrec = (double2*)(B.hist_aos + ((size_t)((unsigned)axis * nv) + (unsigned)(R.vox_begin + l1)) * 6);
+    { const double2 h0 = hrec[0], h1 = hrec[1], h2 = hrec[2]; H.p0 = h0.x; H.p1 = h0.y; H.p2 = h1.x; H.g0 = h1.y; H.g1 = h2.x; H.g2 = h2.y; }
     H.flags = (modebits >> shift) & 3u;
     H.store_hist = false;
     const d3 p1 = mk3(ps[l1], ps[BLOCK + l1], ps[2 * BLOCK + l1]);
@@ -51,10 +50,7 @@ __device__ __forceinline__ bool wide_bond(const DBatch& B, const DRobot& R, cons
     const double s2 = ps[3 * BLOCK + l2];
     const dq q2 = mkq(ps[4 * BLOCK + l2], ps[5 * BLOCK + l2], ps[6 * BLOCK + l2], ps[7 * BLOCK + l2]);
     const BondOut o = bond_compute_rt(axis, B, bct[(unsigned)entry >> 20], H, p1, q1, s1, p2, q2, s2, damp_on);
-    if (H.store_hist) {
-        st_plane(B.hist, 0, nv, voff, H.p0); st_plane(B.hist, 3, nv, voff, H.p1); st_plane(B.hist, 6, nv, voff, H.p2);
-        st_plane(B.hist, 9, nv, voff, H.g0); st_plane(B.hist, 12, nv, voff, H.g1); st_plane(B.hist, 15, nv, voff, H.g2);
-    }
+    if (H.store_hist) { hrec[0] = make_double2(H.p0, H.p1); hrec[1] = make_double2(H.p2, H.g0); hrec[2] = make_double2(H.g1, H.g2); }
     modebits = (modebits & ~(3u << shift)) | (H.flags << shift);
     if constexpr (MESH) {                     // SetStrainDir (VXS_BondInternal.cpp:300-304): +A side of voxel 1, -A side of voxel 2
         st[axis * BLOCK + l1] = o.strain1;

@@ -933,3 +933,14 @@ if __name__ == "__main__" and "mixedlaunch" in sys.argv[1:]:
         r = bench.mixed_generation(engine, 0, options={"steps_per_launch": L})
         print("steps_per_launch %5d: %.3e voxel-steps/s over the GPU's time (%.1f ms, %d launches), wall %.1f ms" % (
             L, r["value"], 1e3 * r["gpu_seconds"], r["launches"], 1e3 * r["wall_seconds"]), flush=True)
+
+
+if __name__ == "__main__" and "smallcfgs" in sys.argv[1:]:
+    # the small populations of BASELINE configs[1] and [3] (wide kernel) and a saturated one, for A/B runs of two libraries
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    for _ in range(2):
+        timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.1, Env(), {})
+        timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, {}, per_voxel_phase=True)
+        timing_cfg(engine.VOXCAD, 512, (8, 8, 8), 0.04, Env(), {})
