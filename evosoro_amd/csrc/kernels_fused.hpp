@@ -5,16 +5,18 @@
 //
 // A step has two kinds of work items mapped onto the same threads:
 //   voxels  thread t owns voxel t: its momenta stay in registers for the whole launch, its pose is published in LDS;
-//   bonds   three rounds, one per axis; in round A thread t owns the t-th bond of that axis (per-robot COMPACTED bond
-//           lists, dealt to the threads by DBatch::bsched), so a sparse robot keeps only ceil(bonds_A / 64) wavefronts busy per round instead
-//           of one lane per voxel whether it has that bond or not.  The axis is a compile-time constant per round.
+//   bonds   three slots per thread, one per axis (the axis is a compile-time constant per slot): the robot's per-axis COMPACTED bond
+//           lists dealt to the threads by DBatch::bsched, so a sparse robot keeps ceil(bonds_A / 64) wavefronts busy per axis instead
+//           of one lane per voxel whether it has that bond or not.  Up to 768 threads the X and Y slots are evaluated back to back
+//           WITHOUT a barrier between them (their sums commute: below), the Y chunks dealt to the wavefronts X leaves idle; Z follows
+//           behind a barrier.  The history of a bond is one 48-byte record in DBatch::hist_aos.
 // Dynamic LDS layout (doubles):
 //   ps   [8][BLOCK]        pose tile: pos x y z, scale, quaternion w x y z of every voxel (read by bonds, contact forces,
 //                          the broad-phase, the drag mesh)
 //   acc  [NACC][6][BLOCK]  force / minus-moment accumulators of every voxel.  NACC = 2: tile 0 collects the bonds in
 //                          which the voxel is the negative end (Force1/Moment1), tile 1 those in which it is the
-//                          positive end; every (axis, tile, voxel) entry has exactly one writer, rounds are separated
-//                          by a barrier.  NACC = 1 (BLOCK 1024, where two tiles do not fit next to the pose tile): one
+//                          positive end; an entry gets at most one contribution per axis, added with an LDS atomic: X and Y
+//                          in either order (a + b == b + a from the zero the voxel phase left), Z behind a barrier.  NACC = 1 (BLOCK 1024, where two tiles do not fit next to the pose tile): one
 //                          tile, the two ends of a round are added in two barrier-separated sub-steps, which gives
 //                          the reference's summation order +X -X +Y -Y +Z -Z.
 //                          Also scratch of latch / broad-phase between steps (re-zeroed by the voxel phase).
