@@ -64,7 +64,6 @@ void EngineSet::distribute()
         distributed_ = true;
         return;
     }
-    no_tiling_if_shared();
     std::vector<RobotModel> all = engines_[0]->take_robots();
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) order[i] = i;
@@ -77,6 +76,11 @@ void EngineSet::distribute()
         share[k].push_back(i);
         load[k] += cost(i);
     }
+    // several engines of ONE device about to step side by side: no multi-workgroup kernel (its tiles must own the device); a batch
+    // that ends up on a single engine -- one large lattice -- keeps it
+    int busy = 0;
+    for (int k = 0; k < nd; ++k) busy += share[k].empty() ? 0 : 1;
+    if (busy > 1) no_tiling_if_shared(); else tiling_allowed_again();
     for (int k = 0; k < nd; ++k) {
         std::sort(share[k].begin(), share[k].end());
         std::vector<RobotModel> mine;
@@ -216,8 +220,8 @@ void EngineSet::bond_modes(long long* large_angle, long long* total)
     for (auto& e : engines_) { if (e->num_robots() == 0) continue; long long l = 0, t = 0; e->bond_modes(&l, &t); *large_angle += l; *total += t; }
 }
 
-// sums over the devices; the times are those of the slowest device (they ran side by side), the dominant kernel that of the device that
-// did most of the work
+// sums over the devices; the times are those of the slowest device (they ran side by side), the dominant kernel that of the device whose
+// dominant kernel did most of the last call's work
 void EngineSet::counters(vxh_counters* out) const
 {
     *out = vxh_counters{};
@@ -228,8 +232,10 @@ void EngineSet::counters(vxh_counters* out) const
         out->voxel_steps += c.voxel_steps; out->bond_steps += c.bond_steps; out->algorithmic_bytes += c.algorithmic_bytes;
         out->kernel_seconds = std::max(out->kernel_seconds, c.kernel_seconds); out->run_seconds = std::max(out->run_seconds, c.run_seconds);
         out->launches += c.launches; out->max_steps = std::max(out->max_steps, c.max_steps);
-        if (c.voxel_steps > best) {
-            best = c.voxel_steps;
+        if (e->num_robots() == 0 && best >= 0) continue;     // (an engine the last call left idle still shows the call before)
+        const double work = e->num_robots() == 0 ? 0.0 : c.dominant_voxel_steps;
+        if (work > best) {
+            best = work;
             out->dominant_block = c.dominant_block; out->dominant_robots = c.dominant_robots; out->dominant_launches = c.dominant_launches;
             out->dominant_seconds = c.dominant_seconds; out->dominant_alg_bytes = c.dominant_alg_bytes; out->dominant_voxel_steps = c.dominant_voxel_steps;
         }

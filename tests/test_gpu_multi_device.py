@@ -85,6 +85,7 @@ def test_more_engines_than_robots_and_reuse_of_the_handle(golden_dir):
         want_300 = [one.state(i) for i in range(2)]
     with eng_mod.Engine(eng_mod.VOXCAD, (0, 0, 0)) as many:
         assert many.num_robots() == 0
+        many.set_option("tiled", 0)                       # (as `one`: a batch that lands on ONE engine may tile, whatever the handle)
         many.run()                                        # nothing to do is not an error
         for p in paths:
             many.add_vxa_file(p)
@@ -153,3 +154,38 @@ def test_a_generation_pipelined_over_two_engines_of_one_device(tmp_path):
         eng.run()
         for i in range(7):
             assert _same(eng.result(i), want[i]), i
+
+
+def test_a_repeated_device_handle_tiles_again_when_one_engine_holds_the_batch(golden_dir, tmp_path):
+    """Engines that share a device do not launch the multi-workgroup kernel while they step side by side; the veto is per batch, not for
+    the life of the handle: after a small generation spread over both engines, one lattice above 1024 voxels (file route: it lands on
+    ONE engine) is stepped by k_tile_steps again, with the record of a one-device engine."""
+    from evosoro_amd import engine as eng_mod, workloads
+    from evosoro_amd.base import Sim, Env
+    from evosoro_amd.tools.read_write_voxelyze import write_voxelyze_file
+    if os.environ.get("VXH_ENGINE_OPTIONS"):
+        pytest.skip("kernel path forced by VXH_ENGINE_OPTIONS")
+    os.makedirs(tmp_path / "voxelyzeFiles")
+    sim = Sim(dt_frac=0.9, simulation_time=0.02, fitness_eval_init_time=0.005)
+    write_voxelyze_file(sim, Env(), workloads.make_individual(0, workloads.full_material(11, 1)), str(tmp_path), "big")
+    big = str(tmp_path / "voxelyzeFiles" / "big--id_00000.vxa")
+    small = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in ("probe6", "rand6_col")]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as one:
+        one.add_vxa_file(big)
+        one.run()
+        want, want_state = one.result(0), one.state(0)
+        assert one.counters().dominant_block == 1
+    with eng_mod.Engine(eng_mod.VOXCAD, (0, 0)) as two:
+        for p in small:
+            two.add_vxa_file(p)
+        two.run()                                             # both engines busy: no tiling in this batch
+        two.clear()
+        two.add_vxa_file(big)
+        two.run()
+        assert two.counters().dominant_block == 1             # k_tile_steps, not the streaming kernels
+        assert _same(two.result(0), want) and np.array_equal(two.state(0), want_state)
+        # ... and a mixed batch afterwards (spread again) steps the lattice on the streaming kernels: same state to the last bit is NOT
+        # promised across kernels, the record's step count and status are
+        two.add_vxa_file(small[0])
+        two.run()
+        assert two.result(0).status == eng_mod.ROBOT_FINISHED and two.result(0).steps == want.steps
