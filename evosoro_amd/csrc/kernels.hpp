@@ -165,11 +165,9 @@ __device__ __forceinline__ double vdiv(double a, double b)
 // (asin(sqrt z) - sqrt z)/(z sqrt z), relative error 6e-17).  The coefficients are pinned to scalar registers: as
 // literals the compiler moves each of them into a vector register pair per evaluation (FP64 has no 64-bit literals).
 __device__ __forceinline__ double sconst(double c) { asm volatile("" : "+s"(c)); return c; }
-__device__ __forceinline__ double vacos(double x)
+// z P(z) of asin(s) = s (1 + z P(z)), z = s^2 <= 1/4 (the device library's acos polynomial)
+__device__ __forceinline__ double asin_zp(double z)
 {
-    const double ax = fabs(x);
-    const bool big = ax >= 0.5;
-    const double z = big ? __builtin_fma(ax, -0.5, 0.5) : x * x;
     double p = sconst(0.028169218060881414);
     p = __builtin_fma(p, z, sconst(-0.010749050339697808));
     p = __builtin_fma(p, z, sconst(0.01603551434914882));
@@ -183,6 +181,14 @@ __device__ __forceinline__ double vacos(double x)
     p = __builtin_fma(p, z, sconst(0.07500000000020764));
     p = __builtin_fma(p, z, sconst(0.1666666666666665));
     p *= z;
+    return p;
+}
+__device__ __forceinline__ double vacos(double x)
+{
+    const double ax = fabs(x);
+    const bool big = ax >= 0.5;
+    const double z = big ? __builtin_fma(ax, -0.5, 0.5) : x * x;
+    const double p = asin_zp(z);
     if (big) {
         const double s = vsqrt_nn(z);
         const double r = 2.0 * __builtin_fma(s, p, s);
@@ -304,9 +310,25 @@ __device__ __forceinline__ double one_minus_square(double w) { const double ww =
 //                   rounding of w w: on this branch sl > 2.4e-3, that rounding is a relative < 2.5e-14 of the result.
 //   else            acos(w) * rsqrt(sl) as before (never taken by a sane bond; kept for the function's contract).
 // The factor 2 of the rotation vector is folded into f (exact).
+// SEL (the resident kernel): the select form -- numerator and rsqrt argument of the lane's branch chosen first, ONE refined v_rsq_f64
+// for both (the same operations on the same values per lane as the branched form: same bits, scripts/dev_gpu_diag.py statehash).
+// Measured, same box: resident kernel 25.15 -> 24.96 us per step (its wavefronts are of both kinds, and run both branches); the wide
+// kernel the other way, 64 x 6^3 5.6 -> 5.7, swimmers 13.8 -> 14.0, 512 x 8^3 16.75 -> 17.05 -- hence a switch.
+template <bool SEL = false>
 __device__ __forceinline__ double rotvec_factor(double w, double slthresh)
 {
     const double sl = one_minus_square(w);
+    if constexpr (SEL) {
+        if (__builtin_expect(w < 0.5 && sl >= slthresh, 0)) return 2.0 * vacos(w) * vrsqrt(sl);
+        const double z = __builtin_fma(w, -0.5, 0.5);
+        const double p = asin_zp(z);
+        const bool approx = sl < slthresh;
+        const double a = __builtin_fma(w, -2.0, 2.0), a2 = __builtin_fma(w, -4.0, 4.0);
+        const double num = approx ? a2 : __builtin_fma(p, 4.0, 4.0);
+        const double arg = approx ? a * sl : __builtin_fma(w, 2.0, 2.0);
+        const double f = num * vrsqrt(arg);
+        return sl <= 0 ? 0.0 : f;
+    }
     if (sl <= 0) return 0.0;                   // (sl > 0 from here: |w| < 1, the reference's clamp of w to 1 cannot act)
     if (sl < slthresh) {
         const double a = __builtin_fma(w, -2.0, 2.0), a2 = __builtin_fma(w, -4.0, 4.0);
@@ -314,26 +336,15 @@ __device__ __forceinline__ double rotvec_factor(double w, double slthresh)
     }
     if (w >= 0.5) {
         const double z = __builtin_fma(w, -0.5, 0.5);
-        double p = sconst(0.028169218060881414);
-        p = __builtin_fma(p, z, sconst(-0.010749050339697808));
-        p = __builtin_fma(p, z, sconst(0.01603551434914882));
-        p = __builtin_fma(p, z, sconst(0.0078029494773533175));
-        p = __builtin_fma(p, z, sconst(0.011875494382636922));
-        p = __builtin_fma(p, z, sconst(0.013929652902326633));
-        p = __builtin_fma(p, z, sconst(0.017355259955786323));
-        p = __builtin_fma(p, z, sconst(0.02237204763174451));
-        p = __builtin_fma(p, z, sconst(0.03038194736709848));
-        p = __builtin_fma(p, z, sconst(0.044642857103423646));
-        p = __builtin_fma(p, z, sconst(0.07500000000020764));
-        p = __builtin_fma(p, z, sconst(0.1666666666666665));
-        p *= z;
+        const double p = asin_zp(z);
         return __builtin_fma(p, 4.0, 4.0) * vrsqrt(__builtin_fma(w, 2.0, 2.0));
     }
     return 2.0 * vacos(w) * vrsqrt(sl);
 }
+template <bool SEL = false>
 __device__ __forceinline__ d3 to_rotvec(dq q, double slthresh)
 {
-    const double f = rotvec_factor(q.w, slthresh);
+    const double f = rotvec_factor<SEL>(q.w, slthresh);
     return mk3(q.x * f, q.y * f, q.z * f);
 }
 
@@ -378,6 +389,7 @@ __device__ __forceinline__ void store_bond_hist(const DBatch& B, int slot, const
 // to both orientations): pure arithmetic, `H` in/out.  The outputs are still in the permuted global frame (the caller applies
 // ToOrigDirBond); f2 is only computed for heterogeneous bonds (F2 = -F1 is enforced after the back-rotation otherwise).
 // damp_on = a previous step exists (no damping on the first one, dt == 0 then: VXS_BondInternal.cpp:311).
+template <bool SEL = false>
 __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DBondClass& C, BondHist& H,
                                                        d3 xrel, dq a1, dq a2, double nom_dist, bool damp_on)
 {
@@ -402,6 +414,9 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
         if (!small && new2w > B.small_angle_w && turn_lt && ext_lt) { small = true; changed = true; }
         else if (small && (!(new2w > B.smallish_angle_w) || turn_gt || ext_gt)) { small = false; changed = true; }
     }
+    // (Round 4, measured: a wavefront whose 64 bonds are of both modes runs both branches below, and in the bench population 6 % of the
+    // bonds are small-angle, so nearly every wavefront does.  The ceiling of sorting the bonds by mode -- every bond forced large-angle, the
+    // small branch compiled out, timing only -- is 25.15 -> 24.92 us per step: not worth a per-launch re-sort of DBatch::bsched.)
 
     // Angle1 is (0, y, z) in both modes: zero in the small one, and the rotation vector of FromAngleToPosX's quaternion, whose x is
     // an exact zero, in the large one -- the x component is left out of everything below (0 - a == -a, a - 0 == a: the same bits)
@@ -420,11 +435,11 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
         const dq align = from_angle_to_pos_x(rel, len);
         rot = qmul_x0(align, conj(a1));
         pos2 = mk3(len - nom_dist, 0, 0);
-        const double f1 = rotvec_factor(align.w, B.slthresh_acos2sqrt);
+        const double f1 = rotvec_factor<SEL>(align.w, B.slthresh_acos2sqrt);
         ang1y = align.y * f1; ang1z = align.z * f1;
         qb2 = qmul(rot, a2);               // (re-associated as align (conj(a1) a2): needs all of conj(a1) a2, 12 operations more than it saves)
     }
-    const d3 ang2 = to_rotvec(qb2, B.slthresh_acos2sqrt);   // one instance for both modes: a mixed wave runs it once
+    const d3 ang2 = to_rotvec<SEL>(qb2, B.slthresh_acos2sqrt);   // one instance for both modes: a mixed wave runs it once
 
     // axial stress (UpdateBondStrain, VXS_BondInternal.cpp:189-307; linear materials): the reference's series-spring
     // iteration is linear in the strain = elongation / L, its three factors (with the 1 / L) are constants of the bond
@@ -478,12 +493,12 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
 }
 
 // ... along axis A between voxel 1 (negative side) and voxel 2, the axis a compile-time constant (fused and streaming kernels)
-template <int A>
+template <int A, bool SEL = false>
 __device__ __forceinline__ BondOut bond_compute(const DBatch& B, const DBondClass& C, BondHist& H,
                                                 d3 p1, dq q1, double s1, d3 p2, dq q2, double s2,
                                                 bool damp_on)
 {
-    BondOut o = bond_compute_xframe(B, C, H, to_xdir<A>(p2 - p1), to_xdir<A>(q1), to_xdir<A>(q2), (s1 + s2) * 0.5, damp_on);
+    BondOut o = bond_compute_xframe<SEL>(B, C, H, to_xdir<A>(p2 - p1), to_xdir<A>(q1), to_xdir<A>(q2), (s1 + s2) * 0.5, damp_on);
     o.f1 = to_orig<A>(o.f1);
     o.f2 = C.homogeneous ? -o.f1 : to_orig<A>(o.f2);
     o.m1 = to_orig<A>(o.m1);
