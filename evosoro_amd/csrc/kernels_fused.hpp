@@ -776,6 +776,21 @@ __device__ __forceinline__ void fused_contact_reach(const double* ps, int seg, i
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// ... pass 1 for the WHOLE workgroup by the wavefronts that hold no bond of the Z slot (resident kernel, two accumulator tiles): they
+// idle there, the poses are those the voxel phase is going to test, and barrier (B) stands between these bits and their readers.
+// Pairs [first, end) of the copy, shared by `nhelp` wavefronts, this one the `help`-th.  Same test, same bits as fused_contact_reach.
+template <int BLOCK>
+__device__ __forceinline__ void fused_contact_reach_all(const double* ps, int first, int end, int help, int nhelp, unsigned long long* mask, const int* rc_code)
+{
+    for (int p = first + (help << 6) + (int)(threadIdx.x & 63); p < end; p += nhelp << 6) {
+        const int code = rc_code[p];
+        const int l2 = code & 1023, l1 = (code >> 10) & 1023;
+        const double nom = (ps[3 * BLOCK + l2] + ps[3 * BLOCK + l1]) * 0.75;
+        if (contact_in_reach(ps[l2] - ps[l1], ps[BLOCK + l2] - ps[BLOCK + l1], ps[2 * BLOCK + l2] - ps[2 * BLOCK + l1], nom))
+            atomicOr(&mask[l1], 1ull << ((unsigned)code >> 20));
+    }
+}
+
 template <int BLOCK>
 __device__ __forceinline__ d3 fused_contact_forces(const DBatch& B, const DRobot& R, const double* ps, d3 F, d3 pos, double scale, int self, int v, int rowd,
                                                    unsigned long long* mask, const int* rc_code, const double* rc_a1)
@@ -866,8 +881,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     // still in the voxel phase of step n (it idles at the barrier otherwise); only the collision-horizon decision,
     // which needs every voxel's new velocity, stays between the barriers
     __shared__ FusedCtl s_ctl[2];
-    __shared__ int s_div, s_seg[2 * (BLOCK / 64)];
-    static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + 2 * sizeof(int) + 2 * 16 * sizeof(int) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
+    __shared__ int s_div, s_na[3], s_seg[2 * (BLOCK / 64)];
+    static_assert(sizeof(DRobotState) + 2 * sizeof(FusedCtl) + 5 * sizeof(int) + 2 * 16 * sizeof(int) + 16 <= VXH_FUSED_STATIC_LDS, "static LDS bound");
 
     const int tid = threadIdx.x;
 #ifdef VXH_PHASE_TIMING
@@ -879,7 +894,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     const int base = R.vox_begin;
     const bool valid = tid < R.nvox;
     const int v = base + tid;
-    if (tid == 0) rs = B.rstate[r];
+    if (tid == 0) { rs = B.rstate[r]; s_na[0] = s_na[1] = s_na[2] = 0; }
     // the robot's class tables: copied into LDS, or (TABG: robots with per-voxel evolved stiffness, where nearly every
     // bond and voxel is a class of its own and the tables outgrow the LDS) read from HBM / L2 where they lie
     const int nbd = TABG ? 0 : R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = TABG ? 0 : R.n_vclass * (int)(sizeof(DVoxClass) / 8);
@@ -927,6 +942,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     for (int a = 0; a < 3; ++a) {
         entry[a] = B.bsched[R.sched_begin + a * BLOCK + tid];      // (also threads without a voxel: the Y chunks are dealt to the idle wavefronts)
         if (entry[a] != -1) modebits |= (unsigned)(B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] & 3) << (2 * a);
+    }
+    // wavefronts that hold bonds of a slot (two tiles: that matters for Z, whose list goes to the threads in order -- the first s_na[2]
+    // wavefronts; one tile: X, Y and Z all do); the others run the contact reach test of the whole workgroup there (fused_contact_reach_all)
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int a = (NACC == 2 ? 2 : 0); a < 3; ++a) if (entry[a] != -1) atomicAdd(&s_na[a], 1);
     }
     if (valid) {
         const int b0 = rs.steps & 1;
@@ -1038,6 +1059,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     { const unsigned long long t_now = __builtin_readcyclecounter(); if (!MESH && B.prof && tid == 0) atomicAdd(&B.prof[2113], t_now - t_pro); t_pro = t_now; }   // rows_to_lds as a whole
 #endif
     __syncthreads();                           // control of the first step + every voxel's pose visible
+    constexpr int NWAVES = BLOCK / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (one tile, 1024 threads: a third of the pairs in each of the three rounds -- a dense lattice leaves ONE wavefront idle per round)
+    const int nz = __builtin_amdgcn_readfirstlane(s_na[2]);
+    const int nx = NACC == 1 ? __builtin_amdgcn_readfirstlane(s_na[0]) : 0, ny = NACC == 1 ? __builtin_amdgcn_readfirstlane(s_na[1]) : 0;
+    const bool reach_early = (R.flags & RF_SELF_COL) && nz < NWAVES && nx < NWAVES && ny < NWAVES && !VXH_DBG(32);     // (uniform)
+    // pairs of the LDS copy that are really there: the wavefronts whose rows fit are a prefix (a wavefront's place is the sum of ALL
+    // earlier totals), so the sum of their totals is the end of the valid stretch
+    auto pairs_in_copy = [&]() { int n = 0; for (int w = 0; w < NWAVES; ++w) n += max(s_seg[2 * w + 1], 0); return __builtin_amdgcn_readfirstlane(n); };
+    int npairs = reach_early ? pairs_in_copy() : 0;
     VXH_T_DECL
 #ifdef VXH_PHASE_TIMING
     unsigned long long reb_cycles = 0;
@@ -1089,6 +1120,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             }
 #endif
             rows_to_lds(false);
+            if (reach_early) npairs = pairs_in_copy();
 #pragma unroll
             for (int k = 1; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;      // the scratch of the broad-phase (plane 0: below)
             scratch_used = true;
@@ -1114,10 +1146,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // X + Y: the held outputs raise the peak of the bond's register need, 28 -> 124 B of scratch, 25.5 -> 25.9 us per step.)
         bool div = false;
         fused_round<0, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[0], modebits, damp_on, div, st, st_stride);
-        if constexpr (NACC == 1) __syncthreads();
+        if constexpr (NACC == 1) {
+            if (reach_early && wave >= nx) fused_contact_reach_all<BLOCK>(ps, 0, npairs / 3, wave - nx, NWAVES - nx, cmask, rc_code);
+            __syncthreads();
+        }
         fused_round<1, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[1], modebits, damp_on, div, st, st_stride);
+        if constexpr (NACC == 1) { if (reach_early && wave >= ny) fused_contact_reach_all<BLOCK>(ps, npairs / 3, 2 * (npairs / 3), wave - ny, NWAVES - ny, cmask, rc_code); }
         __syncthreads();
         fused_round<2, BLOCK, NACC, MESH>(B, R, bct, ps, acc, entry[2], modebits, damp_on, div, st, st_stride);
+        if (reach_early && wave >= nz) fused_contact_reach_all<BLOCK>(ps, NACC == 1 ? 2 * (npairs / 3) : 0, npairs, wave - nz, NWAVES - nz, cmask, rc_code);
         if (div) s_div = 1;
         VXH_T_MARK(2)
         __syncthreads();                       // (B)
@@ -1133,8 +1170,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         double vel2 = 0;
         VoxState S;
         if (R.flags & RF_SELF_COL) {
-            const int nseg = s_seg[2 * (tid >> 6) + 1];     // pairs in the LDS copy of my wavefront's contact rows (-1: the rows are read from memory)
-            if (nseg > 0) fused_contact_reach<BLOCK>(ps, s_seg[2 * (tid >> 6)], nseg, cmask, rc_code);   // every lane: the wavefront shares the pairs
+            if (!reach_early) {                             // (else: done in the Z slot by the wavefronts without a Z bond)
+                const int nseg = s_seg[2 * (tid >> 6) + 1];     // pairs in the LDS copy of my wavefront's contact rows (-1: the rows are read from memory)
+                if (nseg > 0) fused_contact_reach<BLOCK>(ps, s_seg[2 * (tid >> 6)], nseg, cmask, rc_code);   // every lane: the wavefront shares the pairs
+            }
         }
         if (valid) {
             d3 F = mk3(acc[tid], acc[BLOCK + tid], acc[2 * BLOCK + tid]), M = mk3(acc[3 * BLOCK + tid], acc[4 * BLOCK + tid], acc[5 * BLOCK + tid]);

@@ -221,6 +221,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
     }
     rows_to_lds();
     __syncthreads();                           // control of the first step + every voxel's pose visible
+    // wavefronts that finish the bond phase a bond early -- without a bond at all, or, when the list is longer than the workgroup, without a
+    // SECOND one (the list fills the threads in order) -- run the contact reach test of the whole workgroup there (fused_contact_reach_all,
+    // kernels_fused.hpp: the bits are read behind barrier (B))
+    constexpr int NWAVES = BLOCK / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbw = ((nb <= BLOCK ? nb : nb - BLOCK) + 63) >> 6;
+    const bool reach_early = (R.flags & RF_SELF_COL) && nbw < NWAVES;
+    auto pairs_in_copy = [&]() { int n = 0; for (int w = 0; w < NWAVES; ++w) n += max(s_seg[2 * w + 1], 0); return __builtin_amdgcn_readfirstlane(n); };
+    int npairs = reach_early ? pairs_in_copy() : 0;
     // The step loop.  Barriers of a step: (B) behind the bond phase, (X) behind the voxel phase -- and, with ONE pose tile, (A) behind
     // the pose stores that then follow (X).  What used to sit between two barriers on one lane, the collision-horizon update
     // (UpdateCollisions: MaxDisp += |MaxVoxVel dt / lattice|, rebuild when it passes the horizon), every thread now evaluates for
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
         if (__builtin_expect(k_rebuild, 0)) {
             fused_rebuild<BLOCK>(B, R, rs, ps, rec, 12 * BLOCK, (double*)cmask, max(0, lds_doubles - (int)((double*)cmask - lds)), vct);
             rows_to_lds();
+            if (reach_early) npairs = pairs_in_copy();
         }
         d3 drag = mk3(0, 0, 0);
         const bool fluid = MESH && (R.flags & RF_FLUID) != 0;
@@ -261,6 +271,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
         bool div = false;
         if (e0 != -1) div = wide_bond<BLOCK, MESH>(B, R, bct, ps, rec, e0, tid, modebits, 0, damp_on, st);
         if (e1 != -1) div = wide_bond<BLOCK, MESH>(B, R, bct, ps, rec, e1, tid + BLOCK, modebits, 2, damp_on, st) || div;
+        if (reach_early && wave >= nbw) fused_contact_reach_all<BLOCK>(ps, 0, npairs, wave - nbw, NWAVES - nbw, cmask, rc_code);
         if (div) s_divf[par] = 1;
         VXH_T_MARK(2)
         __syncthreads();                       // (B)
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void k_robot_wide(DBatch B, con
         // ---- voxel phase, translation: damping + bond forces in the reference's order, contacts, floor, integration
         double vel2 = 0;
         d3 pos = mk3(0, 0, 0);
-        if (R.flags & RF_SELF_COL) {
+        if ((R.flags & RF_SELF_COL) && !reach_early) {
             const int nseg = s_seg[2 * (tid >> 6) + 1];
             if (nseg > 0) fused_contact_reach<BLOCK>(ps, s_seg[2 * (tid >> 6)], nseg, cmask, rc_code);
         }

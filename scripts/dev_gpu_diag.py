@@ -505,7 +505,9 @@ if __name__ == "__main__" and "launchcost" in sys.argv[1:]:
     for col in ((True,) if lc_dbg else (True, False)):
         sim = Sim(self_collisions_enabled=col, dt_frac=0.9, simulation_time=2.0, fitness_eval_init_time=0.4)
         paths = []
-        for ind in workloads.population(512, (10, 10, 10)):
+        pop = ([workloads.make_individual(i, workloads.full_material(10, 1 + i)) for i in range(512)] if "dense" in sys.argv[1:]      # (the 1024-thread variant)
+               else workloads.population(512, (10, 10, 10)))
+        for ind in pop:
             write_voxelyze_file(sim, Env(), ind, tmp, "c%d" % col)
             paths.append(os.path.join(tmp, "voxelyzeFiles", "c%d--id_%05i.vxa" % (col, ind.id)))
         rows = []
@@ -623,7 +625,9 @@ if __name__ == "__main__" and "lc2" in sys.argv[1:]:
     for col in ((True,) if "colonly" in sys.argv[1:] else (True, False)):
         sim = Sim(self_collisions_enabled=col, dt_frac=0.9, simulation_time=2.0, fitness_eval_init_time=0.4)
         paths = []
-        for ind in workloads.population(512, (10, 10, 10)):
+        pop = ([workloads.make_individual(i, workloads.full_material(10, 1 + i)) for i in range(512)] if "dense" in sys.argv[1:]      # (the 1024-thread variant)
+               else workloads.population(512, (10, 10, 10)))
+        for ind in pop:
             write_voxelyze_file(sim, Env(), ind, tmp, "c%d" % col)
             paths.append(os.path.join(tmp, "voxelyzeFiles", "c%d--id_%05i.vxa" % (col, ind.id)))
         rows = []
@@ -902,7 +906,7 @@ if __name__ == "__main__" and "cli30" in sys.argv[1:]:
 
 
 if __name__ == "__main__" and "statehash" in sys.argv[1:]:
-    # a digest of every voxel's state of 48 bench robots (10^3, self-collision) + 16 dense 9^3 + 8 dense 10^3 ones after 700 steps: two builds of the
+    # a digest of every voxel's state of 48 bench robots (10^3, self-collision) + 16 dense 9^3 + 8 dense 10^3 + 32 small ones after 700 steps: two builds of the
     # library that claim the same arithmetic in another schedule must print the same line (scripts/ab_lib.py <lib> statehash)
     import hashlib
     tmp = tempfile.mkdtemp()
@@ -911,7 +915,9 @@ if __name__ == "__main__" and "statehash" in sys.argv[1:]:
     with engine.Engine(engine.VOXCAD, 0) as eng:
         eng.set_option("tiled", 0)
         inds = ([workloads.random_robot(i, (10, 10, 10), i) for i in range(48)] + [workloads.make_individual(100 + i, workloads.full_material(9, 1 + i)) for i in range(16)]
-                + [workloads.make_individual(200 + i, workloads.full_material(10, 1 + i)) for i in range(8)])      # (the last: the 1024-thread variant)
+                + [workloads.make_individual(200 + i, workloads.full_material(10, 1 + i)) for i in range(8)]      # (the 1024-thread variant)
+                + [workloads.random_robot(300 + i, (6, 6, 6), 300 + i) for i in range(16)]                             # (the wide kernel, few bonds)
+                + [workloads.random_robot(400 + i, (8, 8, 8), 400 + i) for i in range(16)])                            # (the wide kernel, most lanes busy)
         for ind in inds:
             write_voxelyze_file(sim, Env(), ind, tmp, "h")
             eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "h--id_%05i.vxa" % ind.id))
