@@ -1181,11 +1181,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
                 F = F + mk3(acc[6 * BLOCK + tid], acc[7 * BLOCK + tid], acc[8 * BLOCK + tid]);
                 M = M + mk3(acc[9 * BLOCK + tid], acc[10 * BLOCK + tid], acc[11 * BLOCK + tid]);
             }
-#pragma unroll
-            for (int k = 0; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;
             S.pos = mk3(ps[tid], ps[BLOCK + tid], ps[2 * BLOCK + tid]); S.scale = ps[3 * BLOCK + tid];
             S.ang = mkq(ps[4 * BLOCK + tid], ps[5 * BLOCK + tid], ps[6 * BLOCK + tid], ps[7 * BLOCK + tid]);
             S.lm = lm; S.am = am;
+            // (measured and not kept: the class constants copied by value here, so that their LDS reads go out with the sums and the pose
+            // instead of one by one inside the update -- 23.45 -> 23.68 us per step, and other contraction choices, i.e. other last bits)
             const d3 vel = S.lm * C.mass_inv;
             F = F + (vel * (-R.slow_z)) * C.c_lin;
 #ifdef VXH_PHASE_TIMING
@@ -1223,6 +1223,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             vel2 = voxel_update(B, R, C, vv, fetch, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, -1, 0, fluid, drag,
                                 SLIM ? B.act_sb[vv] : pht[tid], SLIM ? B.act_cb[vv] : pht[BLOCK + tid], amp_damp);
             lm = S.lm; am = S.am;
+            // the accumulators zeroed for the next step -- HERE, behind the update: stores into the LDS between the reads above and the
+            // update's own (class table, contact rows) kept the compiler from issuing those reads together (23.75 -> 23.43 us per step)
+#pragma unroll
+            for (int k = 0; k < NACC * 6; ++k) acc[k * BLOCK + tid] = 0.0;
         }
         // next step's control, off the critical path.  (Round 4, measured and taken out again: the same call issued earlier -- next to the
         // X / Y chunks with one Y chunk fewer on this wavefront, 25.2 -> 26.0 us per step: that slot is issue-bound on every SIMD; or
