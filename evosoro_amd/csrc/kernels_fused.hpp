@@ -700,7 +700,9 @@ __device__ __forceinline__ BondOut fused_bond(const DBatch& B, const DRobot& R, 
     const d3 p2 = mk3(ps[l2], ps[BLOCK + l2], ps[2 * BLOCK + l2]);
     const double s2 = ps[3 * BLOCK + l2];
     const dq q2 = mkq(ps[4 * BLOCK + l2], ps[5 * BLOCK + l2], ps[6 * BLOCK + l2], ps[7 * BLOCK + l2]);
-    BondOut o = bond_compute<A, true>(B, bct[(unsigned)entry >> 20], H, p1, q1, s1, p2, q2, s2, damp_on);
+    // (rotation-vector factor in select form where it was measured faster: the 768-thread variant, 25.15 -> 24.96 us per step; on the
+    // 1024-thread one it costs 5 %, dense 10^3 lattices 33.6 -> 35.3 -- same bits either way, kernels.hpp rotvec_factor)
+    BondOut o = bond_compute<A, BLOCK == 768>(B, bct[(unsigned)entry >> 20], H, p1, q1, s1, p2, q2, s2, damp_on);
     if (H.store_hist) { hrec[0] = make_double2(H.p0, H.p1); hrec[1] = make_double2(H.p2, H.g0); hrec[2] = make_double2(H.g1, H.g2); }
     modebits = (modebits & ~(3u << (2 * A))) | (H.flags << (2 * A));
     if constexpr (MESH) {                     // SetStrainDir (VXS_BondInternal.cpp:300-304): +A side of voxel 1, -A side of voxel 2
