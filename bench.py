@@ -20,8 +20,8 @@ N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak
 READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 1024 steps (engine option steps_per_launch), a
 launch of a self-colliding population carries ~0.07 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
 robots run a ~0.04 ms collision broad-phase; 0.27 and 0.17 ms until round 3), and a call ~0.04 ms on the host.  `--steps 20 --warmup 5`
-(what the round-end driver runs) therefore reports ~1.2e10 voxel-steps/s (~29.7 us per step; round 3: 1.03e10, round 2: 7.4e9), the
-default `--steps 2000` ~1.40e10 (~25.5 us; round 3: 1.17e10) -- same kernel, same population; `timed_region` in the line says which case it is.
+(what the round-end driver runs) therefore reports ~1.24e10 voxel-steps/s (~28.7 us per step; round 3: 1.03e10, round 2: 7.4e9), the
+default `--steps 2000` ~1.47e10 (~24.2 us; round 3: 1.17e10) -- same kernel, same population; `timed_region` in the line says which case it is.
 
 The JSON line also carries
   roofline      HBM: algorithmic bytes (224*Nvox + 144*Nbond per voxel-step) of the dominant kernel over its
@@ -587,8 +587,8 @@ def main():
                             "population without self-collision, ~0.065 ms for this one (prologue/epilogue of two robots per CU ~0.03 ms; the "
                             "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.04 ms per run, ~50 of 512 robots in "
                             "any 20-step launch; 0.27 / 0.17 ms until round 3); a call costs ~0.04 ms on the host.  Per step WITHOUT those: "
-                            "~25 us.  --steps 20 times ONE 20-step launch (~29.7 us per step, ~1.2e10 voxel-steps/s); the default "
-                            "--steps 2000 times two launches of up to 1024 steps (~25.5 us, ~1.40e10).  "
+                            "~23.5 us.  --steps 20 times ONE 20-step launch (~28.7 us per step, ~1.24e10 voxel-steps/s); the default "
+                            "--steps 2000 times two launches of up to 1024 steps (~24.2 us, ~1.47e10).  "
                             "DESIGN.md section 4 'The cost of a launch' and 'Measured (MI355X, round 4)'"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,

@@ -941,6 +941,19 @@ if __name__ == "__main__" and "mixedlaunch" in sys.argv[1:]:
             L, r["value"], 1e3 * r["gpu_seconds"], r["launches"], 1e3 * r["wall_seconds"]), flush=True)
 
 
+if __name__ == "__main__" and "benchsides" in sys.argv[1:]:
+    # bench.py's own side configurations (the dense 10^3 population, the mixed generation), for A/B runs of two libraries
+    sys.path.insert(0, REPO)
+    import torch
+    torch.cuda.init()
+    import bench
+    for _ in range(2):
+        r = bench.side_config(engine, "dense", engine.VOXCAD, 512, (10, 10, 10), Env(), 0, 512, full=True, init_time=0.01)
+        print("%s dense 10^3: %.2f us per step" % (os.path.basename(engine.LIB_PATH), r["us_per_step"]), flush=True)
+        r = bench.mixed_generation(engine, 0)
+        print("%s mixed generation: %.3e voxel-steps/s" % (os.path.basename(engine.LIB_PATH), r["value"]), flush=True)
+
+
 if __name__ == "__main__" and "smallcfgs" in sys.argv[1:]:
     # the small populations of BASELINE configs[1] and [3] (wide kernel) and a saturated one, for A/B runs of two libraries
     env_w = Env()
