@@ -10,6 +10,9 @@
 //           of one lane per voxel whether it has that bond or not.  Up to 768 threads the X and Y slots are evaluated back to back
 //           WITHOUT a barrier between them (their sums commute: below), the Y chunks dealt to the wavefronts X leaves idle; Z follows
 //           behind a barrier.  The history of a bond is one 48-byte record in DBatch::hist_aos.
+//   contact pairs  (self-colliding robots) the reach test of every listed pair -- pass 1 of fused_contact_forces -- is run for the whole
+//           workgroup by the wavefronts that hold no bond of the Z slot, while the others evaluate theirs (fused_contact_reach_all): it needs
+//           the poses only, and at the head of the voxel phase it was a latency chain on every wavefront at once.
 // Dynamic LDS layout (doubles):
 //   ps   [8][BLOCK]        pose tile: pos x y z, scale, quaternion w x y z of every voxel (read by bonds, contact forces,
 //                          the broad-phase, the drag mesh)
