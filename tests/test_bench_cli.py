@@ -90,3 +90,25 @@ def test_gpus_2_on_one_device_with_the_real_engine():
     out = _line(proc)
     assert out["n_gpus"] == 2 and out["config"]["robots_per_gpu"] == 16 and out["value"] > 0
     assert out["strong"]["value"] > 0 and out["multi_handle"]["robots"] == 32
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl_with_the_host_side_control_group():
+    """The closest a 1-GPU box gets to the N > 1 launch the round-end driver makes: ONE rank, but through the distributed branch with the
+    real backends -- the default group is RCCL (`init_process_group("nccl", device_id=...)`), the control plane a gloo group beside it,
+    the fitness gather an RCCL collective (VXH_FORCE_DIST=1, rendezvous on 127.0.0.1 as the driver's launcher sets it up)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=REPO, VXH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--robots-per-gpu", "16",
+                           "--lattice", "6", "--no-cpu-baseline", "--no-other-configs"], env=env, cwd=REPO, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=900)
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    out = _line(proc)
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert "gloo host group" in out["control_plane"] and "RCCL" in out["control_plane"], out["control_plane"]
+    assert out["fitness_gather_ms"] is not None and out["fitness_gather_ms"] >= 0
