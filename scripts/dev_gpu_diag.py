@@ -941,6 +941,18 @@ if __name__ == "__main__" and "mixedlaunch" in sys.argv[1:]:
             L, r["value"], 1e3 * r["gpu_seconds"], r["launches"], 1e3 * r["wall_seconds"]), flush=True)
 
 
+if __name__ == "__main__" and "widephases" in sys.argv[1:]:
+    # developer timers of the wide kernel on BASELINE configs[1] and [3] (library built by `make -C evosoro_amd/csrc prof`)
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    print("64 x 6^3", flush=True)
+    timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.1, Env(), {}, phases=True)
+    print("64 x 8^3 swimmers", flush=True)
+    timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, {}, per_voxel_phase=True, phases=True)
+
+
 if __name__ == "__main__" and "benchsides" in sys.argv[1:]:
     # bench.py's own side configurations (the dense 10^3 population, the mixed generation), for A/B runs of two libraries
     sys.path.insert(0, REPO)
