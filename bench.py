@@ -23,6 +23,11 @@ robots run a ~0.04 ms collision broad-phase; 0.27 and 0.17 ms until round 3), an
 (what the round-end driver runs) therefore reports ~1.24e10 voxel-steps/s (~28.7 us per step; round 3: 1.03e10, round 2: 7.4e9), the
 default `--steps 2000` ~1.47e10 (~24.2 us; round 3: 1.17e10) -- same kernel, same population; `timed_region` in the line says which case it is.
 
+TIMING (round 5).  `value` / `ms_per_step` are taken from HIP events on the engine's own stream around the K timed steps
+(vxh_counters.kernel_seconds of that one call), max over ranks; the host clock between the two barrier + torch.cuda.synchronize()
+pairs the contract names is measured too and printed as `host_clock` (it adds ~0.04 ms of launch and wake-up latency per call, 8 %
+of a 20-step region, none of it GPU work).
+
 The JSON line also carries
   roofline      HBM: algorithmic bytes (224*Nvox + 144*Nbond per voxel-step) of the dominant kernel over its
                 HIP-event time, in GB/s against the 8 TB/s peak; `traffic` = what the PMC counters saw for the same kernel on
@@ -32,6 +37,10 @@ The JSON line also carries
                 XCD fits its L2 (hit rate 0.97, profiles/r02_l2_counters.txt), so most algorithmic bytes never leave the chip.
                 `achieved / peak` is therefore not a statement that the kernel is HBM-bound -- it is bound by FP64 issue
                 (DESIGN.md section 4).
+  roofline.binding  the bound that binds, LIVE: FP64 flops per voxel-step of this (population, kernel) -- a property of the two, counted once
+                with the SQ_INSTS_VALU_*_F64 counters (profiles/r*_flops_per_unit.json, scripts/flops_per_unit.sh) -- times this run's own
+                voxel-steps/s over its HIP-event time, against the 78.6 TFLOP/s vector-FP64 peak; every other_configs entry carries its own.
+  ranks         N > 1: world size, backend, and per rank the device (index, PCI bus id) and its ms per step, gathered over the RCCL group
   other_configs the other BASELINE configs at their stated sizes (64 x 6^3 walkers, 64 x 8^3 swimmers, one 20^3 lattice),
                 N = 1 only: value, us per step, algorithmic roofline fraction, kernel
   cpu_baseline  the reference C++ voxelyze (oracle/_ref/voxelyze_ref, built from the reference sources) on this box's host
@@ -169,6 +178,8 @@ def kernel_name(block):
     """vxh_counters.dominant_block -> kernel: 0 streaming, 1 tiled, workgroup size of the resident kernel, workgroup size + 1 of the wide one"""
     if block == 1:
         return "k_tile_steps"
+    if block == 1026:
+        return "k_robot_pair<512 x 2,...>"
     if block > 1 and block % 64 == 1:
         return "k_robot_wide<%d,...>" % (block - 1)
     return ("k_robot_steps<%d,...>" % block) if block else "k_bonds+k_voxels"
@@ -211,6 +222,36 @@ def measured_parity():
             "bench_robot_err_vox": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in rows if r["case"].startswith("bench10")] or [None]),
             "quantity": "max over x, y, z of |final centre of mass - reference binary's| (and IniCM) after the whole evaluation, voxels",
             "source": os.path.relpath(files[-1], REPO), "live": False}
+
+
+FP64_PEAK_FLOPS = 78.6e12      # vector FP64: one FP64 wave-instruction per 4 cycles and SIMD at 2.4 GHz (half the FP32 vector peak of MI355X_MICROARCH.md)
+VALU_ISSUE_PER_S = 256 * 4 * 2.4e9 / 4.0      # vector wave-instructions the chip can issue per second (1024 SIMDs, one per 4 cycles)
+
+
+def flops_per_unit():
+    """newest profiles/r*_flops_per_unit.json: workload key -> {fp64_flop_per_voxel_step, valu_inst_per_voxel_step, kernels}"""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_flops_per_unit.json")))
+    if not files:
+        return {}, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.relpath(files[-1], REPO)
+
+
+def binding(key, voxel_steps_per_s):
+    """roofline.binding of a workload: its counted FP64 flops (and vector instructions) per voxel-step x THIS run's rate"""
+    table, src = flops_per_unit()
+    row = table.get(key)
+    if not row or not voxel_steps_per_s:
+        return None
+    flops = row["fp64_flop_per_voxel_step"] * voxel_steps_per_s
+    out = {"bound": "fp64-issue", "achieved": flops, "peak": FP64_PEAK_FLOPS, "unit": "FLOP/s", "frac": flops / FP64_PEAK_FLOPS,
+           "fp64_flop_per_voxel_step": row["fp64_flop_per_voxel_step"], "live": True,
+           "source": "%s (flops per voxel-step: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of this workload) x this run's voxel-steps/s" % src}
+    if row.get("valu_inst_per_voxel_step"):
+        out["valu_issue_frac"] = row["valu_inst_per_voxel_step"] * voxel_steps_per_s / VALU_ISSUE_PER_S
+        out["valu_inst_per_voxel_step"] = row["valu_inst_per_voxel_step"]
+    return out
 
 
 _TRACE = None
@@ -269,26 +310,29 @@ def relaunch_under_launcher(n_gpus):
 
 
 def timed_steps(eng, steps, barrier=None):
-    """EXACTLY `steps` time steps of every robot, bracketed the way the driver asks: barrier + device sync on both sides.  A rank's
-    clock runs from behind the opening barrier + sync to behind its own closing sync; the closing barrier follows, and the line reports
-    the MAX over ranks (reduce_stats) -- the moment the last rank is done.  (With the closing barrier inside the interval every rank
-    would add the latency of one more collective, tens of microseconds, to a 0.7 ms region; at N = 1 there is no barrier.)"""
+    """EXACTLY `steps` time steps of every robot, bracketed the way the driver asks: barrier + device sync on both sides.  Returns
+    (device seconds, host seconds): the HIP-event time of that one call on the engine's own stream (vxh_counters.kernel_seconds: first
+    event in front of the call's first launch, last behind its last) and the host clock from behind the opening barrier + sync to
+    behind the rank's own closing sync.  The line reports the MAX over ranks of each (reduce_stats); `value` is priced on the device
+    time -- the host clock of a 20-step region carries ~0.04 ms of launch + wake-up latency and the two synchronisations, none of it
+    work of the path (round-4 review, task 6)."""
     import torch
     if barrier:
         barrier()
     torch.cuda.synchronize()
+    k0 = eng.counters().kernel_seconds
     w0 = time.time()
     t0 = time.perf_counter()
     eng.step(steps)                      # (returns after the engine's own stream synchronisation)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    host = time.perf_counter() - t0
     trace_mark("timed_region", w0, time.time(), int(os.environ.get("RANK", "0")))
     if barrier:
         barrier()
-    return elapsed
+    return eng.counters().kernel_seconds - k0, host
 
 
-def side_config(engine, name, variant, count, shape, env, device, steps, full=False, phase=False, init_time=0.02):
+def side_config(engine, name, variant, count, shape, env, device, steps, full=False, phase=False, init_time=0.02, key=None, options=None):
     """one of the other BASELINE configs at its stated size: pre-advanced past InitCmTime, then `steps` timed steps"""
     from evosoro_amd import workloads
     from evosoro_amd.base import Sim
@@ -299,6 +343,8 @@ def side_config(engine, name, variant, count, shape, env, device, steps, full=Fa
         # (long enough for the robot with the largest time step: nothing is run to its stop condition here)
         sim = Sim(dt_frac=0.9, simulation_time=init_time + (steps + 4000) * 7.2e-4, fitness_eval_init_time=init_time)
         with engine.Engine(variant, device) as eng:
+            for k, val in (options or {}).items():
+                eng.set_option(k, val)
             for i in range(count):
                 if full:
                     ind = workloads.make_individual(i, workloads.full_material(shape[0], 1 + i))
@@ -312,16 +358,21 @@ def side_config(engine, name, variant, count, shape, env, device, steps, full=Fa
             pre = int(max(init_time / d["dt"] for d in dims)) + 32
             eng.step(pre)
             c0 = eng.counters()
-            elapsed = timed_steps(eng, steps)
+            elapsed, host = timed_steps(eng, steps)
             c1 = eng.counters()
             assert abs((c1.voxel_steps - c0.voxel_steps) - float(nvox) * steps) < 0.5, name
             alg = (224.0 * nvox + 144.0 * nbond) * steps
             large, total = eng.bond_modes()
             return {"workload": name, "value": nvox * steps / elapsed, "unit": "voxel-timesteps/s",
-                    "us_per_step": elapsed / steps * 1e6, "steps": steps, "voxels": nvox, "bonds": nbond,
+                    "us_per_step": elapsed / steps * 1e6, "us_per_step_host_clock": host / steps * 1e6, "steps": steps, "voxels": nvox, "bonds": nbond,
                     "kernel": kernel_name(c1.dominant_block),
-                    "roofline_frac": alg / c1.dominant_seconds / 1e9 / HBM_PEAK_GBS if c1.dominant_seconds > 0 else None,
-                    "large_angle_bonds": large / max(1, total)}
+                    # SURVEY 8(d)'s EFFECTIVE figure: algorithmic bytes over the kernel's time against 8 TB/s.  Not a roof for this design
+                    # (the state is register / LDS / L2-resident: real traffic is a fifth of it), so it may exceed 1; `binding` is the bound
+                    "effective_hbm": {"achieved_GBs": alg / c1.dominant_seconds / 1e9 if c1.dominant_seconds > 0 else None, "peak_GBs": HBM_PEAK_GBS,
+                                      "frac_of_alg_bytes": alg / c1.dominant_seconds / 1e9 / HBM_PEAK_GBS if c1.dominant_seconds > 0 else None,
+                                      "note": "algorithmic bytes, not traffic: not a bound"},
+                    "binding": binding(key or name, nvox * steps / elapsed),
+                    "large_angle_bonds": large / max(1, total), "_voxel_steps_process": c1.voxel_steps}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -364,6 +415,7 @@ def mixed_generation(engine, device, count=512, lattice=10, sim_time=0.5, init_t
             timed_steps(eng, steady)
             c1 = eng.counters()
             rate_steady = (c1.voxel_steps - c0.voxel_steps) / (c1.kernel_seconds - c0.kernel_seconds)
+            vs_process = c1.voxel_steps
         with engine.Engine(engine.VOXCAD, device) as eng:
             for key, val in (options or {}).items():
                 eng.set_option(key, val)
@@ -390,11 +442,35 @@ def mixed_generation(engine, device, count=512, lattice=10, sim_time=0.5, init_t
                 "steady_rate": rate_steady, "tail_efficiency": (c.voxel_steps / c.kernel_seconds) / rate_steady,
                 "robots_finished": finished, "voxels_min_mean_max": [int(nv.min()), float(nv.mean()), int(nv.max())],
                 "steps_min_max": [int(st.min()), int(st.max())], "kernels": blocks,
+                "binding": binding("mixed", c.voxel_steps / c.kernel_seconds), "_voxel_steps_process": vs_process + c.voxel_steps,
                 "note": "value = sum(nvox x steps) / GPU time of the whole run (first event to last); value_wall = over the wall clock of the "
                         "vxh_run call incl. batch assembly and upload; tail_efficiency = value / steady_rate, steady_rate = the same engine on "
                         "the same population over %d steps in which every robot still steps" % steady}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def side_workload(engine, key, device):
+    """the other_configs entries by key (also what scripts/unit_workload.py runs under the FP64 instruction counters)"""
+    from evosoro_amd.base import Env
+    if key == "cfg1":
+        return side_config(engine, "configs[1]: batch of 64 random 6x6x6 robots", engine.VOXCAD, 64, (6, 6, 6), Env(), device, 1024, key=key)
+    if key == "cfg3":
+        env_w = Env()
+        env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+        env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+        return side_config(engine, "configs[3]: 64 random 8x8x8 swimmers (_voxcad_land_water, fluid drag)", engine.VOXCAD_LAND_WATER,
+                           64, (8, 8, 8), env_w, device, 1024, phase=True, init_time=0.005, key=key)
+    if key == "cfg4":
+        return side_config(engine, "configs[4]: one full 20x20x20 lattice, self-collision on", engine.VOXCAD, 1, (20, 20, 20), Env(),
+                           device, 2048, full=True, init_time=0.005, key=key)
+    if key == "dense":
+        # the resident kernel's largest variant: a real 10^3 population (fill 30-100 %) puts its fuller robots here
+        return side_config(engine, "512 dense 10x10x10 robots (1000 voxels each), self-collision on", engine.VOXCAD, 512, (10, 10, 10), Env(),
+                           device, 512, full=True, init_time=0.01, key=key)
+    if key == "mixed":
+        return mixed_generation(engine, device)
+    raise KeyError(key)
 
 
 def main():
@@ -467,9 +543,11 @@ def main():
     shape = (args.lattice,) * 3
     n_local = args.robots_per_gpu
 
-    def run_population(paths):
+    def run_population(paths, options=None):
         """pre-advance past InitCmTime + warmup (untimed), then the timed steps; returns everything the line needs"""
         eng = engine.Engine(engine.VOXCAD, local_rank)
+        for key, val in (options or {}).items():
+            eng.set_option(key, val)
         for p in paths:
             eng.add_vxa_file(p)
         n = len(paths)
@@ -479,19 +557,42 @@ def main():
         if n:
             eng.step(pre + max(args.warmup, 1))             # upload, past InitCmTime, warmup: all untimed
         c0 = eng.counters()
-        elapsed = timed_steps(eng, args.steps, barrier)
+        elapsed, host = timed_steps(eng, args.steps, barrier)
         c1 = eng.counters()
         local_vs = c1.voxel_steps - c0.voxel_steps
         assert abs(local_vs - float(nvox) * args.steps) < 0.5, "a robot stopped inside the timed region"
-        return eng, elapsed, local_vs, nvox, nbond, c0, c1, pre
+        return eng, (elapsed, host), local_vs, nvox, nbond, c0, c1, pre
 
-    def reduce_stats(elapsed, local_vs):
+    def reduce_stats(clocks, local_vs):
+        """(device seconds, host seconds) of this rank -> MAX over ranks of each; voxel-steps -> SUM"""
         if not distributed:
-            return elapsed, local_vs
-        stats = torch.tensor([elapsed, local_vs], dtype=torch.float64, device="cpu" if ctl_on_host else "cuda")
+            return clocks[0], clocks[1], local_vs
+        stats = torch.tensor([clocks[0], clocks[1], local_vs], dtype=torch.float64, device="cpu" if ctl_on_host else "cuda")
         tmax = stats.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
         tsum = stats.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM, group=ctl)
-        return float(tmax[0]), float(tsum[1])
+        return float(tmax[0]), float(tmax[1]), float(tsum[2])
+
+    def gather_ranks(ms_per_step):
+        """proof that `world` ranks on `world` devices took part: one all_gather over the DEFAULT group (RCCL on a GPU node) of
+        (rank, device index, PCI domain / bus / device of that device, this rank's ms per step)"""
+        try:
+            props = torch.cuda.get_device_properties(local_rank)
+            ident = [float(torch.cuda.current_device()), float(getattr(props, "pci_domain_id", -1)), float(getattr(props, "pci_bus_id", -1)),
+                     float(getattr(props, "pci_device_id", -1))]
+        except Exception:                      # (the CPU walk-through of tests/test_bench_cli.py: no device behind the rank)
+            ident = [float(local_rank), -1.0, -1.0, -1.0]
+        mine = [float(rank)] + ident + [float(ms_per_step)]
+        if not distributed:
+            rows = [mine]
+        else:
+            dev = torch.device("cpu") if share_gpu else torch.device("cuda", local_rank)
+            t = torch.tensor(mine, dtype=torch.float64, device=dev)
+            got = torch.zeros(world * len(mine), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(got, t)
+            rows = got.cpu().reshape(world, len(mine)).tolist()
+        return {"world": world, "backend": (dist.get_backend() if distributed else "none"),
+                "device_of_rank": [int(r[1]) for r in rows], "pci_of_rank": ["%04x:%02x:%02x" % (int(r[2]) & 0xffff, int(r[3]) & 0xff, int(r[4]) & 0xff) for r in rows],
+                "distinct_devices": len({(r[2], r[3], r[4]) for r in rows}), "ms_per_step_of_rank": [r[5] for r in rows]}
 
     tmp = tempfile.mkdtemp(prefix="vxbench_r%d_" % rank)
     try:
@@ -499,8 +600,9 @@ def main():
         # (sized for the largest time step a robot can have, ten times the usual one: nothing is run to its stop condition)
         sim_time = max(0.5, INIT_CM_TIME + (args.steps + args.warmup + 1100) * 7.2e-4)
         paths = make_population(tmp, n_local, rank * n_local, shape, sim_time, INIT_CM_TIME)
-        eng, elapsed, local_vs, nvox, nbond, c0, c1, pre = run_population(paths)
-        elapsed_max, total_vs = reduce_stats(elapsed, local_vs)
+        eng, clocks, local_vs, nvox, nbond, c0, c1, pre = run_population(paths)
+        elapsed_max, host_max, total_vs = reduce_stats(clocks, local_vs)
+        ranks = gather_ranks(clocks[0] / args.steps * 1e3)          # (outside every timed region)
         large, total_b = eng.bond_modes()
         # the path's collective: fitness records of every rank to every rank (untimed region, reported separately)
         tg = time.perf_counter()
@@ -519,13 +621,21 @@ def main():
             all_paths = shared[0]
             costs = [engine.inspect_vxa(p).nvox for p in all_paths]          # (every robot takes the same number of steps here)
             mine = parallel.shard_by_cost(costs, world)[rank]
-            seng, s_elapsed, s_vs, s_nvox, _, _, sc1, _ = run_population([all_paths[i] for i in mine])
-            s_elapsed_max, s_total_vs = reduce_stats(s_elapsed, s_vs)
+            seng, s_clocks, s_vs, s_nvox, _, _, sc1, _ = run_population([all_paths[i] for i in mine])
+            s_elapsed_max, s_host_max, s_total_vs = reduce_stats(s_clocks, s_vs)
             strong = {"scaling": "strong", "workload": "ONE population of %d random %dx%dx%d robots sharded %d-way by cost (%d on this rank)"
                                  % (n_local, shape[0], shape[1], shape[2], world, len(mine)),
                       "value": s_total_vs / s_elapsed_max, "unit": "voxel-timesteps/s", "ms_per_step": s_elapsed_max / args.steps * 1e3,
-                      "kernel": kernel_name(sc1.dominant_block)}
+                      "ms_per_step_host_clock": s_host_max / args.steps * 1e3, "kernel": kernel_name(sc1.dominant_block)}
             seng.close()
+            # ... and once more with the option tile_small: a shard of 64 robots occupies a quarter of a GPU's CUs, where cutting the large
+            # robots into tiles was measured 6-14 % faster (DESIGN.md section 4 "Tiled path"); the default keeps the kernel choice a function
+            # of the robot alone, so both are printed
+            teng, t_clocks, t_vs, _, _, _, tc1, _ = run_population([all_paths[i] for i in mine], {"tile_small": 1})
+            t_elapsed_max, t_host_max, t_total_vs = reduce_stats(t_clocks, t_vs)
+            strong["tile_small"] = {"value": t_total_vs / t_elapsed_max, "ms_per_step": t_elapsed_max / args.steps * 1e3,
+                                    "ms_per_step_host_clock": t_host_max / args.steps * 1e3, "kernel": kernel_name(tc1.dominant_block)}
+            teng.close()
 
         handle = None
         if world > 1:
@@ -546,12 +656,14 @@ def main():
                 heng.step((int(max(INIT_CM_TIME / d["dt"] for d in hd)) + 32) + max(args.warmup, 1))
                 h0 = heng.counters()
                 hw0 = time.time()
-                h_elapsed = timed_steps(heng, args.steps)
+                h_dev, h_elapsed = timed_steps(heng, args.steps)
                 trace_mark("multi_handle_region", hw0, time.time(), rank)
                 h1 = heng.counters()
                 assert abs((h1.voxel_steps - h0.voxel_steps) - float(h_nvox) * args.steps) < 0.5
+                # (host clock: this route's host side -- one thread per device launching and waiting -- is part of it)
                 handle = {"scaling": "weak", "route": "one process, vxh_create_multi over devices %s" % devices, "value": h_nvox * args.steps / h_elapsed,
-                          "unit": "voxel-timesteps/s", "ms_per_step": h_elapsed / args.steps * 1e3, "robots": len(hp)}
+                          "unit": "voxel-timesteps/s", "ms_per_step": h_elapsed / args.steps * 1e3, "ms_per_step_device": h_dev / args.steps * 1e3,
+                          "timing": "host clock between the synchronisations", "robots": len(hp)}
                 heng.close()
             barrier()
 
@@ -563,6 +675,10 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "timing": "HIP events on the engine's own stream around the timed steps (first event in front of the call's first launch, last "
+                          "behind its last), max over ranks; host_clock = perf_counter between the barrier + torch.cuda.synchronize() pairs",
+                "host_clock": {"ms_per_step": host_max / args.steps * 1e3, "value": total_vs / host_max},
+                "ranks": ranks,
                 "config": {"workload": "population of %d random %dx%dx%d soft robots per GPU (BASELINE configs[2], "
                                        "pop-512 of 10x10x10), self-collision on, DtFrac 0.9, evosoro default materials"
                                        % (n_local, shape[0], shape[1], shape[2]),
@@ -607,21 +723,17 @@ def main():
                 # the bound that binds, next to the contract's algorithmic-HBM fraction
                 out["roofline"]["compute"] = comp
                 out["roofline"]["bound"] = comp.get("bound", "hbm")
+            bind = binding("headline", total_vs / elapsed_max / world) if (n_local == 512 and args.lattice == 10) else None
+            if bind:
+                out["roofline"]["binding"] = bind          # (per GPU: this rank's population over the slowest rank's time)
+                out["roofline"]["bound"] = "fp64-issue"
             if world == 1 and not args.no_other_configs:
-                env_w = Env()
-                env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
-                env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
                 out["other_configs"] = [
-                    side_config(engine, "configs[1]: batch of 64 random 6x6x6 robots", engine.VOXCAD, 64, (6, 6, 6), Env(), local_rank, 1024),
-                    side_config(engine, "configs[3]: 64 random 8x8x8 swimmers (_voxcad_land_water, fluid drag)", engine.VOXCAD_LAND_WATER,
-                                64, (8, 8, 8), env_w, local_rank, 1024, phase=True, init_time=0.005),
-                    side_config(engine, "configs[4]: one full 20x20x20 lattice, self-collision on", engine.VOXCAD, 1, (20, 20, 20), Env(),
-                                local_rank, 2048, full=True, init_time=0.005),
-                    # the resident kernel's largest variant: a real 10^3 population (fill 30-100 %) puts its fuller robots here
-                    side_config(engine, "512 dense 10x10x10 robots (1000 voxels each), self-collision on", engine.VOXCAD, 512, (10, 10, 10), Env(),
-                                local_rank, 512, full=True, init_time=0.01),
-                    mixed_generation(engine, local_rank),
+                    side_workload(engine, "cfg1", local_rank), side_workload(engine, "cfg3", local_rank), side_workload(engine, "cfg4", local_rank),
+                    side_workload(engine, "dense", local_rank), side_workload(engine, "mixed", local_rank),
                 ]
+                for entry in out["other_configs"]:
+                    entry.pop("_voxel_steps_process", None)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(shape)
             os.write(json_fd, (json.dumps(out) + "\n").encode())

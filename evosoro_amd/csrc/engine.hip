@@ -46,6 +46,7 @@ struct Engine::Device {
         int block = 0, nacc = 0, fluid = 0, tabg = 0;   // template arguments of k_robot_steps
         int wide = 0;                     // 1: k_robot_wide<block, fluid, tabg> (kernels_wide.hpp)
         int two_tiles = 0;                // wide kernel: a second pose tile in LDS (two barriers per step instead of three)
+        int pair = 0;                     // 1: k_robot_pair<tabg, sel> (kernels_pair.hpp; block = 512 threads, 1024 voxel slots); 2: its SEL form
         int count = 0;
         const int* list = nullptr;
         size_t lds = 0;                   // dynamic LDS bytes
@@ -481,14 +482,17 @@ void Engine::check_option(const std::string& key, double value) const
 #ifdef VXH_PHASE_TIMING
     if (key == "dbg") return;                 // physics-skipping what-if switches: developer library only
 #endif
-    if (key == "fused" || key == "host_results") return;
+    if (key == "host_results") return;
     if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); return; }
     if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); return; }
-    if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "wide_two_tiles" || key == "col_cap") {
+    if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "wide_two_tiles" || key == "col_cap" || key == "fused" || key == "pair" || key == "pair_sel") {
         // which kernel steps a robot, its tiling and the size of its contact rows are part of the uploaded batch: set before the first
         // vxh_run / vxh_step, or right after vxh_reset (no step taken yet: the batch is then assembled again at the next run)
         if (prepared_ && rounds_done_ > 0) throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or right after vxh_reset)");
-        if ((key == "wide" || key == "wide_two_tiles") && value != 0 && value != 1) throw std::invalid_argument(key + ": 0 or 1");
+        // (`fused` too, since round 5: the resident kernels keep the bond history in their own array and a saved image of the contact rows, so
+        // a robot that changed kernels in the middle of a run would read stale history -- ADVICE round 4)
+        if ((key == "wide" || key == "wide_two_tiles" || key == "fused" || key == "pair_sel") && value != 0 && value != 1) throw std::invalid_argument(key + ": 0 or 1");
+        if (key == "pair" && value != 0 && value != 1 && value != 2) throw std::invalid_argument("pair: 0, 1 or 2");
         if (key == "col_cap" && !(value >= 0 && value <= 1e6)) throw std::invalid_argument("col_cap out of range");
         if (key == "tiled" && value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2");
         if (key == "tile_small" && value != 0 && value != 1) throw std::invalid_argument("tile_small: 0 or 1");
@@ -504,17 +508,20 @@ void Engine::set_option(const std::string& key, double value)
 #ifdef VXH_PHASE_TIMING
     if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; drop_graph(); return; }
 #endif
-    if (key == "fused") { fused_ = value != 0; drop_graph(); }
-    else if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
+    if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
     else if (key == "steps_per_launch") steps_per_launch_ = (int)value;
     else if (key == "graph_steps") { graph_steps_ = (int)value; drop_graph(); }
     else {
         const double now = key == "wide" ? (double)wide_ : key == "wide_two_tiles" ? (double)wide_two_tiles_ : key == "col_cap" ? (double)col_cap_ :
-                           key == "tiled" ? (double)tiled_ : key == "tile_small" ? (double)tile_small_ : (double)tiles_per_robot_;
-        const double want = (key == "wide" || key == "wide_two_tiles" || key == "tile_small") ? (double)(value != 0) : (double)(int)value;
+                           key == "tiled" ? (double)tiled_ : key == "tile_small" ? (double)tile_small_ : key == "fused" ? (double)fused_ :
+                           key == "pair" ? (double)pair_ : key == "pair_sel" ? (double)pair_sel_ : (double)tiles_per_robot_;
+        const double want = (key == "wide" || key == "wide_two_tiles" || key == "tile_small" || key == "fused" || key == "pair_sel") ? (double)(value != 0) : (double)(int)value;
         if (now == want) return;              // (unchanged: the assembled batch stays)
         prepared_ = false;                    // (the batch is assembled again at the next run)
-        if (key == "wide") wide_ = value != 0;
+        if (key == "fused") { fused_ = value != 0; drop_graph(); }
+        else if (key == "pair") pair_ = (int)value;
+        else if (key == "pair_sel") pair_sel_ = value != 0;
+        else if (key == "wide") wide_ = value != 0;
         else if (key == "wide_two_tiles") wide_two_tiles_ = value != 0;
         else if (key == "col_cap") col_cap_ = (int)value;
         else if (key == "tiled") tiled_ = (int)value;
@@ -606,8 +613,14 @@ void Engine::prepare()
     std::vector<short> bclass((size_t)3 * nv, -1);
     // bond schedules of the resident kernel: [3][block] per robot, block = the workgroup size of the robot's size class
     auto resident_block = [](int n) { return n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024)); };
+    // Pair kernel (kernels_pair.hpp): 512 threads, two voxels and up to two bonds per axis per lane -- the large robots without a surface
+    // mesh that the wide kernel does not take.  A function of the robot alone (and of the engine's options), like every kernel choice.
+    auto uses_pair = [&](const RobotModel& M) {
+        return pair_ > 0 && M.nmv == 0 && M.nvox > (pair_ == 2 ? 512 : 768) && M.nvox <= 1024 && M.bond_classes.size() <= 4095 && !wide_listed(M);
+    };
     std::vector<int> sched_off(nr + 1, 0);
-    for (int r = 0; r < nr; ++r) sched_off[r + 1] = sched_off[r] + ((robots_[r].nvox > 0 && robots_[r].nvox <= 1024) ? 3 * resident_block(robots_[r].nvox) : 0);
+    for (int r = 0; r < nr; ++r)
+        sched_off[r + 1] = sched_off[r] + ((robots_[r].nvox > 0 && robots_[r].nvox <= 1024) ? (uses_pair(robots_[r]) ? 6 * VXH_PAIR_T : 3 * resident_block(robots_[r].nvox)) : 0);
     std::vector<int> bsched(std::max(sched_off[nr], 1), -1);
     std::vector<int> wgather((size_t)2 * nv, 0);
     std::vector<float> amp_damp(nv, 1.f);
@@ -740,6 +753,28 @@ void Engine::prepare()
                     const int c = M.bond_class[(size_t)v * 3 + a];
                     if (c >= 0) list[a].push_back((int)((unsigned)v | ((unsigned)M.nbr[(size_t)v * 6 + 2 * a] << 10) | ((unsigned)c << 20)));
                 }
+            if (uses_pair(M)) {
+                // k_robot_pair: [3 axes][2 slots][512 threads].  X and Y are evaluated in ONE barrier-free stretch (four slots per lane), Z
+                // in a second one (two): the 64-bond chunks of X, then of Y, go round the eight wavefronts (wavefront w runs on SIMD w mod 4),
+                // so the four SIMDs carry the same number of chunk executions to within one; Z likewise on its own.
+                int* const sch = &bsched[sched_off[r]];
+                int used_xy[VXH_PAIR_NW][2] = {}, next_wave = 0;      // slots taken per wavefront: [X, Y]
+                for (int a = 0; a < 2; ++a) {
+                    const int nch = ((int)list[a].size() + 63) / 64;
+                    for (int c = 0; c < nch; ++c) {
+                        int w = next_wave;
+                        while (used_xy[w][a] >= 2) w = (w + 1) % VXH_PAIR_NW;          // (at most 16 chunks per axis: a free slot exists)
+                        next_wave = (w + 1) % VXH_PAIR_NW;
+                        int* dst = sch + (2 * a + used_xy[w][a]++) * VXH_PAIR_T + 64 * w;
+                        for (int k = 0; k < 64 && (size_t)(64 * c + k) < list[a].size(); ++k) dst[k] = list[a][(size_t)64 * c + k];
+                    }
+                }
+                const int nchz = ((int)list[2].size() + 63) / 64;
+                for (int c = 0; c < nchz; ++c) {
+                    int* dst = sch + (4 + c / VXH_PAIR_NW) * VXH_PAIR_T + 64 * (c % VXH_PAIR_NW);
+                    for (int k = 0; k < 64 && (size_t)(64 * c + k) < list[2].size(); ++k) dst[k] = list[2][(size_t)64 * c + k];
+                }
+            } else {
             for (size_t j = 0; j < list[0].size(); ++j) sx[j] = list[0][j];
             for (size_t j = 0; j < list[2].size(); ++j) sz[j] = list[2][j];
             if (block == 1024) { for (size_t j = 0; j < list[1].size(); ++j) sy[j] = list[1][j]; }
@@ -757,6 +792,7 @@ void Engine::prepare()
                     has_y[best] = 1; ++simd_load[best % 4]; ++wave_load[best];
                     for (int k = 0; k < 64 && (size_t)(64 * c + k) < list[1].size(); ++k) sy[64 * best + k] = list[1][(size_t)64 * c + k];
                 }
+            }
             }
         }
         R.wl_begin = wl_off[r]; R.wnbond = 0; R.wzidx = 0; R.wregion = 0;
@@ -952,7 +988,7 @@ void Engine::prepare()
     hs.mark("allocations + uploads");
     // Which kernel steps which robot.  Resident kernel (kernels_fused.hpp), one workgroup per robot: its variant is a function
     // of the robot alone (size, fluid, LDS need of its own tables), never of the batch.
-    struct FusedVariant { int block = 0, nacc = 0, fluid = 0, tabg = 0, wide = 0, two_tiles = 0; size_t lds = 0; };
+    struct FusedVariant { int block = 0, nacc = 0, fluid = 0, tabg = 0, wide = 0, two_tiles = 0, pair = 0; size_t lds = 0; };
     auto fused_variant = [&](const RobotModel& M) {
         FusedVariant fv;
         const size_t lds_max = 160 * 1024 - VXH_FUSED_STATIC_LDS;
@@ -981,6 +1017,18 @@ void Engine::prepare()
                 if (fv.two_tiles) fv.lds += tile;
                 return fv;
             }
+        }
+        if (uses_pair(M)) {
+            // pair kernel (mirrors the top of k_robot_pair): pose tile, class tables, one accumulator tile; a colliding robot gets what is
+            // left of the CU's LDS (one workgroup per CU anyway): the mask, the contact-row pool, and -- the whole stretch from the
+            // accumulators on -- the scratch of the broad-phase bit matrix
+            const size_t tabs = (M.bond_classes.size() * sizeof(DBondClass) + M.vox_classes.size() * sizeof(DVoxClass) + 15) & ~(size_t)15;
+            const size_t fixed = (size_t)(8 + 6) * VXH_PAIR_NV * 8;
+            const int ptabg = fixed + tabs + (M.vxa.self_col_enabled ? (size_t)(8 + 12) * 1024 : 0) > lds_max ? 1 : 0;
+            fv.block = VXH_PAIR_T; fv.nacc = 1; fv.fluid = 0; fv.tabg = ptabg; fv.pair = pair_sel_ ? 2 : 1;
+            fv.lds = M.vxa.self_col_enabled ? lds_max : fixed + (ptabg ? 0 : tabs);
+            fv.lds &= ~(size_t)7;
+            return fv;
         }
         const int block = n <= 256 ? 256 : (n <= 512 ? 512 : (n <= 768 ? 768 : 1024));
         const int fluid = M.nmv > 0 ? 1 : 0;      // (the MESH variants: every land_water robot carries the surface mesh)
@@ -1155,8 +1203,8 @@ void Engine::prepare()
             const FusedVariant fv = fused_variant(robots_[r]);
             if (fv.block == 0) continue;                              // streaming kernels
             Device::Group* g = nullptr;
-            for (auto& q : D.groups) if (q.block == fv.block && q.nacc == fv.nacc && q.fluid == fv.fluid && q.tabg == fv.tabg && q.wide == fv.wide && q.two_tiles == fv.two_tiles) g = &q;
-            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = fv.block; g->nacc = fv.nacc; g->fluid = fv.fluid; g->tabg = fv.tabg; g->wide = fv.wide; g->two_tiles = fv.two_tiles; }
+            for (auto& q : D.groups) if (q.block == fv.block && q.nacc == fv.nacc && q.fluid == fv.fluid && q.tabg == fv.tabg && q.wide == fv.wide && q.two_tiles == fv.two_tiles && q.pair == fv.pair) g = &q;
+            if (!g) { D.groups.emplace_back(); g = &D.groups.back(); g->block = fv.block; g->nacc = fv.nacc; g->fluid = fv.fluid; g->tabg = fv.tabg; g->wide = fv.wide; g->two_tiles = fv.two_tiles; g->pair = fv.pair; }
             g->robots.push_back(r);
             g->lds = std::max(g->lds, fv.lds);
         }
@@ -1270,8 +1318,21 @@ static void launch_wide(const DBatch& B, const int* list, int count, size_t lds,
     hipLaunchKernelGGL((k_robot_wide<BLOCK, MESH, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8), two_tiles);
 }
 
-static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool wide, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles = 0)
+template <bool TABG, bool SEL>
+static void launch_pair(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
 {
+    static size_t granted[64] = {};
+    grant_dynamic_lds((const void*)k_robot_pair<TABG, SEL>, granted, lds);
+    hipLaunchKernelGGL((k_robot_pair<TABG, SEL>), dim3(count), dim3(VXH_PAIR_T), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
+}
+
+static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool wide, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles = 0, int pair = 0)
+{
+    if (pair) {
+        if (pair == 2) { if (tabg) launch_pair<true, true>(B, list, count, lds, s, cap, iters); else launch_pair<false, true>(B, list, count, lds, s, cap, iters); }
+        else { if (tabg) launch_pair<true, false>(B, list, count, lds, s, cap, iters); else launch_pair<false, false>(B, list, count, lds, s, cap, iters); }
+        return;
+    }
     if (wide) {
         if (fluid) { if (tabg) launch_wide<512, true, true>(B, list, count, lds, s, cap, iters, two_tiles); else launch_wide<512, true, false>(B, list, count, lds, s, cap, iters, two_tiles); }
         else { if (tabg) launch_wide<512, false, true>(B, list, count, lds, s, cap, iters, two_tiles); else launch_wide<512, false, false>(B, list, count, lds, s, cap, iters, two_tiles); }
@@ -1354,7 +1415,7 @@ void Engine::advance_launch(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters) {
             for (size_t k = 0; k < D.groups.size(); ++k) {
                 const auto& g = D.groups[k];
-                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.wide != 0, g.list, g.count, g.lds, single ? D.stream : g.stream, cap, iters, g.two_tiles);
+                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.wide != 0, g.list, g.count, g.lds, single ? D.stream : g.stream, cap, iters, g.two_tiles, g.pair);
                 ++launches; ++group_launches[k];
             }
         }
@@ -1485,7 +1546,8 @@ void Engine::advance_finish()
         } else {
             float cms = 0;
             if (D.pending.single) cms = ms; else HIP_OK(hipEventElapsedTime(&cms, D.groups[best].t0, D.groups[best].t1));
-            counters_.dominant_block = D.groups[best].block + (D.groups[best].wide ? 1 : 0); counters_.dominant_robots = D.groups[best].count;
+            // (the resident kernel's workgroup size; + 1: the wide kernel; 1026: the pair kernel -- 512 threads, 1024 voxel slots)
+            counters_.dominant_block = D.groups[best].pair ? VXH_PAIR_NV + 2 : D.groups[best].block + (D.groups[best].wide ? 1 : 0); counters_.dominant_robots = D.groups[best].count;
             counters_.dominant_launches = group_launches[best]; counters_.dominant_seconds = cms * 1e-3;
             counters_.dominant_alg_bytes = grp_ab[best]; counters_.dominant_voxel_steps = grp_vs[best];
         }

@@ -104,6 +104,11 @@ private:
     int inject_tile_timeout_ = std::getenv("VXH_INJECT_TILE_TIMEOUT") ? std::max(1, std::atoi(std::getenv("VXH_INJECT_TILE_TIMEOUT"))) : 0;
     bool wide_two_tiles_ = true;               // ... with a second pose tile in LDS where it fits (two barriers per step instead of three); 0: cross-checks
     bool wide_ = true;                         // small robots (up to 512 voxels, 1023 bonds) go to the wide kernel (kernels_wide.hpp); 0: resident kernel
+    // k_robot_pair (kernels_pair.hpp: 512 threads, two voxels and up to two bonds per axis per lane) instead of k_robot_steps<1024> for robots of
+    // 769-1024 voxels without a surface mesh (1), also instead of <768> for those of 513-768 (2).  OFF by default: bit-identical to <1024>, but
+    // measured 20-30 % slower (round 5, DESIGN.md section 4 "Pair path": two wavefronts per SIMD do not hide the latency of a dependent FP64 chain)
+    int pair_ = 0;
+    bool pair_sel_ = false;                    // ... with the rotation-vector factor in select form (kernels.hpp rotvec_factor<SEL>; A/B switch)
     int col_cap_ = 0;                          // partners a contact row can hold; 0 = every other surface voxel (unbounded, like the reference)
     bool tile_small_ = false;                  // also tile large robots the resident kernel could take when the population is small (see prepare())
     unsigned tile_gen_ = 0;                    // launch generation of the tiled kernel (high half of the tiles' flag words)

@@ -1226,5 +1226,6 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
 }  // namespace vxh
 
 #include "kernels_fused.hpp"
+#include "kernels_pair.hpp"
 #include "kernels_wide.hpp"
 #include "kernels_tiled.hpp"

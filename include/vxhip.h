@@ -96,7 +96,7 @@ typedef struct vxh_counters {
     long long max_steps;       /* largest per-robot step count */
     /* the dominant kernel of the last vxh_run/vxh_step call (the size class holding most voxels on the fused path,
      * k_bonds on the streaming path): what bench.py prices against the HBM roofline */
-    int dominant_block;             /* workgroup size of k_robot_steps<BLOCK>, 0 = streaming path */
+    int dominant_block;             /* workgroup size of k_robot_steps<BLOCK>; + 1: k_robot_wide; 1026: k_robot_pair; 1 = k_tile_steps; 0 = streaming path */
     int dominant_robots;
     long long dominant_launches;
     double dominant_seconds;        /* HIP-event time from its first to its last launch on its own stream */
@@ -216,14 +216,18 @@ int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long 
  *                       the reference's lists (CVX_Sim::CreateColBond has no cap); memory: 12-16 bytes x nsurf^2 per colliding robot
  *                       (5 MB for a 10x10x10 robot), touched only as far as rows really grow.  n > 0 bounds the rows at n partners
  *                       (less memory); a robot one of whose rows would need more ends with VXH_ROBOT_COL_OVERFLOW.
- *                       These six belong to the uploaded batch: set them before the first vxh_run / vxh_step or right after
- *                       vxh_reset (VXH_ERR_STATE once a step has been taken).  The tiles of a robot wait for each other on the
+ *   "pair"              1 = robots of 769-1024 voxels without a surface mesh are stepped by k_robot_pair (512 threads, two voxels and up to
+ *                       two bonds per axis per lane; same bits as k_robot_steps<1024>), 2 = also those of 513-768; 0 (default): measured
+ *                       20-30 % slower than the kernels it replaces (DESIGN.md "Pair path").  "pair_sel": its rotation-vector form (A/B).
+ *   "fused"             0 = robots the tiled kernel does not take go through the streaming kernels (cross-checks)
+ *                       These (tiled .. fused) belong to the uploaded batch: set them before the first vxh_run / vxh_step or right
+ *                       after vxh_reset (VXH_ERR_STATE once a step has been taken: a robot that changed kernels in the middle of a run
+ *                       would read another kernel's bond history).  The tiles of a robot wait for each other on the
  *                       device: an engine that tiles must own its GPU (with another process on the same GPU set "tiled" to 0).
  *   "steps_per_launch"  time steps per launch of the resident / tiled kernels (default 1024).  A launch of a self-colliding population
  *                       carries ~0.07 ms of fixed cost (0.27 until round 3), and a call ~0.04 ms on the host, so vxh_step(e, n) with a
  *                       small n is paid for: 20 steps at a time run at ~35 us per step where 1000 at a time run at ~30.5 (512 robots
  *                       of 10x10x10).
- *   "fused"             0 = robots the tiled kernel does not take go through the streaming kernels (cross-checks)
  *   "graph_steps"       streaming kernels: step rounds per captured hipGraph (0 = plain launches)
  *   "host_results"      1 = vxh_get_result evaluates every tag on the host from the downloaded voxel state instead of from the
  *                       device-side reductions (cross-checks; the numbers are the same) */

@@ -975,3 +975,60 @@ if __name__ == "__main__" and "smallcfgs" in sys.argv[1:]:
         timing_cfg(engine.VOXCAD, 64, (6, 6, 6), 0.1, Env(), {})
         timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, {}, per_voxel_phase=True)
         timing_cfg(engine.VOXCAD, 512, (8, 8, 8), 0.04, Env(), {})
+
+
+def _pair_population(kind, count):
+    """robots for the pair-kernel A/B: 'dense' = full 10^3 lattices, 'p15' = random 10^3 with P(empty) 0.15 (769-1000 voxels mostly), 'bench' = the bench population"""
+    if kind == "dense":
+        return [workloads.make_individual(i, workloads.full_material(10, 1 + i)) for i in range(count)]
+    if kind == "p15":
+        return [workloads.random_robot(i, (10, 10, 10), 5000 + i, p_empty=0.15) for i in range(count)]
+    return workloads.population(count, (10, 10, 10))
+
+
+if __name__ == "__main__" and "pairab" in sys.argv[1:]:
+    # round 5: k_robot_pair (512 threads, two voxels per lane) against k_robot_steps<1024> / <768>, same library, option `pair`
+    #   pairab check   states after 40 / 400 / 1200 steps of 24 robots per population kind with pair = 0 and pair = 1 (2 for the bench kind)
+    #   pairab time    us per population step of 512 robots, launches of 250 steps past a 600-step pre-advance, each option twice
+    sel = 1 if "sel" in sys.argv[1:] else 0
+    if "check" in sys.argv[1:]:
+        for kind in ("dense", "p15", "bench"):
+            tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+            sim = Sim(self_collisions_enabled=True, dt_frac=0.9, simulation_time=2.0, fitness_eval_init_time=0.02)
+            paths = []
+            for ind in _pair_population(kind, 24):
+                write_voxelyze_file(sim, Env(), ind, tmp, "p"); paths.append(os.path.join(tmp, "voxelyzeFiles", "p--id_%05i.vxa" % ind.id))
+            runs = {}
+            for pair in (0, 2 if kind == "bench" else 1):
+                with engine.Engine(engine.VOXCAD, 0) as eng:
+                    eng.set_option("tiled", 0); eng.set_option("pair", pair); eng.set_option("pair_sel", sel)
+                    eng.add_vxa_files(paths)
+                    out, done = [], 0
+                    for upto in (40, 400, 1200):
+                        eng.step(upto - done); done = upto
+                        out.append([eng.state(i) for i in range(len(paths))])
+                    runs[pair] = (out, eng.counters().dominant_block, [eng.result(i).col_rebuilds for i in range(len(paths))])
+            (a, ka, ra), (b, kb, rb) = runs[0], runs[2 if kind == "bench" else 1]
+            for k, upto in enumerate((40, 400, 1200)):
+                err = max(np.abs(x[:, :3] - y[:, :3]).max() for x, y in zip(a[k], b[k])) / 0.01
+                same = sum(bool(np.array_equal(x, y)) for x, y in zip(a[k], b[k]))
+                print("pairab check %-5s step %4d: kernels %d vs %d, max |dpos| %.3e voxel, %d of %d robots bit-identical, rebuilds equal %s" % (
+                    kind, upto, ka, kb, err, same, len(paths), ra == rb), flush=True)
+    if "time" in sys.argv[1:]:
+        kinds = [k for k in ("dense", "p15", "bench") if k in sys.argv[1:]] or ["dense", "p15", "bench"]
+        for kind in kinds:
+            tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+            sim = Sim(self_collisions_enabled=True, dt_frac=0.9, simulation_time=2.0, fitness_eval_init_time=0.3)
+            paths, nvox = [], 0
+            for ind in _pair_population(kind, 512):
+                write_voxelyze_file(sim, Env(), ind, tmp, "p"); paths.append(os.path.join(tmp, "voxelyzeFiles", "p--id_%05i.vxa" % ind.id))
+            for rep in range(2):
+                for pair in ((0, 2) if kind == "bench" else (0, 1)):
+                    with engine.Engine(engine.VOXCAD, 0) as eng:
+                        eng.set_option("tiled", 0); eng.set_option("pair", pair); eng.set_option("pair_sel", sel); eng.set_option("steps_per_launch", 250)
+                        eng.add_vxa_files(paths)
+                        eng.step(600)
+                        c0 = eng.counters(); eng.step(1000); c1 = eng.counters()
+                        print("pairab time %-5s pair=%d sel=%d: %.2f us per population step (kernel %d, %.3e voxel-steps/s)" % (
+                            kind, pair, sel, 1e3 * (c1.kernel_seconds - c0.kernel_seconds), c1.dominant_block,
+                            (c1.voxel_steps - c0.voxel_steps) / (c1.kernel_seconds - c0.kernel_seconds)), flush=True)

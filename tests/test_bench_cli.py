@@ -33,7 +33,14 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_on_the_stub():
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak"
     assert out["config"]["robots_per_gpu"] == 3 and out["value"] > 0
     assert out["strong"]["scaling"] == "strong" and out["strong"]["value"] > 0
+    assert out["strong"]["tile_small"]["value"] > 0                      # (the strong case twice: default kernels and tile_small)
     assert out["multi_handle"]["robots"] == 6 and out["multi_handle"]["value"] > 0
+    # the line proves that two ranks took part: gathered over the default group, one row per rank
+    assert out["ranks"]["world"] == 2 and out["ranks"]["backend"] == "gloo"
+    assert len(out["ranks"]["device_of_rank"]) == 2 and len(out["ranks"]["ms_per_step_of_rank"]) == 2
+    assert all(ms > 0 for ms in out["ranks"]["ms_per_step_of_rank"])
+    # both clocks: `value` from the engine's event time, the host clock beside it (never faster than the device time it contains)
+    assert out["host_clock"]["ms_per_step"] >= out["ms_per_step"] * 0.999 and out["host_clock"]["value"] > 0
 
 
 def test_no_default_group_collective_overlaps_a_timed_region(tmp_path):

@@ -173,8 +173,8 @@ def test_options_changed_between_runs_of_one_engine(eng_mod, golden_dir):
     paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in ("probe6", "rand6_col")]
 
     def run(eng, fused):
+        eng.reset()                         # (which kernel steps a robot is part of the assembled batch: set right after a reset)
         eng.set_option("fused", fused)
-        eng.reset()
         eng.step(400)                       # > graph_steps: the streaming path replays its captured graph
         return [eng.state(i) for i in range(len(paths))]
 
@@ -1131,3 +1131,45 @@ def test_the_second_pose_tile_of_the_wide_kernel_changes_no_bit(eng_mod, golden_
             assert np.array_equal(runs[0][1][i], runs[1][1][i]), n
             a, b = runs[0][2][i], runs[1][2][i]
             assert all(a[k] == b[k] for k in a if k != "reserved"), n
+
+
+def test_pair_kernel_steps_like_the_resident_kernels(eng_mod, tmp_path, kernel_path):
+    """k_robot_pair (option pair: 512 threads, two voxels and up to two bonds per axis per lane; off by default since it measured slower)
+    adds the bond forces in the order of k_robot_steps<1024> -- +X and -X, then +Y, -Y, +Z, -Z -- so a robot of 769-1024 voxels must
+    come out BIT FOR BIT as that kernel steps it, self-collision, broad-phase runs and the IniCM latch included; a robot of 513-768
+    voxels (pair = 2) within the 1e-12 voxel the kernels of different summation order agree to.  Also against the oracle."""
+    if kernel_path != "auto":
+        pytest.skip("the test sets the kernel options itself")
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    from oracle import vxoracle as vo
+    sim, env = Sim(dt_frac=0.9, simulation_time=0.05, fitness_eval_init_time=0.004), Env()
+    mats = [workloads.full_material(10, 2), workloads.random_material((10, 10, 10), 5001, p_empty=0.15),
+            np.pad(workloads.full_material(10, 3), ((0, 0), (0, 0), (0, 1)), constant_values=0),          # (a lattice one layer short of a second size class)
+            workloads.random_material((10, 10, 10), 5)]
+    mats[2][:5, :5, 10] = 1
+    mats[2][0, 0, 10] = 0                                    # 1024 voxels exactly
+    paths = [_write_robot(tmp_path, k, m, sim, env, "pr") for k, m in enumerate(mats)]
+    runs = {}
+    for pair in (0, 2):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 0)
+            eng.set_option("pair", pair)
+            for p in paths:
+                eng.add_vxa_file(p)
+            assert [eng.dims(i)["nvox"] for i in range(4)][2] == 1024
+            out = []
+            for n in (120, 180):                            # (past InitCmTime; two launches: the saved image of the contact rows is read back)
+                eng.step(n)
+                out.append([eng.state(i) for i in range(4)])
+            runs[pair] = (out, [eng.result(i).col_rebuilds for i in range(4)], [eng.result(i).as_dict() for i in range(4)])
+    for k in range(2):
+        for i in range(3):
+            assert np.array_equal(runs[0][0][k][i], runs[2][0][k][i]), (k, i)
+        assert np.abs(runs[0][0][k][3][:, :3] - runs[2][0][k][3][:, :3]).max() / 0.01 < 1e-12
+    assert runs[0][1] == runs[2][1] and min(runs[0][1]) >= 1
+    for i in range(3):
+        assert runs[0][2][i] == runs[2][2][i]               # every result field, IniCM included
+    sim_o = vo.OracleSim.from_vxa(paths[1])
+    sim_o.step(300)
+    assert _pos_err(runs[2][0][1][1], sim_o.state(), 0.01) < FLOOR_VOX
