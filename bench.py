@@ -204,24 +204,35 @@ def measured_compute(kernel):
 
 
 def measured_parity():
-    """The other half of BASELINE's metric ("CoM-displacement err vs CPU"): the newest committed parity ledger
-    (tests/test_gpu_ledger.py -> profiles/r*_parity_auto.json): every golden case run to its stop condition on the engine, error of the
-    final centre of mass against the reference binary's, in voxels.  A record of the last GPU test run, not of this bench run."""
+    """The other half of BASELINE's metric ("CoM-displacement err vs CPU"): the newest committed parity ledgers
+    (tests/test_gpu_ledger.py -> profiles/r*_parity_{auto,narrow,tiles3}.json, one per kernel path): every golden case run to its stop
+    condition on the engine, error of the final centre of mass against the reference binary's, in voxels.  A record of the last GPU
+    test run, not of this bench run."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_parity_auto.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        led = json.load(f)
-    rows = led.get("rows", [])
-    strict_rows = [r for r in rows if r.get("strict_1e-9")]
-    return {"cases": led.get("cases"), "strict_1e-9": led.get("strict_1e-9"), "within_1e-12": led.get("within_1e-12"),
-            "within_tolerance": led.get("within_tolerance"),
-            "worst_err_vox": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in rows] or [None]),
-            "worst_err_vox_of_the_strict_cases": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in strict_rows] or [None]),
-            "bench_robot_err_vox": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in rows if r["case"].startswith("bench10")] or [None]),
-            "quantity": "max over x, y, z of |final centre of mass - reference binary's| (and IniCM) after the whole evaluation, voxels",
-            "source": os.path.relpath(files[-1], REPO), "live": False}
+    out = None
+    for path_name in ("auto", "narrow", "tiles3"):
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_parity_%s.json" % path_name)))
+        if not files:
+            continue
+        with open(files[-1]) as f:
+            led = json.load(f)
+        rows = led.get("rows", [])
+        strict_rows = [r for r in rows if r.get("strict_1e-9")]
+        worst_row = max(rows, key=lambda r: max(r["err_cur_cm_vox"], r["err_ini_cm_vox"])) if rows else None
+        entry = {"cases": led.get("cases"), "strict_1e-9": led.get("strict_1e-9"), "within_1e-12": led.get("within_1e-12"),
+                 "within_tolerance": led.get("within_tolerance"),
+                 "worst_err_vox": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in rows] or [None]),
+                 "worst_case": worst_row["case"] if worst_row else None,
+                 "worst_err_vox_of_the_strict_cases": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in strict_rows] or [None]),
+                 "bench_robot_err_vox": max([max(r["err_cur_cm_vox"], r["err_ini_cm_vox"]) for r in rows if r["case"].startswith("bench10")] or [None]),
+                 "source": os.path.relpath(files[-1], REPO)}
+        if out is None:
+            out = dict(entry)
+            out["quantity"] = "max over x, y, z of |final centre of mass - reference binary's| (and IniCM) after the whole evaluation, voxels"
+            out["live"] = False
+            out["kernel_paths"] = {}
+        out["kernel_paths"][path_name] = entry
+    return out
 
 
 FP64_PEAK_FLOPS = 78.6e12      # vector FP64: one FP64 wave-instruction per 4 cycles and SIMD at 2.4 GHz (half the FP32 vector peak of MI355X_MICROARCH.md)

@@ -1032,3 +1032,45 @@ if __name__ == "__main__" and "pairab" in sys.argv[1:]:
                         print("pairab time %-5s pair=%d sel=%d: %.2f us per population step (kernel %d, %.3e voxel-steps/s)" % (
                             kind, pair, sel, 1e3 * (c1.kernel_seconds - c0.kernel_seconds), c1.dominant_block,
                             (c1.voxel_steps - c0.voxel_steps) / (c1.kernel_seconds - c0.kernel_seconds)), flush=True)
+
+
+if __name__ == "__main__" and "onestep" in sys.argv[1:]:
+    # round 5: which voxel differs, and by how much, on the steps where ONE step of engine and oracle from the same state differ by more than
+    # 5e-14 voxel (tests/test_gpu_parity.py test_one_step_from_the_same_state): onestep <golden case> <variant 0/1> [steps]
+    name, variant = sys.argv[2], int(sys.argv[3])
+    nsteps = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+    path = os.path.join(G, "vxa", name + ".vxa")
+    model = vo.parse_vxa(path, variant)
+    lat = model["lattice_dim"]
+    sim = vo.OracleSim(model)
+    twin = vo.OracleSim(model)          # the oracle once more, its inputs moved by one ulp before every step: the reference algorithm's OWN one-step noise
+    with engine.Engine(variant, 0) as eng:
+        eng.add_vxa_file(path)
+        prev = sim.state()
+        for step in range(1, nsteps + 1):
+            eng.step(1)
+            got = eng.state(0)
+            sim.set_state(prev)
+            sim.step(1)
+            want = sim.state()
+            twin.set_state(prev)
+            twin.step_jittered(1, seed=step)
+            own = np.abs(twin.state() - want)
+            d = np.abs(got - want)
+            dp = d[:, :3].max() / lat
+            if dp > 5e-14 or own[:, :3].max() / lat > 5e-14:
+                print("step %d: engine - oracle %.3e voxel; oracle(one-ulp jitter) - oracle %.3e voxel (at voxel %d)" % (
+                    step, dp, own[:, :3].max() / lat, int(np.argmax(own[:, :3].max(axis=1)))), flush=True)
+            modes = sim.bond_modes()
+            large_e, total_e = eng.bond_modes()
+            if step <= 40:
+                print("step %d: large-angle bonds engine %d oracle %d of %d%s" % (step, large_e, int((modes == 0).sum()), total_e,
+                      "" if step == 1 else "  oracle flips this step: %s" % np.nonzero(modes != last_modes)[0].tolist()), flush=True)
+            last_modes = modes.copy()
+            if dp > 5e-14:
+                v = int(np.argmax(d[:, :3].max(axis=1)))
+                print("step %d: dpos %.3e voxel at voxel %d (axis %d); its z/lat %.6f, scale/lat %.6f, |vel xy| %.3e, vel z %.3e; quat diff %.2e; voxels over the bar: %d" % (
+                    step, dp, v, int(np.argmax(d[v, :3])), prev[v, 2] / lat, prev[v, 7] / lat, float(np.hypot(prev[v, 8], prev[v, 9])), prev[v, 10],
+                    d[v, 3:7].max(), int((d[:, :3].max(axis=1) / lat > 5e-14).sum())), flush=True)
+                print("   got  pos %s vel %s\n   want pos %s vel %s" % (got[v, :3], got[v, 8:11], want[v, :3], want[v, 8:11]), flush=True)
+            prev = got

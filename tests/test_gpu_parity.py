@@ -1063,25 +1063,31 @@ def test_collision_rows_longer_than_64_partners(eng_mod, tmp_path):
     assert np.array_equal(states[0][1], states[64][1])                    # the neighbour in the batch: the same bits either way
 
 
-def test_one_step_from_the_same_state(eng_mod, golden_dir):
+def test_one_step_from_the_same_state(eng_mod, golden_dir, manifest, kernel_path):
     """What ONE step of the engine and of the oracle differ by when both start from the same state (the oracle is put on the engine's
     state before every step: oracle instrument vxo_set_state).  Differences of earlier steps cannot hide or feed anything here, so the
     bar can sit at the rounding level: 5e-14 voxel and 2e-11 of the largest velocity / angular velocity, step after step (measured
     2e-15 voxel, 3e-13, 1e-12; one-ulp noise on the oracle's own inputs gives 3e-15, 4e-13, 1.4e-12).  Round 3's systematic creep
     was a formula difference of 1.2e-12 voxel per step in exactly this number (kernels.hpp RotInv) that 7806-step trajectories within
-    1e-10 voxel had not shown."""
+    1e-10 voxel had not shown.
+    Round 5: EVERY case of the parity ledger (tests/golden/manifest.json, 31 robots: all BASELINE configs at full size, both simulators,
+    the 1000-voxel lattice of the 1024-thread variant, the shipped .vxa files), on each of the three kernel paths -- so that the
+    ill-conditioned robots (phase4 / trace4: whole runs only held to 20 x their own spread, 0.06 voxel) are pinned at the rounding level
+    per step like everything else.  300 steps each (the whole run where it is shorter; phase4's whole 742)."""
     from oracle import vxoracle as vo
-    for name, variant, nsteps in (("lw_hexapus", 1, 400), ("bench10_0", 0, 400), ("lw_swim6", 1, 300), ("grow5", 0, 400), ("rand6_col", 0, 400), ("lw_stiff5", 1, 300),
-                                  ("cfg1_00", 0, 300), ("cfg3_00", 1, 300),       # (robots of BASELINE configs[1] and [3] at their full size)
-                                  ("phase4", 0, 742)):      # the chaotic robot, its whole run: whole trajectories of it are only held to 20 x its own spread (0.06 voxel); one step from the same state is not chaotic
+    longer = {"phase4": 742, "trace4": 742, "lw_hexapus": 400, "bench10_0": 400}
+    report = []
+    for name, entry in manifest.items():
+        variant = 1 if entry["variant"] == "lw" else 0
         path = os.path.join(golden_dir, "vxa", name + ".vxa")
         model = vo.parse_vxa(path, variant)
         lat = model["lattice_dim"]
-        sim = vo.OracleSim(model)
+        sim, twin = vo.OracleSim(model), vo.OracleSim(model)
         worst = [0.0, 0.0, 0.0]
-        flips = 0
+        flips = taken = noisy = 0
         with eng_mod.Engine(variant, 0) as eng:
             eng.add_vxa_file(path)
+            nsteps = min(longer.get(name, 300), eng.dims(0)["planned_steps"])
             prev = sim.state()
             for step in range(1, nsteps + 1):
                 eng.step(1)
@@ -1089,19 +1095,40 @@ def test_one_step_from_the_same_state(eng_mod, golden_dir):
                 sim.set_state(prev)
                 sim.step(1)
                 want = sim.state()
+                # the reference algorithm's OWN one-step noise: the same step from the same state with every position and quaternion
+                # component moved by one ulp.  Mostly 3e-15 voxel -- but at the ONSET of a bond's rotation (relative rotations of 1e-8 ..
+                # 1e-5 rad, e.g. when the compression wave of a landing robot reaches the bond) ToRotationVector's 1 - w * w
+                # (Vec3D.h:270-285) is a difference of numbers an ulp apart, and the reference's step moves by up to 3e-9 voxel under
+                # that noise (found by this test on the reference's own example_phaseoffset.vxa, steps 8-29; scripts/dev_gpu_diag.py
+                # onestep).  Such steps are held to 4 x that noise instead of to 5e-14.
+                twin.set_state(prev)
+                twin.step_jittered(1, seed=step)
+                own = np.abs(twin.state() - want)
+                own_p = own[:, :3].max() / lat
+                own_v = own[:, 8:11].max() / max(1e-300, np.abs(want[:, 8:11]).max())
+                own_w = own[:, 11:14].max() / max(1e-300, np.abs(want[:, 11:14]).max())
                 d = np.abs(got - want)
                 dp = d[:, :3].max() / lat
                 dv = d[:, 8:11].max() / max(1e-300, np.abs(want[:, 8:11]).max())
                 dw = d[:, 11:14].max() / max(1e-300, np.abs(want[:, 11:14]).max())
-                if dp > 5e-14:          # a bond whose small- / large-angle test sits within an ulp of its threshold may flip on one side only
+                if own_p > 1e-14:
+                    noisy += 1
+                    assert dp <= max(5e-14, 4 * own_p) and dv <= max(2e-11, 4 * own_v) and dw <= max(2e-11, 4 * own_w), (name, step, dp, own_p, dv, own_v, dw, own_w)
+                elif dp > 5e-14:        # a bond whose small- / large-angle test sits within an ulp of its threshold may flip on one side only
                     flips += 1
                 else:
                     worst = [max(worst[0], dp), max(worst[1], dv), max(worst[2], dw)]
                 prev = got
-        print("%s: one step from the same state, worst over %d steps: %.1e voxel, velocity %.1e, angular velocity %.1e; steps set aside: %d" % (
-            name, nsteps, worst[0], worst[1], worst[2], flips))
+                taken += 1
+            kernel = eng.counters().dominant_block
+        report.append((name, taken, kernel, worst, flips))
+        print("%s [%s, kernel %d]: one step from the same state, worst over %d steps: %.1e voxel, velocity %.1e, angular velocity %.1e; steps set aside: %d; "
+              "steps on which the reference's own one-ulp noise exceeds 1e-14 voxel (held to 4 x it): %d" % (
+                  name, kernel_path, kernel, taken, worst[0], worst[1], worst[2], flips, noisy))
+        assert taken >= min(10, nsteps), (name, taken)
         assert flips <= 2, (name, flips)
         assert worst[1] <= 2e-11 and worst[2] <= 2e-11, (name, worst)
+    assert len(report) >= 31
 
 
 def test_the_second_pose_tile_of_the_wide_kernel_changes_no_bit(eng_mod, golden_dir):
