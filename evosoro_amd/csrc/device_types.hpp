@@ -100,7 +100,7 @@ enum { VXH_TILE_BLOCK = 256,          // worker threads of a tile's workgroup = 
        VXH_TILE_CH = 128,             // chunk of the whole-robot passes (latch, broad-phase) staged through LDS
        VXH_TILE_STATIC_LDS = 1024 };   // upper bound of the kernel's static __shared__ variables
 struct TileLayout { int np, no, nbp, o_ps, o_pl, o_hl, o_pht, o_sl, o_sc, o_px, o_rc, o_tab, o_int, total; };
-VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doubles)
+VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doubles, bool mesh)
 {
     TileLayout L;
     L.np = (n_own + n_halo + 1) & ~1; L.no = (n_own + 1) & ~1; L.nbp = (nb + 1) & ~1;
@@ -108,8 +108,8 @@ VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doub
     L.o_pl = L.o_ps + 8 * L.np;
     L.o_hl = L.o_pl + 36 * L.no;
     L.o_pht = L.o_hl + 6 * L.nbp;
-    L.o_sl = L.o_pht + 2 * L.no;          // [6][no] directional strains of the owned voxels (land_water robots: RobotVolume tags)
-    L.o_sc = L.o_sl + 6 * L.no;
+    L.o_sl = L.o_pht + 2 * L.no;          // [6][no] directional strains of the owned voxels (land_water robots only -- `mesh`: RobotVolume tags)
+    L.o_sc = L.o_sl + (mesh ? 6 * L.no : 0);
     L.o_px = L.o_sc + 5 * VXH_TILE_CH + VXH_TILE_CH / 2;
     L.o_rc = L.o_px + 4 * VXH_TILE_XH;
     L.o_tab = L.o_rc + VXH_TILE_ROWPOOL;

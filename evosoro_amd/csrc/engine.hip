@@ -666,11 +666,14 @@ void Engine::prepare()
     if (col_cap_ <= 0) {
         double want = 0, rows = 0;
         for (int r = 0; r < nr; ++r) if (robots_[r].vxa.self_col_enabled) { want += 16.0 * (double)robots_[r].nsurf * (double)std::max(1, robots_[r].nsurf - 1); rows += robots_[r].nsurf; }
+        // (the budget is a third of the device's TOTAL memory, not of what happens to be free: how long a row can grow -- and with it whether a
+        // robot ends FINISHED or COL_OVERFLOW -- must not depend on what other processes hold on the GPU at this moment; if the rows then do
+        // not fit what IS free, the allocation fails with an error instead of changing outcomes silently.  ADVICE round 4)
         size_t free_b = 0, total_b = 0;
-        if (want > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > (double)free_b / 3.0) {
-            row_limit = std::max<long long>(64, (long long)((double)free_b / 3.0 / 16.0 / std::max(1.0, rows)));
-            std::fprintf(stderr, "vxhip: the contact rows of this batch would take %.1f GB uncapped (device memory free: %.1f GB); rows are cut to %lld partners "
-                                 "(option col_cap sets the length; a robot whose row overflows ends with status COL_OVERFLOW)\n", want / 1e9, (double)free_b / 1e9, row_limit);
+        if (want > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > (double)total_b / 3.0) {
+            row_limit = std::max<long long>(64, (long long)((double)total_b / 3.0 / 16.0 / std::max(1.0, rows)));
+            std::fprintf(stderr, "vxhip: the contact rows of this batch would take %.1f GB uncapped (device memory: %.1f GB); rows are cut to %lld partners "
+                                 "(option col_cap sets the length; a robot whose row overflows ends with status COL_OVERFLOW)\n", want / 1e9, (double)total_b / 1e9, row_limit);
         }
     }
     for (int r = 0; r < nr; ++r) {
@@ -1118,7 +1121,7 @@ void Engine::prepare()
                 TilePlan P = plan_tiles(M, k);
                 size_t lds = 0;
                 for (const auto& t : P.tiles)
-                    lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles).total * 8);
+                    lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles, M.nmv > 0).total * 8);
                 if (P.k > VXH_TILE_MAX_TILES) break;                  // (left to the other kernels)
                 if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds, M.nmv > 0 ? 1 : 0}); break; }
                 if (k >= M.nvox / 8) break;                           // cannot be tiled: left to the other kernels

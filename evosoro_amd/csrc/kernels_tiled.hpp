@@ -337,7 +337,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     (void)nv;
     const int n_own = T.n_own, n_halo = T.n_halo, nb = T.nb, k_tiles = T.ntiles;
     const int nbd = TABG ? 0 : R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = TABG ? 0 : R.n_vclass * (int)(sizeof(DVoxClass) / 8);
-    const TileLayout L = tile_layout(n_own, n_halo, nb, nbd + nvd);
+    const TileLayout L = tile_layout(n_own, n_halo, nb, nbd + nvd, MESH);
     const int np = L.np, no = L.no, nbp = L.nbp;
     double* const ps = lds + L.o_ps;          // [8][np] pose tile: owned voxels, then halo voxels
     double* const pl = lds + L.o_pl;          // [6 directions][6][no] bond force / minus bond moment on every owned voxel

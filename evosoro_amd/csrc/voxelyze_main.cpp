@@ -45,6 +45,7 @@
 #include <signal.h>
 #include <sys/file.h>
 #include <sys/socket.h>
+#include <sys/types.h>
 #include <sys/stat.h>
 #include <sys/un.h>
 #include <sys/wait.h>
@@ -56,10 +57,47 @@ namespace {
 
 double env_num(const char* name, double dflt) { const char* v = std::getenv(name); return (v && *v) ? std::atof(v) : dflt; }
 
+// Where a broker listens.  The directory is the user's own -- $XDG_RUNTIME_DIR, else /tmp/vxhip-<uid> created 0700 and checked (owner, mode, not a
+// symlink): nobody else can pre-bind the name or read who connects.  The NAME carries everything a broker's answers depend on, so a
+// client is only ever served by a broker that would compute what the client itself would: the executable (path, size, mtime: a rebuilt
+// binary gets a fresh broker while an old one drains), the device selection (HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES, VXH_BROKER_DEVICES: two
+// experiments pinned to different GPUs get one broker each) and VXH_ENGINE_OPTIONS.  (Round 4 keyed it by uid alone: ADVICE.)
 std::string socket_path()
 {
     if (const char* p = std::getenv("VXH_BROKER_SOCKET")) if (*p) return p;
-    return "/tmp/vxhip-broker-" + std::to_string((long)getuid()) + ".sock";
+    std::string dir;
+    if (const char* x = std::getenv("XDG_RUNTIME_DIR")) { struct stat st; if (*x && ::stat(x, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == getuid() && ::access(x, W_OK) == 0) dir = x; }
+    if (dir.empty()) {
+        dir = "/tmp/vxhip-" + std::to_string((long)getuid());
+        ::mkdir(dir.c_str(), 0700);
+        struct stat st;
+        if (::lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) return std::string();   // (no safe place: no broker)
+    }
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const std::string& t) { for (unsigned char c : t) { h ^= c; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
+    char self[4096];
+    const ssize_t n = ::readlink("/proc/self/exe", self, sizeof(self) - 1);
+    if (n > 0) {
+        self[n] = 0;
+        mix(self);
+        struct stat st;
+        if (::stat(self, &st) == 0) mix(std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime) + ":" + std::to_string((long long)st.st_mtim.tv_nsec));
+    }
+    for (const char* key : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL", "VXH_BROKER_DEVICES", "VXH_ENGINE_OPTIONS"}) {
+        const char* v = std::getenv(key);
+        mix(std::string(key) + "=" + (v ? v : "\x01unset"));
+    }
+    char name[64];
+    std::snprintf(name, sizeof(name), "/broker-%016llx.sock", h);
+    return dir + name;
+}
+
+// the listener must be this user's process (SO_PEERCRED): an answer from anybody else's is not a result
+bool peer_is_me(int fd)
+{
+    struct ucred cr;
+    socklen_t len = sizeof(cr);
+    return ::getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cr, &len) == 0 && cr.uid == getuid();
 }
 
 std::vector<int> parse_devices(const char* p)
@@ -101,6 +139,7 @@ int connect_to(const std::string& path)
     if (path.size() >= sizeof(a.sun_path)) { ::close(fd); return -1; }
     std::strcpy(a.sun_path, path.c_str());
     if (::connect(fd, (sockaddr*)&a, sizeof(a)) != 0) { ::close(fd); return -1; }
+    if (!peer_is_me(fd)) { ::close(fd); return -1; }
     return fd;
 }
 
@@ -292,7 +331,7 @@ int broker_main(const std::string& path)
 bool spawn_broker(const std::string& path, const char* self)
 {
     const std::string lock = path + ".lock";
-    const int lk = ::open(lock.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+    const int lk = ::open(lock.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
     if (lk < 0) return false;
     bool ok = false;
     if (::flock(lk, LOCK_EX) == 0) {
@@ -331,6 +370,7 @@ bool spawn_broker(const std::string& path, const char* self)
 int run_through_broker(const std::string& file, int variant, const char* self)
 {
     const std::string path = socket_path();
+    if (path.empty()) return -1;
     int fd = connect_to(path);
     if (fd < 0) {
         if (!spawn_broker(path, self)) return -1;
@@ -375,7 +415,7 @@ int main(int argc, char* argv[])
         else if (!std::strcmp(argv[i], "--broker-quit")) control = "QUIT";
         else if (!std::strcmp(argv[i], "--broker-stat")) control = "STAT";
     }
-    if (broker) return broker_main(socket_path());
+    if (broker) { const std::string where = socket_path(); if (where.empty()) { std::fprintf(stderr, "voxelyze --broker: no directory of this user's own for the socket\n"); return 0; } return broker_main(where); }
     if (!control.empty()) {
         const int fd = connect_to(socket_path());
         if (fd < 0) { std::printf("no broker at %s\n", socket_path().c_str()); return 0; }
