@@ -1074,3 +1074,29 @@ if __name__ == "__main__" and "onestep" in sys.argv[1:]:
                     d[v, 3:7].max(), int((d[:, :3].max(axis=1) / lat > 5e-14).sum())), flush=True)
                 print("   got  pos %s vel %s\n   want pos %s vel %s" % (got[v, :3], got[v, 8:11], want[v, :3], want[v, 8:11]), flush=True)
             prev = got
+
+
+if __name__ == "__main__" and "swimhash" in sys.argv[1:]:
+    # a digest of every voxel's state of 24 swimmers of 8^3 and 8 of 6^3 (wide MESH kernel) + 4 of 10^3 (768-thread MESH variant) after 500 steps: two builds that
+    # claim the same arithmetic must print the same line (scripts/ab_lib.py <lib> swimhash)
+    import hashlib
+    from collections import OrderedDict
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    sim = Sim(self_collisions_enabled=True, dt_frac=0.9, simulation_time=0.3, fitness_eval_init_time=0.005)
+    with engine.Engine(engine.VOXCAD_LAND_WATER, 0) as eng:
+        n = 0
+        for shape, cnt in (((8, 8, 8), 24), ((6, 6, 6), 8), ((10, 10, 10), 4)):
+            for i in range(cnt):
+                ind = workloads.random_robot(n, shape, 900 + n, phase_offset=True)
+                write_voxelyze_file(sim, env_w, ind, tmp, "sw")
+                eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "sw--id_%05i.vxa" % n))
+                n += 1
+        eng.step(200); eng.step(300)
+        h = hashlib.sha256()
+        for i in range(n):
+            h.update(np.ascontiguousarray(eng.state(i)).tobytes())
+        print("%s swimhash %s (%d swimmers, 500 steps, kernel of most voxel-steps %d)" % (os.path.basename(engine.LIB_PATH), h.hexdigest()[:24], n, eng.counters().dominant_block), flush=True)
