@@ -1068,6 +1068,10 @@ void Engine::prepare()
     D.tile_launches.clear();
     std::vector<DTile> h_tiles;
     std::vector<int> tile_vox, tile_bond, tile_bcls, tile_bslot, xslot(nv, 0);
+    std::vector<int> tmv_slot[8], tf_owner, tf_vert[3], tile_ffirst;      // fluid tiles: mesh vertices (per corner code), facets
+    std::vector<double> tmv_v0[3];
+    std::vector<unsigned char> tile_fcount;
+    bool any_fluid_tiles = false;
     int nx_total = 0;
     const int tiled_now = tiling_allowed_ ? tiled_ : 0;
     if (tiled_now > 0) {
@@ -1091,7 +1095,8 @@ void Engine::prepare()
             // land_water robots in a FLUID are not tiled: their drag needs the deformable surface mesh, whose vertices average the corners of
             // up to seven voxels, across tile boundaries (resident / streaming kernels); on land they are (round 4: the tiles keep the
             // directional strains the RobotVolume tags need)
-            if (M.nvox == 0 || (M.nmv > 0 && variant_ == 1 && M.vxa.fluid_env)) continue;
+            // (round 5: in a fluid too -- the tile then carries its part of the drag mesh, k_tile_steps "fluid")
+            if (M.nvox == 0) continue;
             const int block = fused_variant(M).block;
             if (tiled_now == 2 || !fused_ || block == 0 || (small_population && block >= 768)) cand.push_back(r);
         }
@@ -1109,6 +1114,19 @@ void Engine::prepare()
         long long sum_lat = 0;
         for (int r : cand) sum_lat += k_latency(robots_[r]);
         struct Planned { int r; TilePlan plan; int tabg; size_t lds; int mesh; };
+        // a robot in a fluid: per tile the mesh vertices its owned voxels' facets use and those facets (counts, for the LDS layout; the tables
+        // themselves are filled when the exchange slots of the robot's voxels are known)
+        auto in_fluid = [&](const RobotModel& M) { return variant_ == 1 && M.vxa.fluid_env && M.nmv > 0; };
+        auto tile_mesh_counts = [&](const RobotModel& M, const TilePlan::Tile& t, int& n_mv, int& n_f) {
+            n_mv = n_f = 0;
+            if (!in_fluid(M)) return;
+            std::vector<char> seen(M.nmv, 0);
+            for (int v : t.own)
+                for (int f = M.facet_first[v]; f < M.facet_first[v] + (int)M.facet_count[v]; ++f) {
+                    ++n_f;
+                    for (int k = 0; k < 3; ++k) { const int i = M.facet_vert[(size_t)f * 3 + k]; if (!seen[i]) { seen[i] = 1; ++n_mv; } }
+                }
+        };
         std::vector<Planned> planned;
         for (int r : cand) {
             const RobotModel& M = robots_[r];
@@ -1120,8 +1138,11 @@ void Engine::prepare()
             for (;;) {
                 TilePlan P = plan_tiles(M, k);
                 size_t lds = 0;
-                for (const auto& t : P.tiles)
-                    lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles, M.nmv > 0).total * 8);
+                for (const auto& t : P.tiles) {
+                    int n_mv = 0, n_f = 0;
+                    tile_mesh_counts(M, t, n_mv, n_f);
+                    lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles, M.nmv > 0, n_mv, n_f).total * 8);
+                }
                 if (P.k > VXH_TILE_MAX_TILES) break;                  // (left to the other kernels)
                 if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds, M.nmv > 0 ? 1 : 0}); break; }
                 if (k >= M.nvox / 8) break;                           // cannot be tiled: left to the other kernels
@@ -1149,7 +1170,7 @@ void Engine::prepare()
                     d.robot = q.r; d.tile0 = tile0; d.ntiles = k;
                     d.n_own = (int)T.own.size(); d.n_halo = (int)T.halo.size(); d.nb = (int)T.bond_v1.size();
                     d.vox_off = (int)tile_vox.size(); d.bond_off = (int)tile_bond.size();
-                    d.xoff = nx_total; d.pad = 0;
+                    d.xoff = nx_total; d.pad = 0; d.mv_off = d.n_mv = d.f_off = d.n_f = 0;
                     for (size_t i = 0; i < T.own.size(); ++i) { tile_vox.push_back(base + T.own[i]); xslot[base + T.own[i]] = nx_total + (int)i; }
                     nx_total += ((int)T.own.size() + 63) / 64 * 64;
                     for (int v : T.halo) tile_vox.push_back(-(base + v) - 1);      // (exchange slots once every tile of the robot has its range)
@@ -1164,6 +1185,41 @@ void Engine::prepare()
                 for (int t = 0; t < k; ++t) {                          // halo voxels: global slot -> exchange slot
                     const DTile& d = h_tiles[tile0 + t];
                     for (int i = 0; i < d.n_halo; ++i) { int& e = tile_vox[d.vox_off + d.n_own + i]; e = xslot[-(e + 1)]; }
+                }
+                tile_ffirst.resize(tile_vox.size(), 0); tile_fcount.resize(tile_vox.size(), 0);
+                if (in_fluid(robots_[q.r])) {
+                    // the drag mesh, tile by tile: the vertices the facets of the tile's owned voxels use (every voxel touching such a vertex named
+                    // by its EXCHANGE slot: the vertex pass reads pose and strains of all of them from the exchange buffer, whoever owns them)
+                    // and those facets, per owned voxel in the reference's order
+                    const RobotModel& M = robots_[q.r];
+                    any_fluid_tiles = true;
+                    for (int t = 0; t < k; ++t) {
+                        DTile& d = h_tiles[tile0 + t];
+                        const TilePlan::Tile& T = q.plan.tiles[t];
+                        std::vector<int> local(M.nmv, -1), verts;
+                        d.f_off = (int)tf_owner.size();
+                        for (size_t o = 0; o < T.own.size(); ++o) {
+                            const int v = T.own[o];
+                            tile_ffirst[d.vox_off + o] = (int)tf_owner.size() - d.f_off;
+                            tile_fcount[d.vox_off + o] = M.facet_count[v];
+                            for (int f = M.facet_first[v]; f < M.facet_first[v] + (int)M.facet_count[v]; ++f) {
+                                tf_owner.push_back((int)o);
+                                for (int c = 0; c < 3; ++c) {
+                                    const int i = M.facet_vert[(size_t)f * 3 + c];
+                                    if (local[i] < 0) { local[i] = (int)verts.size(); verts.push_back(i); }
+                                    tf_vert[c].push_back(local[i]);
+                                }
+                            }
+                        }
+                        d.n_f = (int)tf_owner.size() - d.f_off;
+                        d.mv_off = (int)tmv_v0[0].size(); d.n_mv = (int)verts.size();
+                        for (int i : verts) {
+                            int slot[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+                            for (int e = 0; e < 8; ++e) { const int c = M.vert_comp[(size_t)i * 8 + e]; if (c >= 0) slot[c & 7] = xslot[base + (c >> 3)]; }
+                            for (int c = 0; c < 8; ++c) tmv_slot[c].push_back(slot[c]);
+                            for (int c = 0; c < 3; ++c) tmv_v0[c].push_back(M.vert_v0[(size_t)i * 3 + c]);
+                        }
+                    }
                 }
                 cur.count += k;
                 cur.robots.push_back(q.r);
@@ -1197,7 +1253,20 @@ void Engine::prepare()
     B.tile_bslot = D.upload(tile_bslot);
     B.nx = std::max(nx_total, 64);
     B.xslot = D.upload(xslot);
-    B.xch = D.alloc_zero<unsigned long long>(h_tiles.empty() ? 1 : (size_t)48 * B.nx);
+    B.xplanes = any_fluid_tiles ? 28 : 16;
+    B.xch = D.alloc_zero<unsigned long long>(h_tiles.empty() ? 1 : (size_t)3 * B.xplanes * B.nx);
+    {   // fluid tiles: their parts of the drag mesh
+        const size_t nm = tmv_v0[0].size(), nf = tf_owner.size();
+        std::vector<int> mvert(std::max<size_t>(1, 8 * nm), -1), facet(std::max<size_t>(1, 4 * nf), 0);
+        std::vector<double> mv0(std::max<size_t>(1, 3 * nm), 0.0);
+        for (int c = 0; c < 8; ++c) for (size_t i = 0; i < nm; ++i) mvert[(size_t)c * nm + i] = tmv_slot[c][i];
+        for (int c = 0; c < 3; ++c) for (size_t i = 0; i < nm; ++i) mv0[(size_t)c * nm + i] = tmv_v0[c][i];
+        for (size_t f = 0; f < nf; ++f) { facet[f] = tf_owner[f]; for (int c = 0; c < 3; ++c) facet[(size_t)(c + 1) * nf + f] = tf_vert[c][f]; }
+        tile_ffirst.resize(std::max<size_t>(1, tile_vox.size()), 0); tile_fcount.resize(std::max<size_t>(1, tile_vox.size()), 0);
+        B.n_tmv = (int)nm; B.n_tf = (int)nf;
+        B.tile_mvert = D.upload(mvert); B.tile_mv0 = D.upload(mv0); B.tile_facet = D.upload(facet);
+        B.tile_ffirst = D.upload(tile_ffirst); B.tile_fcount = D.upload(tile_fcount);
+    }
     B.tile_mv = D.alloc_zero<unsigned long long>(std::max<size_t>(1, h_tiles.size()) * 3 * VXH_TILE_MV_STRIDE);
     {   // fused path: launch groups by kernel variant; inside a group the longest-running robots first
         D.groups.clear();

@@ -1100,3 +1100,25 @@ if __name__ == "__main__" and "swimhash" in sys.argv[1:]:
         for i in range(n):
             h.update(np.ascontiguousarray(eng.state(i)).tobytes())
         print("%s swimhash %s (%d swimmers, 500 steps, kernel of most voxel-steps %d)" % (os.path.basename(engine.LIB_PATH), h.hexdigest()[:24], n, eng.counters().dominant_block), flush=True)
+
+
+if __name__ == "__main__" and "bigswim" in sys.argv[1:]:
+    # round 5: swimmers above 1024 voxels (full 11^3 and 14^3 lattices in a fluid) on the tiled kernel (fluid tiles) against the streaming kernels
+    from collections import OrderedDict
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    for n, count in ((11, 1), (14, 1), (11, 16)):
+        for opts in ({}, {"tiled": 0}):
+            tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+            sim = Sim(dt_frac=0.9, simulation_time=0.06, fitness_eval_init_time=0.005, self_collisions_enabled=True)
+            with engine.Engine(engine.VOXCAD_LAND_WATER, 0) as eng:
+                for k, v in opts.items():
+                    eng.set_option(k, v)
+                for i in range(count):
+                    ind = workloads.make_individual(i, workloads.full_material(n, 1 + i), OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(70 + i).uniform(-1, 1, size=(n, n, n)), 3))]))
+                    write_voxelyze_file(sim, env_w, ind, tmp, "b")
+                    eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "b--id_%05i.vxa" % i))
+                eng.step(200)
+                c0 = eng.counters(); eng.step(600); c1 = eng.counters()
+                print("bigswim %d x %d^3 swimmers %s: %.2f us per step (kernel %d)" % (count, n, opts, 1e6 * (c1.kernel_seconds - c0.kernel_seconds) / 600, c1.dominant_block), flush=True)
