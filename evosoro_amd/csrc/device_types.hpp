@@ -84,6 +84,7 @@ struct DTile {
     // robots in a FLUID (round 5): the part of the drag mesh the tile's owned voxels carry facets on -- its vertices in DBatch::tile_mvert /
     // tile_mv0 [mv_off ..), its facets in DBatch::tile_facet [f_off ..) (per owned voxel contiguous, in the reference's order)
     int mv_off, n_mv, f_off, n_f;
+    int mx_off, n_mx;     // ... and the voxels those vertices average over (DBatch::tile_mvox [mx_off ..): exchange slots), staged in LDS every step
 };
 
 // dynamic LDS of a tile's workgroup, in doubles from the base; the host sizes the launch with the same function
@@ -102,8 +103,8 @@ enum { VXH_TILE_BLOCK = 256,          // worker threads of a tile's workgroup = 
        VXH_TILE_XH = 192,             // most contact partners owned by other tiles that a tile mirrors in LDS (the rest: fetched from memory)
        VXH_TILE_CH = 128,             // chunk of the whole-robot passes (latch, broad-phase) staged through LDS
        VXH_TILE_STATIC_LDS = 1024 };   // upper bound of the kernel's static __shared__ variables
-struct TileLayout { int np, no, nbp, nmvp, nfp, o_ps, o_pl, o_hl, o_pht, o_sl, o_sc, o_px, o_rc, o_tab, o_int, o_mesh, total; };
-VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doubles, bool mesh, int n_mv = 0, int n_f = 0)
+struct TileLayout { int np, no, nbp, nmvp, nfp, nmxp, o_ps, o_pl, o_hl, o_pht, o_sl, o_sc, o_px, o_rc, o_tab, o_int, o_mesh, total; };
+VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doubles, bool mesh, int n_mv = 0, int n_f = 0, int n_mx = 0)
 {
     TileLayout L;
     L.np = (n_own + n_halo + 1) & ~1; L.no = (n_own + 1) & ~1; L.nbp = (nb + 1) & ~1;
@@ -117,10 +118,11 @@ VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doub
     L.o_rc = L.o_px + 4 * VXH_TILE_XH;
     L.o_tab = L.o_rc + VXH_TILE_ROWPOOL;
     L.o_int = L.o_tab + ((tab_doubles + 1) & ~1);
-    // a tile of a robot in a fluid: [3][nmvp] vertices of its part of the drag mesh, [3][nfp] drag of its facets, [3][no] velocities of its voxels
-    L.nmvp = (n_mv + 1) & ~1; L.nfp = (n_f + 1) & ~1;
+    // a tile of a robot in a fluid: [3][nmvp] vertices of its part of the drag mesh, [3][nfp] drag of its facets, [3][no] velocities of its voxels,
+    // [13][nmxp] position, quaternion and the six strains of every voxel its vertices average over
+    L.nmvp = (n_mv + 1) & ~1; L.nfp = (n_f + 1) & ~1; L.nmxp = (n_mx + 1) & ~1;
     L.o_mesh = L.o_int + (3 * L.nbp + VXH_TILE_XH + 2 * VXH_TILE_HASH + VXH_TILE_ROWPOOL + 1) / 2;
-    L.total = L.o_mesh + ((n_mv > 0 || n_f > 0) ? 3 * L.nmvp + 3 * L.nfp + 3 * L.no : 0);
+    L.total = L.o_mesh + ((n_mv > 0 || n_f > 0) ? 3 * L.nmvp + 3 * L.nfp + 3 * L.no + 13 * L.nmxp : 0);
     return L;
 }
 
@@ -224,7 +226,8 @@ struct DBatch {
     const int* xslot;                 // [nv] exchange slot of every voxel of a tiled robot: owner tile's xoff + its index there
     int nx, xplanes;                  // exchange slots in all (every tile's range padded to a multiple of 64); granule planes per buffer: 16, or 28 when
                                       // a tiled robot is in a fluid (planes 16 .. 27: low / high granules of the voxel's six directional strains)
-    const int* tile_mvert;            // [8][n_tmv] fluid tiles: per mesh vertex of a tile and corner code, the EXCHANGE slot of the voxel touching it there, or -1
+    const int* tile_mvox;             // fluid tiles: the voxels a tile's mesh vertices average over, as exchange slots (DTile::mx_off, n_mx)
+    const int* tile_mvert;            // [8][n_tmv] fluid tiles: per mesh vertex of a tile and corner code, the voxel touching it there as an index into the tile's tile_mvox list, or -1
     const double* tile_mv0;           // [3][n_tmv] its rest position
     const int* tile_facet;            // [4][n_tf] per facet of a tile: owner (index among the tile's owned voxels), its three vertices (tile-local)
     const int* tile_ffirst;           // [as tile_vox] per owned voxel: first facet (tile-local) ...

@@ -1068,7 +1068,7 @@ void Engine::prepare()
     D.tile_launches.clear();
     std::vector<DTile> h_tiles;
     std::vector<int> tile_vox, tile_bond, tile_bcls, tile_bslot, xslot(nv, 0);
-    std::vector<int> tmv_slot[8], tf_owner, tf_vert[3], tile_ffirst;      // fluid tiles: mesh vertices (per corner code), facets
+    std::vector<int> tmv_slot[8], tf_owner, tf_vert[3], tile_ffirst, tile_mvox;      // fluid tiles: mesh vertices (per corner code), facets, the voxels under the vertices
     std::vector<double> tmv_v0[3];
     std::vector<unsigned char> tile_fcount;
     bool any_fluid_tiles = false;
@@ -1117,14 +1117,19 @@ void Engine::prepare()
         // a robot in a fluid: per tile the mesh vertices its owned voxels' facets use and those facets (counts, for the LDS layout; the tables
         // themselves are filled when the exchange slots of the robot's voxels are known)
         auto in_fluid = [&](const RobotModel& M) { return variant_ == 1 && M.vxa.fluid_env && M.nmv > 0; };
-        auto tile_mesh_counts = [&](const RobotModel& M, const TilePlan::Tile& t, int& n_mv, int& n_f) {
-            n_mv = n_f = 0;
+        auto tile_mesh_counts = [&](const RobotModel& M, const TilePlan::Tile& t, int& n_mv, int& n_f, int& n_mx) {
+            n_mv = n_f = n_mx = 0;
             if (!in_fluid(M)) return;
-            std::vector<char> seen(M.nmv, 0);
+            std::vector<char> seen(M.nmv, 0), vseen(M.nvox, 0);
             for (int v : t.own)
                 for (int f = M.facet_first[v]; f < M.facet_first[v] + (int)M.facet_count[v]; ++f) {
                     ++n_f;
-                    for (int k = 0; k < 3; ++k) { const int i = M.facet_vert[(size_t)f * 3 + k]; if (!seen[i]) { seen[i] = 1; ++n_mv; } }
+                    for (int k = 0; k < 3; ++k) {
+                        const int i = M.facet_vert[(size_t)f * 3 + k];
+                        if (seen[i]) continue;
+                        seen[i] = 1; ++n_mv;
+                        for (int e = 0; e < 8; ++e) { const int c = M.vert_comp[(size_t)i * 8 + e]; if (c >= 0 && !vseen[c >> 3]) { vseen[c >> 3] = 1; ++n_mx; } }
+                    }
                 }
         };
         std::vector<Planned> planned;
@@ -1139,20 +1144,20 @@ void Engine::prepare()
                 TilePlan P = plan_tiles(M, k);
                 size_t lds = 0;
                 for (const auto& t : P.tiles) {
-                    int n_mv = 0, n_f = 0;
-                    tile_mesh_counts(M, t, n_mv, n_f);
-                    lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles, M.nmv > 0, n_mv, n_f).total * 8);
+                    int n_mv = 0, n_f = 0, n_mx = 0;
+                    tile_mesh_counts(M, t, n_mv, n_f, n_mx);
+                    lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles, M.nmv > 0, n_mv, n_f, n_mx).total * 8);
                 }
                 if (P.k > VXH_TILE_MAX_TILES) break;                  // (left to the other kernels)
-                if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds, M.nmv > 0 ? 1 : 0}); break; }
+                if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds, M.nmv > 0 ? (in_fluid(M) ? 2 : 1) : 0}); break; }
                 if (k >= M.nvox / 8) break;                           // cannot be tiled: left to the other kernels
                 k = std::min(std::max(k + 1, k * 5 / 4 + 1), std::max(1, M.nvox / 8));
             }
         }
         // launches: all tiles of a robot in one launch, a launch no larger than what the chip keeps resident (the tiles of a
         // robot wait for each other); 226 vector registers: at most two workgroups per CU
-        for (int kind = 0; kind < 4; ++kind) {
-            const int tabg = kind & 1, mesh = kind >> 1;
+        for (int kind = 0; kind < 6; ++kind) {
+            const int tabg = kind & 1, mesh = kind >> 1;      // mesh: 0 _voxcad, 1 land_water on land, 2 land_water in a fluid
             Device::TileLaunch cur;
             cur.tabg = tabg; cur.mesh = mesh;
             auto capacity = [&](size_t lds) { return (long long)D.n_cu * std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)(lds + VXH_TILE_STATIC_LDS))); };
@@ -1170,7 +1175,7 @@ void Engine::prepare()
                     d.robot = q.r; d.tile0 = tile0; d.ntiles = k;
                     d.n_own = (int)T.own.size(); d.n_halo = (int)T.halo.size(); d.nb = (int)T.bond_v1.size();
                     d.vox_off = (int)tile_vox.size(); d.bond_off = (int)tile_bond.size();
-                    d.xoff = nx_total; d.pad = 0; d.mv_off = d.n_mv = d.f_off = d.n_f = 0;
+                    d.xoff = nx_total; d.pad = 0; d.mv_off = d.n_mv = d.f_off = d.n_f = d.mx_off = d.n_mx = 0;
                     for (size_t i = 0; i < T.own.size(); ++i) { tile_vox.push_back(base + T.own[i]); xslot[base + T.own[i]] = nx_total + (int)i; }
                     nx_total += ((int)T.own.size() + 63) / 64 * 64;
                     for (int v : T.halo) tile_vox.push_back(-(base + v) - 1);      // (exchange slots once every tile of the robot has its range)
@@ -1213,12 +1218,21 @@ void Engine::prepare()
                         }
                         d.n_f = (int)tf_owner.size() - d.f_off;
                         d.mv_off = (int)tmv_v0[0].size(); d.n_mv = (int)verts.size();
+                        d.mx_off = (int)tile_mvox.size();
+                        std::vector<int> vlocal(M.nvox, -1);
                         for (int i : verts) {
                             int slot[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-                            for (int e = 0; e < 8; ++e) { const int c = M.vert_comp[(size_t)i * 8 + e]; if (c >= 0) slot[c & 7] = xslot[base + (c >> 3)]; }
+                            for (int e = 0; e < 8; ++e) {
+                                const int c = M.vert_comp[(size_t)i * 8 + e];
+                                if (c < 0) continue;
+                                const int v = c >> 3;
+                                if (vlocal[v] < 0) { vlocal[v] = (int)tile_mvox.size() - d.mx_off; tile_mvox.push_back(xslot[base + v]); }
+                                slot[c & 7] = vlocal[v];
+                            }
                             for (int c = 0; c < 8; ++c) tmv_slot[c].push_back(slot[c]);
                             for (int c = 0; c < 3; ++c) tmv_v0[c].push_back(M.vert_v0[(size_t)i * 3 + c]);
                         }
+                        d.n_mx = (int)tile_mvox.size() - d.mx_off;
                     }
                 }
                 cur.count += k;
@@ -1266,6 +1280,8 @@ void Engine::prepare()
         B.n_tmv = (int)nm; B.n_tf = (int)nf;
         B.tile_mvert = D.upload(mvert); B.tile_mv0 = D.upload(mv0); B.tile_facet = D.upload(facet);
         B.tile_ffirst = D.upload(tile_ffirst); B.tile_fcount = D.upload(tile_fcount);
+        if (tile_mvox.empty()) tile_mvox.push_back(0);
+        B.tile_mvox = D.upload(tile_mvox);
     }
     B.tile_mv = D.alloc_zero<unsigned long long>(std::max<size_t>(1, h_tiles.size()) * 3 * VXH_TILE_MV_STRIDE);
     {   // fused path: launch groups by kernel variant; inside a group the longest-running robots first
@@ -1365,12 +1381,12 @@ static void launch_variant(const DBatch& B, const int* list, int count, size_t l
     hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
 }
 
-template <bool TABG, bool MESH>
+template <bool TABG, bool MESH, bool FLUID = false>
 static void launch_tiles(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
 {
     static size_t granted[64] = {};
-    grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH>, granted, lds);
-    hipLaunchKernelGGL((k_tile_steps<TABG, MESH>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
+    grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH, FLUID>, granted, lds);
+    hipLaunchKernelGGL((k_tile_steps<TABG, MESH, FLUID>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
 }
 
 template <bool FLUID, bool TABG>
@@ -1507,7 +1523,9 @@ void Engine::advance_launch(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters)
             for (const auto& L : D.tile_launches) {
                 ++tile_gen_;
-                if (L.mesh) { if (L.tabg) launch_tiles<true, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                if (L.mesh == 2) { if (L.tabg) launch_tiles<true, true, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                                   else launch_tiles<false, true, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_); }
+                else if (L.mesh) { if (L.tabg) launch_tiles<true, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
                               else launch_tiles<false, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_); }
                 else if (L.tabg) launch_tiles<true, false>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
                 else launch_tiles<false, false>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);

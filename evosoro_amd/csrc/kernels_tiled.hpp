@@ -314,7 +314,7 @@ __device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DR
 #endif
 
 
-template <bool TABG, bool MESH>
+template <bool TABG, bool MESH, bool FLUID = false>      // FLUID (implies MESH): the robots of the launch are in a fluid (drag mesh per tile, strains exchanged)
 __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const DRobot* __restrict__ robots, const DTile* __restrict__ tiles,
                                                                  const int* __restrict__ tile_list, long long step_cap, int iters, unsigned gen)
 {
@@ -338,9 +338,10 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     const int n_own = T.n_own, n_halo = T.n_halo, nb = T.nb, k_tiles = T.ntiles;
     const int nbd = TABG ? 0 : R.n_bclass * (int)(sizeof(DBondClass) / 8), nvd = TABG ? 0 : R.n_vclass * (int)(sizeof(DVoxClass) / 8);
     // a robot in a FLUID (round 5): the tile carries the part of the drag mesh its owned voxels have facets on (DTile::n_mv / n_f)
-    const bool fluid = MESH && (R.flags & RF_FLUID) != 0 && T.n_f > 0;
-    const int n_mv = MESH ? T.n_mv : 0, n_f = MESH ? T.n_f : 0;
-    const TileLayout L = tile_layout(n_own, n_halo, nb, nbd + nvd, MESH, n_mv, n_f);
+    static_assert(MESH || !FLUID, "a robot in a fluid is a land_water robot");
+    const bool fluid = FLUID && T.n_f > 0;
+    const int n_mv = FLUID ? T.n_mv : 0, n_f = FLUID ? T.n_f : 0, n_mx = FLUID ? T.n_mx : 0;
+    const TileLayout L = tile_layout(n_own, n_halo, nb, nbd + nvd, MESH, n_mv, n_f, n_mx);
     const int np = L.np, no = L.no, nbp = L.nbp;
     double* const ps = lds + L.o_ps;          // [8][np] pose tile: owned voxels, then halo voxels
     double* const pl = lds + L.o_pl;          // [6 directions][6][no] bond force / minus bond moment on every owned voxel
@@ -362,10 +363,11 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     double* const msh = lds + L.o_mesh;       // fluid: [3][nmvp] my mesh vertices of this step
     double* const fdr = msh + 3 * L.nmvp;     // fluid: [3][nfp] drag of my facets
     double* const spd = fdr + 3 * L.nfp;      // fluid: [3][no] velocities of my voxels at the start of the step
-    const int nmvp = L.nmvp, nfp = L.nfp;
+    double* const mst = spd + 3 * L.no;       // fluid: [13][nmxp] position, quaternion, six strains of every voxel my vertices average over
+    const int nmvp = L.nmvp, nfp = L.nfp, nmxp = L.nmxp;
     const unsigned nx = B.nx;                 // exchange slots (every tile's owned voxels contiguous: its pose stores fill whole lines)
     const size_t xbuf = (size_t)B.xplanes * nx;   // granules per exchange buffer (a ring of three): 16 planes of poses (+ 12 of strains when a tiled robot is in a fluid)
-    const bool xstrain = MESH && B.xplanes > 16 && (R.flags & RF_FLUID) != 0;      // my voxels' strains travel with their poses
+    constexpr bool xstrain = FLUID;           // my voxels' strains travel with their poses
     const int xs_own = T.xoff + tid;          // exchange slot of my owned voxel
     const size_t mvbuf = (size_t)VXH_TILE_MV_STRIDE * B.n_tiles;
 
@@ -421,11 +423,9 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         const unsigned tag1 = tile_tag(gen, 0, 1);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ps[k * np + tid] = q8[k]; st_gran2(xq0 + (size_t)(2 * k) * nx, nx, q8[k], tag1); }
-        if constexpr (mesh) {
-            if (xstrain) {
+        if constexpr (xstrain) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) st_gran2(xq0 + (size_t)(16 + 2 * k) * nx, nx, sl[k * no + tid], tag1);
-            }
+            for (int k = 0; k < 6; ++k) st_gran2(xq0 + (size_t)(16 + 2 * k) * nx, nx, sl[k * no + tid], tag1);
         }
     }
     int my_ff = 0, my_fc = 0;                 // fluid: my voxel's facets among the tile's
@@ -572,48 +572,29 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 for (int k = 0; k < 4; ++k) px[k * VXH_TILE_XH + e] = gran2_value(g[2 * k], g[2 * k + 1]);
             }
         }
-        if constexpr (MESH) {
+        if constexpr (FLUID) {
             if (go && fluid && !svc) {
-                // ---- 1b. fluid drag, the surface mesh (LW/VX_MeshUtil.cpp:388-428, as k_mesh_vertices / fused_drag): every vertex my facets use =
-                // mean over the voxels touching that lattice corner of Pos + R(Angle) * corner offset, corner offsets from the strains of the
-                // PREVIOUS step's bonds -- pose and strains of ALL of them from the exchange buffer of this step (they may be mine, a
-                // neighbour tile's, or a diagonal neighbour's that is no halo voxel: one protocol), summed in corner-code order
+                // ---- 1b. fluid drag, staging: pose and strains (of the PREVIOUS step's bonds) of every voxel my part of the drag mesh averages
+                // over -- mine, a neighbour tile's, or a diagonal neighbour's that is no halo voxel: ONE protocol, the exchange buffer of this
+                // step -- one voxel per lane, one memory round trip for all of them
                 if (valid) { const d3 sp = lm * C.mass_inv; spd[tid] = sp.x; spd[no + tid] = sp.y; spd[2 * no + tid] = sp.z; }
-                const double nom = R.lat;
-                for (int i = tid; i < n_mv; i += BLOCK) {
-                    d3 part = mk3(0, 0, 0);
-                    int count = 0;
-                    for (int corner = 0; corner < 8; ++corner) {
-                        const int xs = B.tile_mvert[(size_t)corner * B.n_tmv + T.mv_off + i];
-                        if (xs < 0) continue;
-                        const int sidx[3] = {(corner & 4) ? 0 : 3, (corner & 2) ? 1 : 4, (corner & 1) ? 2 : 5};      // CornerPosCur / CornerNegCur
-                        unsigned long long g[20];
-                        for (;;) {
-                            bool ok = true;
+                for (int j = tid; j < n_mx; j += BLOCK) {
+                    const int xs = B.tile_mvox[T.mx_off + j];
+                    unsigned long long g[26];
+                    for (;;) {
+                        bool ok = true;
 #pragma unroll
-                            for (int k = 0; k < 6; ++k) g[k] = ld_gran(xq + (size_t)k * nx + xs);                       // position
+                        for (int k = 0; k < 6; ++k) g[k] = ld_gran(xq + (size_t)k * nx + xs);                           // position
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) g[6 + k] = ld_gran(xq + (size_t)(8 + k) * nx + xs);             // quaternion
+                        for (int k = 0; k < 20; ++k) g[6 + k] = ld_gran(xq + (size_t)(8 + k) * nx + xs);                // quaternion, strains
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) { g[14 + 2 * k] = ld_gran(xq + (size_t)(16 + 2 * sidx[k]) * nx + xs); g[15 + 2 * k] = ld_gran(xq + (size_t)(17 + 2 * sidx[k]) * nx + xs); }
-#pragma unroll
-                            for (int k = 0; k < 20; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
-                            if (ok) break;
-                            __builtin_amdgcn_s_sleep(1);
-                            if (++spins > VXH_TILE_SPIN_LIMIT) { s_abort = 1; break; }
-                        }
-                        const d3 vp = mk3(gran2_value(g[0], g[1]), gran2_value(g[2], g[3]), gran2_value(g[4], g[5]));
-                        const RotFwd M(mkq(gran2_value(g[6], g[7]), gran2_value(g[8], g[9]), gran2_value(g[10], g[11]), gran2_value(g[12], g[13])));
-                        const double hx = (1 + gran2_value(g[14], g[15])) * nom * 0.5, hy = (1 + gran2_value(g[16], g[17])) * nom * 0.5, hz = (1 + gran2_value(g[18], g[19])) * nom * 0.5;
-                        part = part + (vp + M(mk3((corner & 4) ? hx : -hx, (corner & 2) ? hy : -hy, (corner & 1) ? hz : -hz)));
-                        ++count;
+                        for (int k = 0; k < 26; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
+                        if (ok) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > VXH_TILE_SPIN_LIMIT) { s_abort = 1; break; }
                     }
-                    const double inv = vrcp((double)count);
-                    const size_t at = (size_t)T.mv_off + i;
-                    const d3 v0 = mk3(B.tile_mv0[at], B.tile_mv0[(size_t)B.n_tmv + at], B.tile_mv0[2 * (size_t)B.n_tmv + at]);
-                    const d3 npos = part * inv;
-                    const d3 now = v0 + (npos - v0);                 // v + DrawOffset, as the reference stores it
-                    msh[i] = now.x; msh[nmvp + i] = now.y; msh[2 * nmvp + i] = now.z;
+#pragma unroll
+                    for (int k = 0; k < 13; ++k) mst[k * nmxp + j] = gran2_value(g[2 * k], g[2 * k + 1]);
                 }
             }
         }
@@ -622,6 +603,38 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         VXH_TT_MARK(0)
         VXH_TS(1, tid == 0)
         const bool damp_on = K.damp_on != 0;
+        if constexpr (FLUID) {
+            if (go && fluid) {                 // (uniform over the workgroup: its barrier)
+                // ---- 1c. the surface mesh (LW/VX_MeshUtil.cpp:388-428, as k_mesh_vertices / fused_drag): every vertex my facets use = mean over
+                // the voxels touching that lattice corner of Pos + R(Angle) * corner offset, summed in corner-code order
+                if (!svc) {
+                    const double nom = R.lat;
+                    for (int i = tid; i < n_mv; i += BLOCK) {
+                        d3 part = mk3(0, 0, 0);
+                        int count = 0;
+#pragma unroll
+                        for (int corner = 0; corner < 8; ++corner) {
+                            const int j = B.tile_mvert[(size_t)corner * B.n_tmv + T.mv_off + i];
+                            if (j < 0) continue;
+                            const double* q = mst + j;
+                            const double hx = (1 + q[(7 + ((corner & 4) ? 0 : 3)) * nmxp]) * nom * 0.5;      // CornerPosCur / CornerNegCur
+                            const double hy = (1 + q[(7 + ((corner & 2) ? 1 : 4)) * nmxp]) * nom * 0.5;
+                            const double hz = (1 + q[(7 + ((corner & 1) ? 2 : 5)) * nmxp]) * nom * 0.5;
+                            const RotFwd M(mkq(q[3 * nmxp], q[4 * nmxp], q[5 * nmxp], q[6 * nmxp]));
+                            part = part + (mk3(q[0], q[nmxp], q[2 * nmxp]) + M(mk3((corner & 4) ? hx : -hx, (corner & 2) ? hy : -hy, (corner & 1) ? hz : -hz)));
+                            ++count;
+                        }
+                        const double inv = vrcp((double)count);
+                        const size_t at = (size_t)T.mv_off + i;
+                        const d3 v0 = mk3(B.tile_mv0[at], B.tile_mv0[(size_t)B.n_tmv + at], B.tile_mv0[2 * (size_t)B.n_tmv + at]);
+                        const d3 npos = part * inv;
+                        const d3 now = v0 + (npos - v0);                 // v + DrawOffset, as the reference stores it
+                        msh[i] = now.x; msh[nmvp + i] = now.y; msh[2 * nmvp + i] = now.z;
+                    }
+                }
+                __syncthreads();
+            }
+        }
 
         // ---- 2. workers: bond phase, every bond with an owned end, all axes in one round.  Service wavefront, on steps that do
         // not speculate: the per-robot barrier
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 VXH_TT_MARK(7)
             }
         } else if (go && !s_abort) {
-            if constexpr (MESH) {
+            if constexpr (FLUID) {
                 if (fluid) {
                     // ---- 2a. fluid drag of my facets (LW/VX_Sim.cpp:1516-1597; facet_drag_force), each on its voxel's velocity at the start of the step
                     for (int f = tid; f < n_f; f += BLOCK) {
@@ -720,7 +733,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         // is redone (attempt 1) after the broad-phase if the lists turn out to have been due for a rebuild
         const bool diverged_here = s_div != 0;
         d3 drag = mk3(0, 0, 0);
-        if constexpr (MESH) {
+        if constexpr (FLUID) {
             if (fluid && valid)                // my facets' drag in facet order (barrier (B) stands between the facet pass and here)
                 for (int k = my_ff; k < my_ff + my_fc; ++k) drag = drag + mk3(fdr[k], fdr[nfp + k], fdr[2 * nfp + k]);
         }
@@ -754,7 +767,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                     const FetchTile fetch{ps, px, np, tid, codes_live, pose};
                     F = tile_contacts(B, R, fetch, F, S, gv, row, ccnt, roff, rc_code, rc_a1);
                     VXH_TV(1)
-                    vel2 = voxel_update(B, R, C, gv, pose, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, row, 0, MESH && (R.flags & RF_FLUID) != 0, drag,
+                    vel2 = voxel_update(B, R, C, gv, pose, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, row, 0, FLUID, drag,
                                         pht[tid], pht[no + tid], amp_damp);
                 }
                 VXH_TV(2)
@@ -764,11 +777,9 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 p8[0] = S.pos.x; p8[1] = S.pos.y; p8[2] = S.pos.z; p8[3] = S.scale; p8[4] = S.ang.w; p8[5] = S.ang.x; p8[6] = S.ang.y; p8[7] = S.ang.z;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_own, nx, p8[k], tagn);
-                if constexpr (mesh) {
-                    if (xstrain) {             // ... and the strains this step's bonds left: the next step's mesh is built from them
+                if constexpr (xstrain) {       // ... and the strains this step's bonds left: the next step's mesh is built from them
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) st_gran2(xqn + (size_t)(16 + 2 * k) * nx + xs_own, nx, sl[k * no + tid], tagn);
-                    }
+                    for (int k = 0; k < 6; ++k) st_gran2(xqn + (size_t)(16 + 2 * k) * nx + xs_own, nx, sl[k * no + tid], tagn);
                 }
                 VXH_TV(3)
             }

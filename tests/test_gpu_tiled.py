@@ -324,3 +324,31 @@ def test_a_land_water_lattice_above_1024_voxels_on_land_is_tiled(tmp_path):
         a, b = getattr(tiled_res, f), getattr(ref_res, f)
         assert b > 0 and abs(a - b) <= 1e-9 * abs(b), (f, a, b)
     assert abs(tiled_res.robot_volume_end - tiled_res.robot_volume_start) > 1e-6 * tiled_res.robot_volume_start      # the strains did reach the host: a deformed mesh
+
+
+def test_swimmers_on_tiles_do_not_depend_on_the_tiling(golden_dir):
+    """Round 5: robots IN A FLUID on the tiled kernel.  Every tile carries the part of the drag mesh its owned voxels have facets on; a
+    mesh vertex averages the corners of up to seven voxels -- the tile's own, a neighbour's, or a diagonal neighbour's that is no halo
+    voxel -- whose poses AND strains (of the previous step's bonds) come through the exchange buffer.  Same arithmetic and the same
+    orders of summation as the resident / wide kernels (fused_drag), so: different tile counts give the same bits; tiled vs the resident
+    MESH kernel within 1e-12 voxel; launch boundaries invisible (the strains are published with the poses a launch starts from)."""
+    from evosoro_amd import engine as eng_mod
+    names = ["lw_swim6", "cfg3_00", "lw_swim10", "lw_hexapus"]
+    paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in names]
+    checkpoints = (1, 5, 200, 700)
+    ref = _states(eng_mod, paths, {"tiled": 0, "wide": 0}, checkpoints, variant=1)
+    a = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": 2}, checkpoints, variant=1)
+    b = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": 7}, checkpoints, variant=1)
+    for c in range(len(checkpoints)):
+        for i, name in enumerate(names):
+            assert np.array_equal(a[c][i], b[c][i]), (checkpoints[c], name)
+            assert np.abs(a[c][i][:, :8] - ref[c][i][:, :8]).max() < 1e-12, (checkpoints[c], name)
+    pieces = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": 4, "steps_per_launch": 64}, (1, 3, 256, 700), variant=1)[-1]
+    whole = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": 4, "steps_per_launch": 64}, (700,), variant=1)[-1]
+    for x, y in zip(pieces, whole):
+        assert np.array_equal(x, y)
+    with eng_mod.Engine(1, 0) as eng:          # (and the tiled kernel is what stepped them)
+        eng.set_option("tiled", 2); eng.set_option("tiles_per_robot", 4)
+        eng.add_vxa_file(paths[1])
+        eng.step(10)
+        assert eng.counters().dominant_block == 1
