@@ -1092,10 +1092,9 @@ void Engine::prepare()
         std::vector<int> cand;
         for (int r = 0; r < nr; ++r) {
             const RobotModel& M = robots_[r];
-            // land_water robots in a FLUID are not tiled: their drag needs the deformable surface mesh, whose vertices average the corners of
-            // up to seven voxels, across tile boundaries (resident / streaming kernels); on land they are (round 4: the tiles keep the
-            // directional strains the RobotVolume tags need)
-            // (round 5: in a fluid too -- the tile then carries its part of the drag mesh, k_tile_steps "fluid")
+            // land_water robots are tiled on land (round 4: the tiles keep the directional strains the RobotVolume tags need) and, since
+            // round 5, in a FLUID: the tile then carries its part of the drag mesh, and the voxels a mesh vertex averages over -- up to
+            // seven, across tile boundaries, diagonal neighbours included -- come through the exchange buffer with their strains
             if (M.nvox == 0) continue;
             const int block = fused_variant(M).block;
             if (tiled_now == 2 || !fused_ || block == 0 || (small_population && block >= 768)) cand.push_back(r);

@@ -37,6 +37,14 @@
 // A diverging bond (strain > 100, VX_Sim.cpp:1775) stops the robot BEFORE the voxel loop of that step; the other tiles learn
 // of it at the next per-robot barrier: the voxel phase that ran meanwhile is rolled back (momenta kept a step, poses still in
 // the ring); the bond history of a stopped robot is dead.
+// Robots in a FLUID (template argument FLUID, round 5; fluid drag LW/VX_Sim.cpp:1516-1597).  A tile carries the part of the deformable
+// surface mesh its owned voxels have facets on.  A mesh vertex is the mean of the corners of the up to seven voxels meeting in it --
+// owned ones, halo ones, and diagonal neighbours that are neither -- and a corner needs its voxel's pose AND its directional strains of
+// the previous step's bonds; so the owners publish the six strains with every pose (planes 16 .. 27 of the exchange buffer, same tags), and
+// at the top of a step every lane fetches one of the voxels under the tile's vertices (DBatch::tile_mvox) into LDS: one protocol and one
+// memory round trip whoever owns the voxel.  Then: vertices (corner-code order, as fused_drag and k_mesh_vertices), a workgroup barrier,
+// the facets' drag next to the bond phase, and behind barrier (B) every voxel adds its facets in the reference's order.  Same arithmetic
+// and orders as the resident / wide / streaming kernels: different tilings give the same bits (tests/test_gpu_tiled.py).
 // The control block (time, stop rule, collision horizon) is replicated: every tile runs the same serial control code on the
 // same inputs.  Residency: all tiles of a robot must be on the chip at the same time; the host sizes every launch to what the
 // CUs admit and issues the tiled launches of an engine on ONE stream.  Spins are bounded (VXH_ROBOT_SYNC_TIMEOUT).
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     double* const hl = lds + L.o_hl;          // [6][nbp] bond history
     double* const pht = lds + L.o_pht;        // [2][no] sin / cos of the actuation phase offsets
     double* const sl = lds + L.o_sl;          // [6][no] land_water robots: the directional strains of my voxels (CurStrainV1/V2 of their bonds, SetStrainDir)
-    constexpr bool mesh = MESH;               // land_water robots (on land: robots in a fluid are not tiled): the strains are part of their state
+    constexpr bool mesh = MESH;               // land_water robots: the strains are part of their state (FLUID: and travel with the poses)
     double* const sc = lds + L.o_sc;          // scratch of latch / broad-phase
     double* const px = lds + L.o_px;          // [4][VXH_TILE_XH] position + scale of the mirrored contact partners
     double* const rc_a1 = lds + L.o_rc;       // [VXH_TILE_ROWPOOL] the tile's contact rows: pair stiffnesses ...
