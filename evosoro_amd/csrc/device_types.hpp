@@ -122,7 +122,8 @@ VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doub
     // [13][nmxp] position, quaternion and the six strains of every voxel its vertices average over
     L.nmvp = (n_mv + 1) & ~1; L.nfp = (n_f + 1) & ~1; L.nmxp = (n_mx + 1) & ~1;
     L.o_mesh = L.o_int + (3 * L.nbp + VXH_TILE_XH + 2 * VXH_TILE_HASH + VXH_TILE_ROWPOOL + 1) / 2;
-    L.total = L.o_mesh + ((n_mv > 0 || n_f > 0) ? 3 * L.nmvp + 3 * L.nfp + 3 * L.no + 13 * L.nmxp : 0);
+    // ... and the constant tables of that mesh (copied once per launch): [3][nmvp] rest positions, [8][nmvp] ints voxel per corner code, [4][nfp] ints facets
+    L.total = L.o_mesh + ((n_mv > 0 || n_f > 0) ? 3 * L.nmvp + 3 * L.nfp + 3 * L.no + 13 * L.nmxp + 3 * L.nmvp + 4 * L.nmvp + 2 * L.nfp : 0);
     return L;
 }
 

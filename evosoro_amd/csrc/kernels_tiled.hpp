@@ -372,6 +372,9 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     double* const fdr = msh + 3 * L.nmvp;     // fluid: [3][nfp] drag of my facets
     double* const spd = fdr + 3 * L.nfp;      // fluid: [3][no] velocities of my voxels at the start of the step
     double* const mst = spd + 3 * L.no;       // fluid: [13][nmxp] position, quaternion, six strains of every voxel my vertices average over
+    double* const mv0 = mst + 13 * L.nmxp;    // fluid: [3][nmvp] rest positions of my vertices (constant tables: copied once per launch)
+    int* const mvt = (int*)(mv0 + 3 * L.nmvp);   // fluid: [8][nmvp] per vertex and corner code, the voxel touching it there (index into mst) or -1
+    int* const fct = mvt + 8 * L.nmvp;        // fluid: [4][nfp] per facet: owner voxel, its three vertices
     const int nmvp = L.nmvp, nfp = L.nfp, nmxp = L.nmxp;
     const unsigned nx = B.nx;                 // exchange slots (every tile's owned voxels contiguous: its pose stores fill whole lines)
     const size_t xbuf = (size_t)B.xplanes * nx;   // granules per exchange buffer (a ring of three): 16 planes of poses (+ 12 of strains when a tiled robot is in a fluid)
@@ -434,6 +437,19 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         if constexpr (xstrain) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) st_gran2(xq0 + (size_t)(16 + 2 * k) * nx, nx, sl[k * no + tid], tag1);
+        }
+    }
+    if constexpr (FLUID) {
+        for (int i = tid; i < n_mv; i += NT) {
+            const size_t at = (size_t)T.mv_off + i;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mv0[c * nmvp + i] = B.tile_mv0[(size_t)c * B.n_tmv + at];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mvt[c * nmvp + i] = B.tile_mvert[(size_t)c * B.n_tmv + at];
+        }
+        for (int f = tid; f < n_f; f += NT) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) fct[c * nfp + f] = B.tile_facet[(size_t)c * B.n_tf + T.f_off + f];
         }
     }
     int my_ff = 0, my_fc = 0;                 // fluid: my voxel's facets among the tile's
@@ -622,7 +638,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                         int count = 0;
 #pragma unroll
                         for (int corner = 0; corner < 8; ++corner) {
-                            const int j = B.tile_mvert[(size_t)corner * B.n_tmv + T.mv_off + i];
+                            const int j = mvt[corner * nmvp + i];
                             if (j < 0) continue;
                             const double* q = mst + j;
                             const double hx = (1 + q[(7 + ((corner & 4) ? 0 : 3)) * nmxp]) * nom * 0.5;      // CornerPosCur / CornerNegCur
@@ -633,8 +649,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                             ++count;
                         }
                         const double inv = vrcp((double)count);
-                        const size_t at = (size_t)T.mv_off + i;
-                        const d3 v0 = mk3(B.tile_mv0[at], B.tile_mv0[(size_t)B.n_tmv + at], B.tile_mv0[2 * (size_t)B.n_tmv + at]);
+                        const d3 v0 = mk3(mv0[i], mv0[nmvp + i], mv0[2 * nmvp + i]);
                         const d3 npos = part * inv;
                         const d3 now = v0 + (npos - v0);                 // v + DrawOffset, as the reference stores it
                         msh[i] = now.x; msh[nmvp + i] = now.y; msh[2 * nmvp + i] = now.z;
@@ -666,8 +681,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 if (fluid) {
                     // ---- 2a. fluid drag of my facets (LW/VX_Sim.cpp:1516-1597; facet_drag_force), each on its voxel's velocity at the start of the step
                     for (int f = tid; f < n_f; f += BLOCK) {
-                        const size_t at = (size_t)T.f_off + f, tf = (size_t)B.n_tf;
-                        const int u = B.tile_facet[at], ia = B.tile_facet[tf + at], ib = B.tile_facet[2 * tf + at], ic = B.tile_facet[3 * tf + at];
+                        const int u = fct[f], ia = fct[nfp + f], ib = fct[2 * nfp + f], ic = fct[3 * nfp + f];
                         const d3 speed = mk3(spd[u], spd[no + u], spd[2 * no + u]);
                         const d3 contrib = facet_drag_force(speed, normalized3(speed), mk3(msh[ia], msh[nmvp + ia], msh[2 * nmvp + ia]),
                                                             mk3(msh[ib], msh[nmvp + ib], msh[2 * nmvp + ib]), mk3(msh[ic], msh[nmvp + ic], msh[2 * nmvp + ic]), R.drag_coef);

@@ -1122,3 +1122,34 @@ if __name__ == "__main__" and "bigswim" in sys.argv[1:]:
                 eng.step(200)
                 c0 = eng.counters(); eng.step(600); c1 = eng.counters()
                 print("bigswim %d x %d^3 swimmers %s: %.2f us per step (kernel %d)" % (count, n, opts, 1e6 * (c1.kernel_seconds - c0.kernel_seconds) / 600, c1.dominant_block), flush=True)
+    # the same lattices as land_water robots ON LAND (tiles with the strain tile, no drag mesh), for what the drag costs a tile
+    for n in (11, 14):
+        tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+        sim = Sim(dt_frac=0.9, simulation_time=0.06, fitness_eval_init_time=0.005, self_collisions_enabled=True)
+        with engine.Engine(engine.VOXCAD_LAND_WATER, 0) as eng:
+            ind = workloads.make_individual(0, workloads.full_material(n, 1), OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(70).uniform(-1, 1, size=(n, n, n)), 3))]))
+            write_voxelyze_file(sim, Env(), ind, tmp, "b")
+            eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "b--id_%05i.vxa" % 0))
+            eng.step(200)
+            c0 = eng.counters(); eng.step(600); c1 = eng.counters()
+            print("bigswim 1 x %d^3 ON LAND: %.2f us per step (kernel %d)" % (n, 1e6 * (c1.kernel_seconds - c0.kernel_seconds) / 600, c1.dominant_block), flush=True)
+
+
+if __name__ == "__main__" and "swimtimeline" in sys.argv[1:]:
+    # per-tile timeline (VXH_PROF_TILES=1, developer library) of a full 11^3 land_water lattice in a fluid and on land
+    from collections import OrderedDict
+    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libvxhip_prof.so")
+    for fluid in (1, 0):
+        env_w = Env()
+        if fluid:
+            env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+            env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+        tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+        sim = Sim(dt_frac=0.9, simulation_time=0.06, fitness_eval_init_time=0.005, self_collisions_enabled=True)
+        with engine.Engine(engine.VOXCAD_LAND_WATER, 0) as eng:
+            ind = workloads.make_individual(0, workloads.full_material(11, 1), OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(70).uniform(-1, 1, size=(11, 11, 11)), 3))]))
+            write_voxelyze_file(sim, env_w, ind, tmp, "b")
+            eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "b--id_%05i.vxa" % 0))
+            eng.step(600)
+            print("swimtimeline fluid=%d" % fluid, flush=True)
+            eng.clear()
