@@ -488,7 +488,14 @@ void Engine::check_option(const std::string& key, double value) const
     if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "wide_two_tiles" || key == "col_cap" || key == "fused" || key == "pair" || key == "pair_sel") {
         // which kernel steps a robot, its tiling and the size of its contact rows are part of the uploaded batch: set before the first
         // vxh_run / vxh_step, or right after vxh_reset (no step taken yet: the batch is then assembled again at the next run)
-        if (prepared_ && rounds_done_ > 0) throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or right after vxh_reset)");
+        {   // (an unchanged value is always fine: nothing would be assembled again)
+            const double now = key == "wide" ? (double)wide_ : key == "wide_two_tiles" ? (double)wide_two_tiles_ : key == "col_cap" ? (double)col_cap_ :
+                               key == "tiled" ? (double)tiled_ : key == "tile_small" ? (double)tile_small_ : key == "fused" ? (double)fused_ :
+                               key == "pair" ? (double)pair_ : key == "pair_sel" ? (double)pair_sel_ : (double)tiles_per_robot_;
+            const bool flag = key == "wide" || key == "wide_two_tiles" || key == "tile_small" || key == "fused" || key == "pair_sel";
+            if (prepared_ && rounds_done_ > 0 && now != (flag ? (double)(value != 0) : (double)(int)value))
+                throw std::logic_error("option " + key + " must be set before the first vxh_run/vxh_step (or right after vxh_reset)");
+        }
         // (`fused` too, since round 5: the resident kernels keep the bond history in their own array and a saved image of the contact rows, so
         // a robot that changed kernels in the middle of a run would read stale history -- ADVICE round 4)
         if ((key == "wide" || key == "wide_two_tiles" || key == "fused" || key == "pair_sel") && value != 0 && value != 1) throw std::invalid_argument(key + ": 0 or 1");

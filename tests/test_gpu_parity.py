@@ -1203,3 +1203,30 @@ def test_pair_kernel_steps_like_the_resident_kernels(eng_mod, tmp_path, kernel_p
     sim_o = vo.OracleSim.from_vxa(paths[1])
     sim_o.step(300)
     assert _pos_err(runs[2][0][1][1], sim_o.state(), 0.01) < FLOOR_VOX
+
+
+def test_kernel_choice_options_are_part_of_the_assembled_batch(eng_mod, golden_dir, kernel_path):
+    """Which kernel steps a robot decides where its bond history lives (the resident / wide kernels keep 48-byte records of their own, and a
+    saved image of the contact rows; the streaming / tiled ones the planes): once a step has been taken, `fused`, `pair`, `wide`, `tiled`
+    are refused (VXH_ERR_STATE) instead of silently handing a robot another kernel's stale history (round-4 advisor finding for `fused`);
+    right after a reset they are accepted, and an unchanged value is always fine."""
+    if kernel_path != "auto":
+        pytest.skip("the test sets the kernel options itself")
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.add_vxa_file(os.path.join(golden_dir, "vxa", "rand6_col.vxa"))
+        eng.set_option("fused", 1)
+        eng.step(10)
+        for key, val in (("fused", 0), ("pair", 1), ("wide", 0), ("tiled", 0)):
+            with pytest.raises(eng_mod.VxhError):
+                eng.set_option(key, val)
+        eng.set_option("fused", 1)              # unchanged: accepted, the batch stays
+        before = eng.state(0)
+        eng.step(10)
+        eng.reset()
+        eng.set_option("fused", 0)              # right after a reset: accepted
+        eng.step(20)
+        streamed = eng.state(0)
+        eng.reset()
+        eng.set_option("fused", 1)
+        eng.step(20)
+        assert np.abs(eng.state(0)[:, :8] - streamed[:, :8]).max() < 1e-12 and before.shape == streamed.shape
