@@ -42,3 +42,6 @@ python $root/scripts/pmc_sum.py $root/gpurun_out/prof_${tag}_cfg4_sq* > $root/gp
 # on the swimmers): kernel trace + stats of scripts/dev_gpu_diag.py tileprof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_${tag}_tiled -- python $root/scripts/dev_gpu_diag.py tileprof > $root/gpurun_out/prof_${tag}_tiled.log 2>&1
 python $root/scripts/profile_sum.py $root/gpurun_out $tag tiled
+# FP64 flops / vector instructions per voxel-step of every bench workload (what bench.py's roofline.binding multiplies by a run's own rate):
+# two counter passes per workload; condensed locally by scripts/flops_sum.py gpurun_out <tag> into profiles/<tag>_flops_per_unit.json
+$root/scripts/flops_per_unit.sh $tag
