@@ -347,6 +347,15 @@ def test_swimmers_on_tiles_do_not_depend_on_the_tiling(golden_dir):
     whole = _states(eng_mod, paths, {"tiled": 2, "tiles_per_robot": 4, "steps_per_launch": 64}, (700,), variant=1)[-1]
     for x, y in zip(pieces, whole):
         assert np.array_equal(x, y)
+    # the automatic policy with tile_small: a lone 709-voxel swimmer (768-thread class) is tiled -- in a fluid too
+    small = _states(eng_mod, [paths[2]], {"tiled": 1, "tiles_per_robot": 0, "tile_small": 1}, (300,), variant=1)[0][0]
+    lone = _states(eng_mod, [paths[2]], {"tiled": 0, "wide": 0}, (300,), variant=1)[0][0]
+    assert np.abs(small[:, :8] - lone[:, :8]).max() < 1e-12
+    with eng_mod.Engine(1, 0) as eng:
+        eng.set_option("tiled", 1); eng.set_option("tiles_per_robot", 0); eng.set_option("tile_small", 1)
+        eng.add_vxa_file(paths[2])
+        eng.step(10)
+        assert eng.counters().dominant_block == 1
     with eng_mod.Engine(1, 0) as eng:          # (and the tiled kernel is what stepped them)
         eng.set_option("tiled", 2); eng.set_option("tiles_per_robot", 4)
         eng.add_vxa_file(paths[1])
