@@ -1153,3 +1153,12 @@ if __name__ == "__main__" and "swimtimeline" in sys.argv[1:]:
             eng.step(600)
             print("swimtimeline fluid=%d" % fluid, flush=True)
             eng.clear()
+
+
+if __name__ == "__main__" and "cfg3tiles" in sys.argv[1:]:
+    # BASELINE configs[3] (64 random 8^3 swimmers) on the tiled kernel by tiles per robot (fluid tiles, round 5) against the wide kernel
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    for opts in ({}, {"tiled": 2, "tiles_per_robot": 2}, {"tiled": 2, "tiles_per_robot": 3}, {"tiled": 2, "tiles_per_robot": 4}, {"tiled": 2, "tiles_per_robot": 6}):
+        timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, opts, per_voxel_phase=True)
