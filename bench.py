@@ -93,10 +93,52 @@ def run_reference(ref, paths, tmp, concurrency):
     return time.time() - t0
 
 
-def cpu_baseline(shape):
+def live_parity(paths, tmp, device):
+    """The result files the reference binary has just written for the cpu_baseline sample (tmp/fitnessFiles), against the engine's for the
+    same .vxa files, evaluated now on `device`: how many are byte-identical (every tag printed with six significant digits, as the
+    reference prints them), and the largest difference of any numeric tag otherwise.  The reference's files are the checker; the
+    engine's run is not part of any timed figure."""
+    import re
+    from evosoro_amd import engine
+    tag = re.compile(r"<(\w+)>\s*([-+0-9.eE]+|nan|inf|-inf|-nan)\s*</\1>")
+    with engine.Engine(engine.VOXCAD, device) as eng:
+        eng.add_vxa_files(paths)
+        names = [eng.fitness_file_name(i) for i in range(len(paths))]
+        ref_text = []
+        for n in names:
+            with open(n if os.path.isabs(n) else os.path.join(tmp, n)) as f:
+                ref_text.append(f.read())
+        eng.run()
+        steps = sum(eng.result(i).steps for i in range(len(paths)))
+        out_dir = os.path.join(tmp, "engineFitness")
+        os.makedirs(out_dir, exist_ok=True)
+        identical, worst, worst_tag, tags = 0, 0.0, None, 0
+        for i in range(len(paths)):
+            mine = os.path.join(out_dir, "%05d.xml" % i)
+            eng.write_result_xml(i, mine)
+            with open(mine) as f:
+                text = f.read()
+            if text == ref_text[i]:
+                identical += 1
+            a, b = dict(tag.findall(ref_text[i])), dict(tag.findall(text))
+            if set(a) != set(b):
+                raise RuntimeError("result file %d: tags differ from the reference's: %s" % (i, sorted(set(a) ^ set(b))))
+            tags = len(a)
+            for k in a:
+                d = abs(float(a[k]) - float(b[k]))
+                if d > worst:
+                    worst, worst_tag = d, k
+    return {"live": True, "robots": len(paths), "steps": int(steps), "numeric_tags_per_file": tags, "result_files_byte_identical": identical,
+            "worst_tag_difference": worst, "worst_tag": worst_tag,
+            "against": "the reference binary's result files for the cpu_baseline sample (oracle/_ref/voxelyze_ref, this run)",
+            "note": "tags are printed with six significant digits by both; a difference is in the tag's own unit (metres / voxels as the tag says)"}
+
+
+def cpu_baseline(shape, device=None):
     """Reference voxelyze (oracle/_ref) on the host cores.  Sample: 2 x nproc robots of the bench population (at most 512),
     0.12 s of simulated time each (about 1900 steps), nproc processes at a time, like evaluation.py:89 -- sized for roughly
-    10-30 s of wall clock; then ONE robot alone for the single-core figure."""
+    10-30 s of wall clock; then ONE robot alone for the single-core figure.  With a `device`: the result files of that sample
+    are compared with the engine's for the same robots (live_parity), returned under "parity_check"."""
     from evosoro_amd import engine
     ref = os.path.join(REPO, "oracle", "_ref", "voxelyze_ref")
     nproc = os.cpu_count() or 1
@@ -123,13 +165,14 @@ def cpu_baseline(shape):
                     raise RuntimeError("reference finished %d of %d robots" % (done, len(paths)))
             used = min(walls, key=walls.get)
             wall = walls[used]
+            check = live_parity(paths, tmp, device) if device is not None else None
             one = run_reference(ref, paths[:1], tmp, 1)
             # context: the same robot with the optimisation level the reference SHIPS with (its library objects are compiled with an
             # empty CXXFLAGS = -O0); every other figure here is the -O3 build, which flatters the reference
             ref_O0 = ref + "_O0"
             one_O0 = run_reference(ref_O0, paths[:1], tmp, 1) if os.path.exists(ref_O0) else None
             return {"value": work_of(paths) / wall, "unit": "voxel-timesteps/s", "cores": used, "kind": "reference",
-                    "nproc": nproc, "single_core_value": work_of(paths[:1]) / one,
+                    "nproc": nproc, "parity_check": check, "single_core_value": work_of(paths[:1]) / one,
                     "single_core_value_shipped_flags": (work_of(paths[:1]) / one_O0) if one_O0 else None,
                     "sample": "%d random %dx%dx%d robots of the bench population, %.2f s simulated each (%.3g voxel-steps), one process per "
                               "robot (evaluation.py:89), g++ -O3 build of the reference sources, host with %d hardware threads: %s; "
@@ -746,7 +789,10 @@ def main():
                 for entry in out["other_configs"]:
                     entry.pop("_voxel_steps_process", None)
             if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(shape)
+                out["cpu_baseline"] = cpu_baseline(shape, local_rank)
+                check = out["cpu_baseline"].pop("parity_check", None)
+                if check:
+                    out.setdefault("parity", {})["live_check"] = check
             os.write(json_fd, (json.dumps(out) + "\n").encode())
     finally:
         if distributed:

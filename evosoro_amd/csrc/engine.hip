@@ -554,6 +554,17 @@ struct HostStages {
 };
 }
 
+// Workgroups of a k_tile_steps instance one CU keeps resident at `lds` bytes of dynamic LDS, by the runtime's own occupancy rule.
+static long long tile_workgroups_per_cu(int tabg, int mesh, size_t lds)
+{
+    const void* f = mesh == 2 ? (tabg ? (const void*)k_tile_steps<true, true, true> : (const void*)k_tile_steps<false, true, true>)
+                  : mesh == 1 ? (tabg ? (const void*)k_tile_steps<true, true, false> : (const void*)k_tile_steps<false, true, false>)
+                              : (tabg ? (const void*)k_tile_steps<true, false, false> : (const void*)k_tile_steps<false, false, false>);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, VXH_TILE_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n = 1; }
+    return std::max(1, n);
+}
+
 void Engine::prepare()
 {
     HostStages hs;
@@ -1161,12 +1172,13 @@ void Engine::prepare()
             }
         }
         // launches: all tiles of a robot in one launch, a launch no larger than what the chip keeps resident (the tiles of a
-        // robot wait for each other); 226 vector registers: at most two workgroups per CU
+        // robot wait for each other).  How many workgroups of THIS kernel a CU holds is asked of the runtime (registers, wavefront
+        // slots and LDS of the compiled code: five wavefronts of 256 vector registers are one workgroup per CU, whatever the LDS says)
         for (int kind = 0; kind < 6; ++kind) {
             const int tabg = kind & 1, mesh = kind >> 1;      // mesh: 0 _voxcad, 1 land_water on land, 2 land_water in a fluid
             Device::TileLaunch cur;
             cur.tabg = tabg; cur.mesh = mesh;
-            auto capacity = [&](size_t lds) { return (long long)D.n_cu * std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)(lds + VXH_TILE_STATIC_LDS))); };
+            auto capacity = [&](size_t lds) { return (long long)D.n_cu * tile_workgroups_per_cu(tabg, mesh, lds); };
             for (auto& q : planned) {
                 if (q.tabg != tabg || q.mesh != mesh) continue;
                 const int k = q.plan.k;
@@ -1253,6 +1265,9 @@ void Engine::prepare()
             // a launch with no more tiles than CUs: a CU to every tile.  Two tiles that share a CU share its SIMDs, run at half
             // speed, and the whole robot waits for them at every barrier; asking for more than half of the LDS keeps them apart.
             if (L.count <= D.n_cu) L.lds = std::max(L.lds, (size_t)(81 * 1024));
+            if (std::getenv("VXH_PROF_TILES"))
+                std::fprintf(stderr, "vxhip: tile launch kind tabg=%d mesh=%d: %d tiles of %zu robots, %zu B of LDS, %lld workgroups per CU\n", L.tabg, L.mesh, L.count,
+                             L.robots.size(), L.lds, tile_workgroups_per_cu(L.tabg, L.mesh, L.lds));
         }
     }
     {

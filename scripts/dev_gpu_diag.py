@@ -1162,3 +1162,12 @@ if __name__ == "__main__" and "cfg3tiles" in sys.argv[1:]:
     env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
     for opts in ({}, {"tiled": 2, "tiles_per_robot": 2}, {"tiled": 2, "tiles_per_robot": 3}, {"tiled": 2, "tiles_per_robot": 4}, {"tiled": 2, "tiles_per_robot": 6}):
         timing_cfg(engine.VOXCAD_LAND_WATER, 64, (8, 8, 8), 0.1, env_w, opts, per_voxel_phase=True)
+
+
+if __name__ == "__main__" and "tilecap" in sys.argv[1:]:
+    # more tiles in one launch than the chip keeps resident: populations of large robots (VXH_PROF_TILES=1 prints what a CU holds);
+    # VXH_LIB=<path> to compare builds
+    if os.environ.get("VXH_LIB"):
+        engine.LIB_PATH = os.environ["VXH_LIB"]
+    for count, n in ((40, 11), (96, 11), (200, 11), (24, 16)):
+        timing_cfg(engine.VOXCAD, count, (n, n, n), 0.02, Env(), {}, full=True)

@@ -119,3 +119,22 @@ def test_one_rank_over_rccl_with_the_host_side_control_group():
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert "gloo host group" in out["control_plane"] and "RCCL" in out["control_plane"], out["control_plane"]
     assert out["fitness_gather_ms"] is not None and out["fitness_gather_ms"] >= 0
+
+
+@pytest.mark.gpu
+def test_the_bench_lines_live_parity_check(tmp_path):
+    """bench.py's cpu_baseline leg compares the reference binary's result files for its sample with the engine's (parity.live_check):
+    here on six robots of the bench population, 0.06 s simulated -- every file byte-identical."""
+    ref = os.path.join(REPO, "oracle", "_ref", "voxelyze_ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref is not built")
+    sys.path.insert(0, REPO)
+    try:
+        import bench
+    finally:
+        sys.path.remove(REPO)
+    paths = bench.make_population(str(tmp_path), 6, 40, (6, 6, 6), 0.06, 0.02)
+    bench.run_reference(ref, paths, str(tmp_path), 6)
+    check = bench.live_parity(paths, str(tmp_path), 0)
+    assert check["live"] and check["robots"] == 6 and check["numeric_tags_per_file"] >= 10
+    assert check["result_files_byte_identical"] == 6 and check["worst_tag_difference"] == 0.0, check
