@@ -28,6 +28,7 @@ enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_ST
                   // _voxcad development (VXS_Voxel.cpp:236-328): any layer present / which ones
                   RF_DEV = 256, RF_DEV_SIZE = 512 /* Initial- or FinalVoxelSize */, RF_DEV_FSIZE = 1024, RF_DEV_FPHASE = 2048, RF_DEV_FTAD = 4096 };
 
+enum { VXH_ORDER_MAX_STEPS = 128 };  // launches of at most this many steps are dispatched "robots due for a broad-phase run first" (kernels_fused.hpp)
 enum { VXH_RIMG_CAP = 2048 };     // entries of a saved contact-row image (the LDS pool holds at most 24 KB / 12 B)
 
 struct DRobot {               // constant per robot
@@ -62,7 +63,8 @@ struct DRobotState {          // mutable per robot
     double act_sin, act_cos;      // streaming path: sincos of the actuation phase of the current step (actuation_sincos)
     unsigned long long maxvel2_bits;
     int steps, status, cm_init, active, diverged, col_overflow, rebuild_now, rebuilds;
-    int rows_img, pad_rs;         // resident kernel: DBatch::rimg_* hold the LDS image of this robot's contact rows as the last launch left it
+    int rows_img, reb_step;       // resident kernel: DBatch::rimg_* hold the LDS image of this robot's contact rows as the last launch left it;
+                                  // `steps` at the last broad-phase run (the dispatch order of short launches: fused_dispatch_slot)
     int col_tiled, ntrace;        // the contact rows were built by the tiled kernel (DBatch::col_code / tile_xh are valid for them) ; points
                                   // of the centre-of-mass trace recorded so far (SS.CMTrace, VX_Sim.cpp:1537-1547)
     double last_trace_time;

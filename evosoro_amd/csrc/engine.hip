@@ -49,6 +49,10 @@ struct Engine::Device {
         int pair = 0;                     // 1: k_robot_pair<tabg, sel> (kernels_pair.hpp; block = 512 threads, 1024 voxel slots); 2: its SEL form
         int count = 0;
         const int* list = nullptr;
+        // dispatch order of short launches (kernels_fused.hpp fused_dispatch_slot): one bit per list entry, written by a launch for the next
+        unsigned long long* order_bits[2] = {nullptr, nullptr};
+        int order_cur = 0;
+        bool order_valid = false, order_use = false;
         size_t lds = 0;                   // dynamic LDS bytes
         hipStream_t stream = nullptr;
         hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1334,6 +1338,11 @@ void Engine::prepare()
                 return (double)robots_[a].planned_steps * robots_[a].nvox > (double)robots_[b].planned_steps * robots_[b].nvox; });
             g.count = (int)g.robots.size();
             g.list = D.upload(g.robots);
+            g.order_valid = false; g.order_cur = 0; g.order_use = false;
+            if (!g.wide && !g.pair) {       // (k_robot_steps; colliding robots only: the others have no broad-phase runs to spread)
+                for (int r : g.robots) if (robots_[r].vxa.self_col_enabled) g.order_use = true;
+                if (g.order_use) for (int k = 0; k < 2; ++k) g.order_bits[k] = D.alloc_zero<unsigned long long>((size_t)(g.count + 63) / 64 + 1);
+            }
             if (D.group_streams.size() <= gi) {
                 hipStream_t st; hipEvent_t e0, e1;
                 // launch groups of one call are meant to run side by side (two size classes of one population: 64 + 64 workgroups on 256
@@ -1395,11 +1404,12 @@ static void grant_dynamic_lds(const void* kernel, size_t (&granted)[64], size_t 
 }
 
 template <int BLOCK, int NACC, bool FLUID, bool TABG>
-static void launch_variant(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+static void launch_variant(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters,
+                           const unsigned long long* order_in, unsigned long long* order_out)
 {
     static size_t granted[64] = {};
     grant_dynamic_lds((const void*)k_robot_steps<BLOCK, NACC, FLUID, TABG>, granted, lds);
-    hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
+    hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8), order_in, order_out);
 }
 
 template <bool TABG, bool MESH, bool FLUID = false>
@@ -1411,12 +1421,13 @@ static void launch_tiles(const DBatch& B, const int* list, int count, size_t lds
 }
 
 template <bool FLUID, bool TABG>
-static void launch_sized(const DBatch& B, int block, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
+static void launch_sized(const DBatch& B, int block, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters,
+                         const unsigned long long* order_in, unsigned long long* order_out)
 {
-    if (block == 256) launch_variant<256, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
-    else if (block == 512) launch_variant<512, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
-    else if (block == 768) launch_variant<768, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters);
-    else launch_variant<1024, 1, FLUID, TABG>(B, list, count, lds, s, cap, iters);
+    if (block == 256) launch_variant<256, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters, order_in, order_out);
+    else if (block == 512) launch_variant<512, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters, order_in, order_out);
+    else if (block == 768) launch_variant<768, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters, order_in, order_out);
+    else launch_variant<1024, 1, FLUID, TABG>(B, list, count, lds, s, cap, iters, order_in, order_out);
 }
 
 template <int BLOCK, bool MESH, bool TABG>
@@ -1435,7 +1446,8 @@ static void launch_pair(const DBatch& B, const int* list, int count, size_t lds,
     hipLaunchKernelGGL((k_robot_pair<TABG, SEL>), dim3(count), dim3(VXH_PAIR_T), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
 }
 
-static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool wide, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles = 0, int pair = 0)
+static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool wide, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles = 0, int pair = 0,
+                         const unsigned long long* order_in = nullptr, unsigned long long* order_out = nullptr)
 {
     if (pair) {
         if (pair == 2) { if (tabg) launch_pair<true, true>(B, list, count, lds, s, cap, iters); else launch_pair<false, true>(B, list, count, lds, s, cap, iters); }
@@ -1447,8 +1459,8 @@ static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool
         else { if (tabg) launch_wide<512, false, true>(B, list, count, lds, s, cap, iters, two_tiles); else launch_wide<512, false, false>(B, list, count, lds, s, cap, iters, two_tiles); }
         return;
     }
-    if (fluid) { if (tabg) launch_sized<true, true>(B, block, list, count, lds, s, cap, iters); else launch_sized<true, false>(B, block, list, count, lds, s, cap, iters); }
-    else { if (tabg) launch_sized<false, true>(B, block, list, count, lds, s, cap, iters); else launch_sized<false, false>(B, block, list, count, lds, s, cap, iters); }
+    if (fluid) { if (tabg) launch_sized<true, true>(B, block, list, count, lds, s, cap, iters, order_in, order_out); else launch_sized<true, false>(B, block, list, count, lds, s, cap, iters, order_in, order_out); }
+    else { if (tabg) launch_sized<false, true>(B, block, list, count, lds, s, cap, iters, order_in, order_out); else launch_sized<false, false>(B, block, list, count, lds, s, cap, iters, order_in, order_out); }
 }
 
 // A call in two halves: advance_launch enqueues every kernel of the call and returns; advance_finish waits for the device, reads
@@ -1523,8 +1535,13 @@ void Engine::advance_launch(long long max_rounds)
         }
         for (long long done = 0; done < todo || done == 0; done += iters) {
             for (size_t k = 0; k < D.groups.size(); ++k) {
-                const auto& g = D.groups[k];
-                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.wide != 0, g.list, g.count, g.lds, single ? D.stream : g.stream, cap, iters, g.two_tiles, g.pair);
+                auto& g = D.groups[k];
+                // a short launch (what is left of the call, or the launch length itself): flagged robots first, flags for the next one
+                const long long len = std::min<long long>(iters, std::max<long long>(1, todo - done));
+                const bool dyn = g.order_use && len <= VXH_ORDER_MAX_STEPS;
+                launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.wide != 0, g.list, g.count, g.lds, single ? D.stream : g.stream, cap, iters, g.two_tiles, g.pair,
+                             (dyn && g.order_valid) ? g.order_bits[g.order_cur] : nullptr, dyn ? g.order_bits[g.order_cur ^ 1] : nullptr);
+                if (dyn) { g.order_cur ^= 1; g.order_valid = true; } else g.order_valid = false;
                 ++launches; ++group_launches[k];
             }
         }

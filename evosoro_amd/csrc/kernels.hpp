@@ -846,7 +846,7 @@ __device__ __forceinline__ void step_control_horizon(const DRobot& R, DRobotStat
         const double mv = vsqrt_nn(__longlong_as_double((long long)rs.maxvel2_bits));
         rs.max_disp += fabs(vdiv(mv * dt_prev, R.lat));
         rs.maxvel2_bits = 0ull;
-        if (!(R.flags & RF_HORIZON_COL) || rs.max_disp > (R.col_horizon - 1.0) / 2) { c.rebuild = 1; rs.max_disp = 0.0; rs.rebuilds += 1; rs.col_tiled = 0; }
+        if (!(R.flags & RF_HORIZON_COL) || rs.max_disp > (R.col_horizon - 1.0) / 2) { c.rebuild = 1; rs.max_disp = 0.0; rs.rebuilds += 1; rs.col_tiled = 0; rs.reb_step = rs.steps; }
     }
     rs.rebuild_now = c.rebuild;
 }

@@ -866,10 +866,36 @@ __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotSta
 }
 __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K) { fused_control_horizon(R, rs, K, rs.dt_prev); }
 
+// Dispatch order of SHORT launches (a call of a few dozen steps: one launch, two robots per CU one after the other).  A broad-phase run
+// is ~42 us, a sixth of a 20-step launch, and the launch ends with its slowest CU: with the robots in their fixed list order the last
+// workgroups to be dispatched -- which land on the CUs that a run has already delayed -- bring runs of their own four times out of five
+// (scripts/dev_gpu_diag.py launchcost: 69 us of fixed cost per launch against 20 without collisions).  So every workgroup leaves a bit at
+// the end of a launch: "my robot is due for a run within the next launch" (its displacement since the last run, extrapolated at the
+// average rate since then), and the next launch takes the flagged robots FIRST: workgroup i steps the i-th flagged robot of the list,
+// or the (i - flagged)-th unflagged one.  Every workgroup reads the same words (written by the PREVIOUS launch, two buffers), so the
+// assignment is a permutation whatever the bits are; the robots do not interact, so the order changes no result.
+__device__ __forceinline__ int fused_dispatch_slot(const unsigned long long* __restrict__ bits, int count, int i)
+{
+    const int nw = (count + 63) >> 6;
+    int flagged = 0;
+    for (int w = 0; w < nw; ++w) flagged += __builtin_popcountll(bits[w]);
+    const bool set = i < flagged;
+    int k = set ? i : i - flagged;
+    for (int w = 0; w < nw; ++w) {
+        unsigned long long x = set ? bits[w] : ~bits[w];
+        if (!set && w == nw - 1 && (count & 63)) x &= (1ull << (count & 63)) - 1;
+        const int c = __builtin_popcountll(x);
+        if (k < c) { for (int j = 0; j < k; ++j) x &= x - 1; return (w << 6) + __builtin_ctzll(x); }
+        k -= c;
+    }
+    return i;      // (not reached: flagged + unflagged == count)
+}
+
 template <int BLOCK, int NACC, bool MESH, bool TABG>
 __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBatch B, const DRobot* __restrict__ robots,
                                                                             const int* __restrict__ robot_list, long long step_cap, int iters,
-                                                                            int lds_doubles)
+                                                                            int lds_doubles, const unsigned long long* __restrict__ order_in,
+                                                                            unsigned long long* order_out)
 {
     extern __shared__ __align__(16) double lds[];
     double* const ps = lds;
@@ -893,7 +919,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #ifdef VXH_PHASE_TIMING
     const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
-    const int r = __builtin_amdgcn_readfirstlane(robot_list[blockIdx.x]);   // robots of one launch group, longest-running first; uniform -> scalar loads of R
+    const int slot = order_in ? __builtin_amdgcn_readfirstlane(fused_dispatch_slot(order_in, (int)gridDim.x, (int)blockIdx.x)) : (int)blockIdx.x;
+    const int r = __builtin_amdgcn_readfirstlane(robot_list[slot]);   // robots of one launch group, longest-running first; uniform -> scalar loads of R
     const DRobot& R = robots[r];            // separate noalias argument: its loads stay scalar although the kernel stores to HBM
     const unsigned nv = B.nv;
     const int base = R.vox_begin;
@@ -1079,7 +1106,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
     unsigned long long reb_cycles = 0;
     if (!MESH && B.prof && (tid & 63) == 0) atomicAdd(&B.prof[(tid >> 6) * 8 + 6], __builtin_readcyclecounter() - t_entry);   // prologue
 #endif
-    for (int it = 0;; ++it) {
+    int it = 0;
+    for (;; ++it) {
         const FusedCtl& K = s_ctl[it & 1];
         FusedCtl& Knext = s_ctl[(it + 1) & 1];
         const int kf = __builtin_amdgcn_readfirstlane(K.flags);
@@ -1276,7 +1304,20 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
 #pragma unroll
     for (int a = 0; a < 3; ++a)
         if (entry[a] != -1) B.small_angle[(unsigned)a * nv + (base + (entry[a] & 1023))] = (unsigned char)((modebits >> (2 * a)) & 3u);
-    if (tid == 0) { B.rstate[r] = rs; if (B.rstate_mirror) B.rstate_mirror[r] = rs; }
+    if (tid == 0) {
+        B.rstate[r] = rs; if (B.rstate_mirror) B.rstate_mirror[r] = rs;
+        if (order_out) {       // due for a broad-phase run within a launch like this one?  (see fused_dispatch_slot)
+            bool soon = false;
+            if (rs.status == 0 && (R.flags & RF_SELF_COL) && (R.flags & RF_HORIZON_COL)) {
+                const double rate = rs.max_disp / (double)max(1, rs.steps - rs.reb_step);
+                soon = rs.max_disp + rate * (1.25 * (double)max(1, it)) > (R.col_horizon - 1.0) / 2;      // (`it`: the steps of this launch)
+            }
+            // (the slot is worked out again rather than kept: a scalar register held across the step loop costs the loop a spill)
+            const int my = order_in ? fused_dispatch_slot(order_in, (int)gridDim.x, (int)blockIdx.x) : (int)blockIdx.x;
+            const unsigned long long bit = 1ull << (my & 63);
+            if (soon) atomicOr(&order_out[my >> 6], bit); else atomicAnd(&order_out[my >> 6], ~bit);
+        }
+    }
 #ifdef VXH_PHASE_TIMING
     __builtin_amdgcn_s_waitcnt(0);          // (the write-back has left the wavefront)
     if (!MESH && B.prof && (tid & 63) == 0) atomicAdd(&B.prof[(tid >> 6) * 8 + 7], __builtin_readcyclecounter() - t_loop_end);   // epilogue

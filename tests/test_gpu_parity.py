@@ -1230,3 +1230,30 @@ def test_kernel_choice_options_are_part_of_the_assembled_batch(eng_mod, golden_d
         eng.set_option("fused", 1)
         eng.step(20)
         assert np.abs(eng.state(0)[:, :8] - streamed[:, :8]).max() < 1e-12 and before.shape == streamed.shape
+
+
+def test_short_calls_dispatch_due_robots_first_and_change_nothing(eng_mod, tmp_path, kernel_path):
+    """Launches of at most VXH_ORDER_MAX_STEPS steps hand the robots that are due for a broad-phase run to the first workgroups
+    (kernels_fused.hpp fused_dispatch_slot; the bits are written by the previous launch).  The assignment must be a permutation -- every
+    robot steps exactly once per launch -- and, the robots being independent, invisible: 70 colliding robots (a list that does not fill
+    its last 64-bit word) stepped 24 x 25 steps come out bit for bit as stepped 600 steps in one call, broad-phase runs included."""
+    if kernel_path != "auto":
+        pytest.skip("resident kernels: the default path")
+    from evosoro_amd import workloads
+    from evosoro_amd.base import Sim, Env
+    sim, env = Sim(dt_frac=0.9, simulation_time=0.2, fitness_eval_init_time=0.004), Env()
+    paths = [_write_robot(tmp_path, k, workloads.random_material((10, 10, 10), 9100 + k, p_empty=0.25 + 0.002 * k), sim, env, "od") for k in range(70)]
+    outs = []
+    for pieces in ([25] * 24, [600]):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 0)
+            for p in paths:
+                eng.add_vxa_file(p)
+            assert all(eng.dims(i)["nvox"] > 512 for i in range(len(paths)))        # (k_robot_steps, not the wide kernel)
+            for n in pieces:
+                eng.step(n)
+            assert [eng.result(i).steps for i in range(len(paths))] == [600] * len(paths)
+            outs.append(([eng.state(i) for i in range(len(paths))], [eng.result(i).col_rebuilds for i in range(len(paths))]))
+    assert outs[0][1] == outs[1][1] and max(outs[0][1]) >= 2
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
