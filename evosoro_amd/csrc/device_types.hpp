@@ -28,7 +28,8 @@ enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_ST
                   // _voxcad development (VXS_Voxel.cpp:236-328): any layer present / which ones
                   RF_DEV = 256, RF_DEV_SIZE = 512 /* Initial- or FinalVoxelSize */, RF_DEV_FSIZE = 1024, RF_DEV_FPHASE = 2048, RF_DEV_FTAD = 4096 };
 
-enum { VXH_ORDER_MAX_STEPS = 128 };  // launches of at most this many steps are dispatched "robots due for a broad-phase run first" (kernels_fused.hpp)
+enum { VXH_ORDER_MAX_STEPS = 128,    // launches of at most this many steps are dispatched "robots due for a broad-phase run first" (kernels_fused.hpp)
+       VXH_ORDER_HORIZON = 32 };     // ... and what a longer launch calls "due" when it leaves the flags for the launch behind it
 enum { VXH_RIMG_CAP = 2048 };     // entries of a saved contact-row image (the LDS pool holds at most 24 KB / 12 B)
 
 struct DRobot {               // constant per robot

@@ -1538,10 +1538,10 @@ void Engine::advance_launch(long long max_rounds)
                 auto& g = D.groups[k];
                 // a short launch (what is left of the call, or the launch length itself): flagged robots first, flags for the next one
                 const long long len = std::min<long long>(iters, std::max<long long>(1, todo - done));
-                const bool dyn = g.order_use && len <= VXH_ORDER_MAX_STEPS;
+                const bool dyn = g.order_use && g.order_valid && len <= VXH_ORDER_MAX_STEPS;
                 launch_group(B, g.block, g.fluid != 0, g.tabg != 0, g.wide != 0, g.list, g.count, g.lds, single ? D.stream : g.stream, cap, iters, g.two_tiles, g.pair,
-                             (dyn && g.order_valid) ? g.order_bits[g.order_cur] : nullptr, dyn ? g.order_bits[g.order_cur ^ 1] : nullptr);
-                if (dyn) { g.order_cur ^= 1; g.order_valid = true; } else g.order_valid = false;
+                             dyn ? g.order_bits[g.order_cur] : nullptr, g.order_use ? g.order_bits[g.order_cur ^ 1] : nullptr);
+                if (g.order_use) { g.order_cur ^= 1; g.order_valid = true; }      // (every launch leaves the flags for the next)
                 ++launches; ++group_launches[k];
             }
         }

@@ -870,8 +870,8 @@ __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotSta
 // is ~42 us, a sixth of a 20-step launch, and the launch ends with its slowest CU: with the robots in their fixed list order the last
 // workgroups to be dispatched -- which land on the CUs that a run has already delayed -- bring runs of their own four times out of five
 // (scripts/dev_gpu_diag.py launchcost: 69 us of fixed cost per launch against 20 without collisions).  So every workgroup leaves a bit at
-// the end of a launch: "my robot is due for a run within the next launch" (its displacement since the last run, extrapolated at the
-// average rate since then), and the next launch takes the flagged robots FIRST: workgroup i steps the i-th flagged robot of the list,
+// the end of EVERY launch: "my robot is due for a run within a launch like this one, or within VXH_ORDER_HORIZON steps if this one was
+// longer" (its displacement since the last run, extrapolated at the average rate since then), and a SHORT launch takes the flagged robots FIRST: workgroup i steps the i-th flagged robot of the list,
 // or the (i - flagged)-th unflagged one.  Every workgroup reads the same words (written by the PREVIOUS launch, two buffers), so the
 // assignment is a permutation whatever the bits are; the robots do not interact, so the order changes no result.
 __device__ __forceinline__ int fused_dispatch_slot(const unsigned long long* __restrict__ bits, int count, int i)
@@ -1310,7 +1310,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             bool soon = false;
             if (rs.status == 0 && (R.flags & RF_SELF_COL) && (R.flags & RF_HORIZON_COL)) {
                 const double rate = rs.max_disp / (double)max(1, rs.steps - rs.reb_step);
-                soon = rs.max_disp + rate * (1.25 * (double)max(1, it)) > (R.col_horizon - 1.0) / 2;      // (`it`: the steps of this launch)
+                // (`it`: the steps of this launch; a long launch -- whose own order does not matter -- leaves the flags for a short one behind it)
+                soon = rs.max_disp + rate * (1.25 * (double)min(max(1, it), (int)VXH_ORDER_HORIZON)) > (R.col_horizon - 1.0) / 2;
             }
             // (the slot is worked out again rather than kept: a scalar register held across the step loop costs the loop a spill)
             const int my = order_in ? fused_dispatch_slot(order_in, (int)gridDim.x, (int)blockIdx.x) : (int)blockIdx.x;
