@@ -1310,8 +1310,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             bool soon = false;
             if (rs.status == 0 && (R.flags & RF_SELF_COL) && (R.flags & RF_HORIZON_COL)) {
                 const double rate = rs.max_disp / (double)max(1, rs.steps - rs.reb_step);
-                // (`it`: the steps of this launch; a long launch -- whose own order does not matter -- leaves the flags for a short one behind it)
-                soon = rs.max_disp + rate * (1.25 * (double)min(max(1, it), (int)VXH_ORDER_HORIZON)) > (R.col_horizon - 1.0) / 2;
+                // (`it`: the steps of this launch; a long launch -- whose own order does not matter -- leaves the flags for a short one behind it.
+                // Generous: a robot flagged for nothing costs nothing, a run in the second round of a late CU costs the launch 42 us; 2.5 against
+                // 1.25 launch lengths: the driver's command 1.383-1.405e10 against 1.380-1.403e10, same box, alternating)
+                soon = rs.max_disp + rate * (2.5 * (double)min(max(1, it), (int)VXH_ORDER_HORIZON)) > (R.col_horizon - 1.0) / 2;
             }
             // (the slot is worked out again rather than kept: a scalar register held across the step loop costs the loop a spill)
             const int my = order_in ? fused_dispatch_slot(order_in, (int)gridDim.x, (int)blockIdx.x) : (int)blockIdx.x;
