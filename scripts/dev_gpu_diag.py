@@ -1171,3 +1171,60 @@ if __name__ == "__main__" and "tilecap" in sys.argv[1:]:
         engine.LIB_PATH = os.environ["VXH_LIB"]
     for count, n in ((40, 11), (96, 11), (200, 11), (24, 16)):
         timing_cfg(engine.VOXCAD, count, (n, n, n), 0.02, Env(), {}, full=True)
+
+
+if __name__ == "__main__" and "sweepcase" in sys.argv[1:]:
+    # one robot of a wider campaign of tests/test_gpu_parity.py test_land_water_parameter_sweep_vs_oracle (VXH_SWEEP_SEED / _COUNT / _MAXDIM) that
+    # missed its bar: sweepcase <seed> <count> <maxdim> <index> [steps] -- regenerated with the test's generator, then ONE step of engine and
+    # oracle from the same state, step after step (what differs first, and how much the oracle itself moves under a one-ulp jitter), and the
+    # free-running difference at the end
+    from collections import OrderedDict
+    seed, count, maxdim, index = (int(a) for a in sys.argv[2:6])
+    nsteps = int(sys.argv[6]) if len(sys.argv) > 6 else 150
+    rng = np.random.RandomState(seed)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    path = None
+    for k in range(count):
+        shape = tuple(int(n) for n in rng.randint(2, maxdim, size=3))
+        sim_p = Sim(dt_frac=float(np.round(rng.uniform(0.3, 0.95), 2)), simulation_time=0.05,
+                    fitness_eval_init_time=float(np.round(rng.uniform(0.0, 0.01), 3)), self_collisions_enabled=bool(rng.randint(2)))
+        env_p = Env(frequency=float(np.round(rng.uniform(2, 8), 1)), gravity_enabled=int(rng.randint(2)), temp_enabled=int(rng.randint(2)),
+                    floor_enabled=int(rng.randint(2)), temp_amp=float(np.round(rng.uniform(26, 45), 0)))
+        if rng.randint(3) > 0:
+            env_p.add_param("fluid_environment", 1, "<FluidEnvironment>")
+            env_p.add_param("aggregate_drag_coefficient", float(rng.choice([50.0, 750.0, 3000.0])), "<AggregateDragCoefficient>")
+        layers = OrderedDict()
+        if rng.randint(2):
+            layers["<PhaseOffset>"] = np.round(rng.uniform(-1, 1, size=shape), 3)
+        if rng.randint(2):
+            layers["<Stiffness>"] = np.round(10 ** rng.uniform(6.0, 8.0, size=shape), 0)
+        ind = workloads.make_individual(k, workloads.random_material(shape, 300 + k, 0.2), layers or None)
+        if k == index:
+            write_voxelyze_file(sim_p, env_p, ind, tmp, "w")
+            path = os.path.join(tmp, "voxelyzeFiles", "w--id_%05i.vxa" % k)
+            print("robot %d: shape %s, dt_frac %.2f, selfcol %s, gravity %d temp %d floor %d, extra %s, layers %s" % (
+                k, shape, sim_p.dt_frac, sim_p.self_collisions_enabled, env_p.gravity_enabled, env_p.temp_enabled, env_p.floor_enabled,
+                [(p, v) for p, v in getattr(env_p, "new_param_tag_dict", {}).items()] if hasattr(env_p, "new_param_tag_dict") else "?", list(layers)), flush=True)
+    model = vo.parse_vxa(path, 1)
+    lat = model["lattice_dim"]
+    sim, twin, free = vo.OracleSim(model), vo.OracleSim(model), vo.OracleSim(model)
+    with engine.Engine(engine.VOXCAD_LAND_WATER, 0) as eng:
+        eng.add_vxa_file(path)
+        print("nvox %d nbond %d, kernel %s" % (eng.dims(0)["nvox"], eng.dims(0)["nbond"], eng.counters().dominant_block), flush=True)
+        prev = sim.state()
+        for step in range(1, nsteps + 1):
+            eng.step(1)
+            got = eng.state(0)
+            sim.set_state(prev); sim.step(1)
+            want = sim.state()
+            twin.set_state(prev); twin.step_jittered(1, seed=step)
+            free.step(1)
+            own = np.abs(twin.state() - want)[:, :3].max() / lat
+            dp = np.abs(got - want)[:, :3].max() / lat
+            fr = np.abs(got - free.state())[:, :3].max() / lat
+            if dp > 5e-14 or own > 5e-14 or step in (1, 3, 20, 60, 100, 150) or step == nsteps:
+                v = int(np.argmax(np.abs(got - want)[:, :3].max(axis=1)))
+                print("step %3d: one step engine - oracle %.3e voxel (voxel %d, z/lat %.4f); oracle under a one-ulp jitter %.3e; free-running difference %.3e" % (
+                    step, dp, v, prev[v, 2] / lat, own, fr), flush=True)
+            prev = got

@@ -63,6 +63,22 @@ def _spread(model, checkpoints):
     return pos, quat
 
 
+def _jitter_spread(model, upto):
+    """Position deviation after `upto` steps of the oracle from a twin of itself whose first three steps start from positions moved by one
+    ulp each, up or down at random (vxo_jitter): the conditioning probe for robots whose instability the one-input twin of _spread does not
+    excite.  Found by a wider campaign of the land_water sweep (VXH_SWEEP_SEED=34, 120 robots): a 3 x 5 x 3 block resting on the floor
+    keeps its symmetry under a change of g, and its buckling mode -- which amplifies rounding-size differences 3000-fold every 40 steps --
+    only starts from a perturbation that breaks the symmetry, as any other arithmetic's roundings do.  The engine was 1e-15 voxel from
+    the oracle on EVERY single step from the same state (scripts/dev_gpu_diag.py sweepcase) and 7e-4 voxel after 150 free-running steps,
+    where the one-input twin had moved by 1.5e-9.  Used only for a robot that misses the bar that follows from _spread."""
+    from oracle import vxoracle as vo
+    a, c = vo.OracleSim(model), vo.OracleSim(model)
+    c.step_jittered(min(3, upto), seed=7)
+    a.step(upto)
+    c.step(upto - c.info().steps)
+    return _pos_err(a.state(), c.state(), model["lattice_dim"])
+
+
 def test_early_steps_match_oracle(eng_mod, golden_dir):
     from oracle import vxoracle as vo
     models = [vo.parse_vxa(os.path.join(golden_dir, "vxa", n + ".vxa")) for n in CASES]
@@ -692,6 +708,7 @@ def test_parameter_sweep_vs_oracle(eng_mod, tmp_path):
     models = [vo.parse_vxa(p) for p in paths]
     sims = [vo.OracleSim(m) for m in models]
     spreads = [_spread(m, (60, 150))[0] for m in models]
+    jittered = set()
     with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
         eng.add_vxa_files(paths)
         for upto in (1, 3, 20, 150):
@@ -701,8 +718,12 @@ def test_parameter_sweep_vs_oracle(eng_mod, tmp_path):
                 lat = models[i]["lattice_dim"]
                 tol = FLOOR_VOX if upto <= 20 else max(FLOOR_VOX, 20 * spreads[i])
                 err = _pos_err(eng.state(i), o.state(), lat)
+                if err > tol and upto > 20:        # (a robot whose instability the one-input twin does not excite: _jitter_spread)
+                    tol = max(tol, 20 * _jitter_spread(models[i], upto))
+                    jittered.add(i)
                 assert err <= tol, (i, upto, err, tol, paths[i])
     assert sum(1 for sp in spreads if sp < 1e-10) >= 0.75 * count      # the strict bar applied to most of them
+    assert len(jittered) <= max(1, count // 40)                        # ... and the symmetry-breaking probe was needed for next to none
 
 
 def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
@@ -737,6 +758,7 @@ def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
     models = [vo.parse_vxa(p, 1) for p in paths]
     sims = [vo.OracleSim(m) for m in models]
     spreads = [_spread(m, (60, 150))[0] for m in models]
+    jittered = set()
     with eng_mod.Engine(eng_mod.VOXCAD_LAND_WATER, 0) as eng:
         eng.add_vxa_files(paths)
         for upto in (1, 3, 20, 150):
@@ -745,8 +767,12 @@ def test_land_water_parameter_sweep_vs_oracle(eng_mod, tmp_path):
                 o.step(upto - o.info().steps)
                 tol = FLOOR_VOX if upto <= 20 else max(FLOOR_VOX, 20 * spreads[i])
                 err = _pos_err(eng.state(i), o.state(), models[i]["lattice_dim"])
+                if err > tol and upto > 20:
+                    tol = max(tol, 20 * _jitter_spread(models[i], upto))
+                    jittered.add(i)
                 assert err <= tol, (i, upto, err, tol, paths[i])
     assert sum(1 for sp in spreads if sp < 1e-10) >= 0.75 * count
+    assert len(jittered) <= max(1, count // 40)
 
 
 def test_in_memory_hand_off_builds_the_same_robots(eng_mod, tmp_path):
