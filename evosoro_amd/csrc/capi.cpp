@@ -261,7 +261,18 @@ int vxh_write_result_xml(const vxh_engine* ce, int robot, const char* path_or_nu
     std::string path = path_or_null ? path_or_null : m.vxa.fitness_file_name;
     if (path.empty()) { e->last_error = "no FitnessFileName in the .vxa and no path given"; return VXH_ERR_IO; }
     std::string text;
-    rc = guarded(e, [&] { text = vxh::result_xml(m, res, e->impl->trace_of(robot)); });
+    std::vector<double> ex_end;       // land_water: angle excesses of the final mesh (the curvatures file below; its first value is <ShapeComplexityEnd>)
+    rc = guarded(e, [&] {
+        double shape_start = -1.0, shape_end = -1.0;
+        if (m.vxa.variant == 1 && m.nmv > 0) {
+            std::vector<double> ex_start;
+            vxh::mesh_angle_excess(m, nullptr, nullptr, nullptr, ex_start);
+            ex_end = e->impl->angle_excess(robot, true);
+            shape_start = vxh::shape_complexity_as_the_reference_prints_it(m, ex_start);
+            shape_end = vxh::shape_complexity_as_the_reference_prints_it(m, ex_end);
+        }
+        text = vxh::result_xml(m, res, e->impl->trace_of(robot), shape_start, shape_end);
+    });
     if (rc != VXH_OK) return rc;
     std::FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) { e->last_error = "cannot write " + path; return VXH_ERR_IO; }
@@ -272,11 +283,8 @@ int vxh_write_result_xml(const vxh_engine* ce, int robot, const char* path_or_nu
     // significant digits, as CVX_MeshUtil::computeShapeComplexity leaves them for curvatureEntropy.py (LW/VX_MeshUtil.cpp:1016-1031;
     // the reference then runs that script -- absent from its repository -- and removes the file; here the file stays)
     if (m.vxa.variant == 1 && !m.vxa.curvatures_tmp_file.empty() && m.nmv > 0) {
-        std::vector<double> ex;
-        rc = guarded(e, [&] { ex = e->impl->angle_excess(robot, true); });
-        if (rc != VXH_OK) return rc;
         if (std::FILE* c = std::fopen(m.vxa.curvatures_tmp_file.c_str(), "wb")) {      // (an unwritable path: skipped, like the reference's `return -1`)
-            for (double v : ex) std::fprintf(c, "%g\t", v);
+            for (double v : ex_end) std::fprintf(c, "%g\t", v);
             std::fclose(c);
         }
     }

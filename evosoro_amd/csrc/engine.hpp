@@ -164,7 +164,8 @@ int hip_device_count();      // engine.hip: HIP devices this process can use (0 
 
 // results.cpp: the numbers of CVX_SimGA::WriteResultFile from a final state, and the XML text
 void compute_result(const RobotModel& model, const HostState& st, vxh_result* out);
-std::string result_xml(const RobotModel& model, const vxh_result& res, const std::vector<double>& cm_trace);
+std::string result_xml(const RobotModel& model, const vxh_result& res, const std::vector<double>& cm_trace, double shape_start = -1.0, double shape_end = -1.0);
+double shape_complexity_as_the_reference_prints_it(const RobotModel& model, const std::vector<double>& angle_excess);
 const std::vector<double>& empty_trace();
 double convex_hull_volume(const std::vector<double>& xyz);   // results.cpp: what stands in for the reference's external qhull
 // results.cpp: per-vertex angle excess of the surface mesh (LW/VX_MeshUtil.cpp:956-1014); pos / quat / strain null = the rest state

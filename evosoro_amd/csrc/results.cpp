@@ -318,7 +318,22 @@ void tag(std::string& out, const char* name, double value)
 
 const std::vector<double>& empty_trace() { static const std::vector<double> none; return none; }
 
-std::string result_xml(const RobotModel& M, const vxh_result& r, const std::vector<double>& cm_trace)
+// <ShapeComplexityStart/End> as the reference binary prints them when it is built from its repository: computeShapeComplexity
+// (LW/VX_MeshUtil.cpp:1016-1076) writes the angle excesses to <CurvaturesTmpFile> (six significant digits each, tab-separated), runs
+// `python <base>/../curvatureEntropy.py <file>` -- a script the repository does not contain, so the call fails and the file stays as it
+// is --, waits a second and reads ONE number back from the file: the first vertex's angle excess as printed.  (Seen in every result
+// file the reference writes here: tests/golden/expected/lw_*.xml carry the first value of their *.curv_start / *.curv_end vectors.)
+// -1 where the reference returns it: no <CurvaturesTmpFile>, no vertex, a value the stream extraction rejects.
+double shape_complexity_as_the_reference_prints_it(const RobotModel& M, const std::vector<double>& angle_excess)
+{
+    if (M.vxa.curvatures_tmp_file.empty() || angle_excess.empty()) return -1.0;
+    char text[64];
+    std::snprintf(text, sizeof(text), "%g", angle_excess[0]);
+    if (!std::isfinite(angle_excess[0])) return -1.0;            // ("nan" / "inf": operator>> fails and leaves the -1 it started from)
+    return std::strtod(text, nullptr);
+}
+
+std::string result_xml(const RobotModel& M, const vxh_result& r, const std::vector<double>& cm_trace, double shape_start, double shape_end)
 {
     std::string out = "<?xml version=\"1.0\" ?>\n<Voxelyze_Sim_Result Version=\"1.0\">\n    <Fitness>\n";
     if (M.vxa.variant == 0) {
@@ -345,13 +360,13 @@ std::string result_xml(const RobotModel& M, const vxh_result& r, const std::vect
         tag(out, "normDistY", r.norm_dist_y);
         tag(out, "normDistZ", r.norm_dist_z);
         // the hull volumes: the reference shells out to qhull (and prints -1 when that is not installed), here computed in place;
-        // the shape complexity needs curvatureEntropy.py, an external script that the reference repository does not contain: -1
+        // the shape complexity: what the reference prints without its absent entropy script (shape_complexity_as_the_reference_prints_it)
         tag(out, "RobotVolumeStart", r.robot_volume_start);
         tag(out, "ConvexHullVolumeStart", r.hull_volume_start);
         tag(out, "RobotVolumeEnd", r.robot_volume_end);
         tag(out, "ConvexHullVolumeEnd", r.hull_volume_end);
-        tag(out, "ShapeComplexityStart", -1);
-        tag(out, "ShapeComplexityEnd", -1);
+        tag(out, "ShapeComplexityStart", shape_start);
+        tag(out, "ShapeComplexityEnd", shape_end);
     }
     out += "    </Fitness>\n";
     if (M.vxa.variant == 0 && M.vxa.time_between_traces > 0 && M.vxa.save_traces) {     // VX_SimGA.cpp:170-184

@@ -71,12 +71,14 @@ typedef struct vxh_result {
     int reserved;
     double hull_volume_start, hull_volume_end;     /* <ConvexHullVolumeStart/End>: convex hull of the surface-mesh vertices, which the
                                                       reference gets from an external qhull (LW/VX_MeshUtil.cpp:775-900); the
-                                                      <ShapeComplexity*> tags are printed as -1 (their script is not in the reference) */
+                                                      <ShapeComplexity*> tags: see vxh_get_angle_excess */
 } vxh_result;
 /* land_water shape descriptor, per vertex of the deformable surface mesh: the angle excess 2 pi - sum of the angles of the facets
  * meeting in the vertex, exactly as CVX_MeshUtil::computeShapeComplexity forms it (LW/VX_MeshUtil.cpp:956-1014) before handing the
- * vector to curvatureEntropy.py through <CurvaturesTmpFile> (:1016-1036).  That script is not in the reference repository, so the
- * <ShapeComplexityStart/End> tags stay -1; the vector is what can be computed and pinned: at_end = 0 the rest state (what
+ * vector to curvatureEntropy.py through <CurvaturesTmpFile> (:1016-1036).  That script is not in the reference repository: its call fails,
+ * the reference reads ONE number back from the file it wrote itself, and <ShapeComplexityStart/End> are the first vertex's angle excess
+ * as printed (six digits) -- which is what vxh_write_result_xml prints too (-1 without a <CurvaturesTmpFile>, as the reference).  The
+ * vector is what can be computed and pinned: at_end = 0 the rest state (what
  * computeInitialShapeComplexity sees, voxelyzeMain/main.cpp:65), 1 the state after the last step (computeFinalShapeComplexity, :117).
  * `count_out` receives the number of mesh vertices (0 for a _voxcad robot); at most `capacity` values are written.
  * vxh_write_result_xml also writes the final vector to the robot's <CurvaturesTmpFile>, tab-separated, six significant digits. */

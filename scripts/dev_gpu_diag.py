@@ -1228,3 +1228,77 @@ if __name__ == "__main__" and "sweepcase" in sys.argv[1:]:
                 print("step %3d: one step engine - oracle %.3e voxel (voxel %d, z/lat %.4f); oracle under a one-ulp jitter %.3e; free-running difference %.3e" % (
                     step, dp, v, prev[v, 2] / lat, own, fr), flush=True)
             prev = got
+
+
+if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
+    # whole evaluations through the boundary against the REFERENCE BINARY (oracle/_ref, built where the reference lies): `count` random robots with
+    # random switches (the generator of the parameter sweeps), every result file compared tag by tag.  refcampaign <variant 0/1> <seed> <count> <maxdim>
+    import re, subprocess
+    from collections import OrderedDict
+    variant, seed, count, maxdim = (int(a) for a in sys.argv[2:6])
+    ref = os.path.join(REPO, "oracle", "_ref", "voxelyze_lw_ref" if variant else "voxelyze_ref")
+    rng = np.random.RandomState(seed)
+    tmp = tempfile.mkdtemp()
+    for d in ("voxelyzeFiles", "fitnessFiles", "tempFiles", "engineFitness"):
+        os.makedirs(os.path.join(tmp, d))
+    paths = []
+    for k in range(count):
+        shape = tuple(int(n) for n in rng.randint(2, maxdim, size=3))
+        sim_p = Sim(dt_frac=float(np.round(rng.uniform(0.3, 0.95), 2)), simulation_time=float(np.round(rng.uniform(0.05, 0.25), 2)),
+                    fitness_eval_init_time=float(np.round(rng.uniform(0.0, 0.02), 3)), self_collisions_enabled=bool(rng.randint(2)))
+        env_p = Env(frequency=float(np.round(rng.uniform(2, 8), 1)), gravity_enabled=int(rng.randint(2)), temp_enabled=int(rng.randint(2)),
+                    floor_enabled=int(rng.randint(2)), temp_amp=float(np.round(rng.uniform(26, 45), 0)))
+        if variant and rng.randint(3) > 0:
+            env_p.add_param("fluid_environment", 1, "<FluidEnvironment>")
+            env_p.add_param("aggregate_drag_coefficient", float(rng.choice([50.0, 750.0, 3000.0])), "<AggregateDragCoefficient>")
+        layers = OrderedDict()
+        if rng.randint(2):
+            layers["<PhaseOffset>"] = np.round(rng.uniform(-1, 1, size=shape), 3)
+        if rng.randint(2):
+            layers["<Stiffness>"] = np.round(10 ** rng.uniform(6.0, 8.0, size=shape), 0)
+        ind = workloads.make_individual(k, workloads.random_material(shape, 300 + k, 0.2), layers or None)
+        write_voxelyze_file(sim_p, env_p, ind, tmp, "c")
+        paths.append(os.path.join(tmp, "voxelyzeFiles", "c--id_%05i.vxa" % k))
+    running, queue = [], list(paths)
+    while queue or running:
+        while queue and len(running) < (os.cpu_count() or 8):
+            running.append(subprocess.Popen(["timeout", "600", ref, "-f", queue.pop(0)], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        running = [p for p in running if p.poll() is None]
+        time.sleep(0.005)
+    tag = re.compile(r"<(\w+)>\s*([-+0-9.eE]+|nan|inf|-inf|-nan)\s*</\1>")
+    identical, worst, worst_of, missing, steps, saved, differing = 0, 0.0, None, 0, 0, 0, {}
+    with engine.Engine(variant, 0) as eng:
+        eng.add_vxa_files(paths)
+        names = [eng.fitness_file_name(i) for i in range(count)]
+        eng.run()
+        for i in range(count):
+            steps += eng.result(i).steps
+            rp = names[i] if os.path.isabs(names[i]) else os.path.join(tmp, names[i])
+            if not os.path.exists(rp):
+                missing += 1          # (the reference wrote nothing: an empty lattice, or it ran into its own time-out)
+                continue
+            ref_text = open(rp).read()
+            mine = os.path.join(tmp, "engineFitness", "%05d.xml" % i)
+            eng.write_result_xml(i, mine)
+            text = open(mine).read()
+            identical += text == ref_text
+            if text != ref_text and saved < 4:          # keep a few differing pairs for inspection
+                saved += 1
+                out = os.path.join(REPO, "gpurun_out", "refcampaign")
+                os.makedirs(out, exist_ok=True)
+                open(os.path.join(out, "v%d_s%d_r%d_reference.xml" % (variant, seed, i)), "w").write(ref_text)
+                open(os.path.join(out, "v%d_s%d_r%d_engine.xml" % (variant, seed, i)), "w").write(text)
+                import shutil
+                shutil.copy(paths[i], os.path.join(out, "v%d_s%d_r%d.vxa" % (variant, seed, i)))
+            a, b = dict(tag.findall(ref_text)), dict(tag.findall(text))
+            for k2 in a:
+                if a[k2] != b[k2]:
+                    differing[k2] = differing.get(k2, 0) + 1
+            assert set(a) == set(b), (i, sorted(set(a) ^ set(b)))
+            for k2 in a:
+                d = abs(float(a[k2]) - float(b[k2])) / max(1e-12, abs(float(a[k2])))
+                if d > worst:
+                    worst, worst_of = d, (i, k2, a[k2], b[k2])
+    print("variant %d seed %d: %d robots, %d steps in all; reference files missing %d; byte-identical %d of %d; worst relative tag difference %.3e %s" % (
+        variant, seed, count, steps, missing, identical, count - missing, worst, worst_of), flush=True)
+    print("   files in which a tag's TEXT differs, by tag: %s" % differing, flush=True)
