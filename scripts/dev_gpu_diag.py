@@ -1302,3 +1302,34 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
     print("variant %d seed %d: %d robots, %d steps in all; reference files missing %d; byte-identical %d of %d; worst relative tag difference %.3e %s" % (
         variant, seed, count, steps, missing, identical, count - missing, worst, worst_of), flush=True)
     print("   files in which a tag's TEXT differs, by tag: %s" % differing, flush=True)
+
+
+if __name__ == "__main__" and "onestepfile" in sys.argv[1:]:
+    # as sweepcase, for a .vxa file on disk: onestepfile <path> <variant> [steps]
+    path, variant = sys.argv[2], int(sys.argv[3])
+    model = vo.parse_vxa(path, variant)
+    lat = model["lattice_dim"]
+    sim, twin, free = vo.OracleSim(model), vo.OracleSim(model), vo.OracleSim(model)
+    with engine.Engine(variant, 0) as eng:
+        eng.add_vxa_file(path)
+        planned = eng.dims(0)["planned_steps"]
+        nsteps = int(sys.argv[4]) if len(sys.argv) > 4 else planned
+        print("nvox %d nbond %d planned steps %d" % (eng.dims(0)["nvox"], eng.dims(0)["nbond"], planned), flush=True)
+        prev = sim.state()
+        worst_one, worst_own = 0.0, 0.0
+        for step in range(1, nsteps + 1):
+            eng.step(1)
+            got = eng.state(0)
+            sim.set_state(prev); sim.step(1)
+            want = sim.state()
+            twin.set_state(prev); twin.step_jittered(1, seed=step)
+            free.step(1)
+            own = np.abs(twin.state() - want)[:, :3].max() / lat
+            dp = np.abs(got - want)[:, :3].max() / lat
+            worst_one, worst_own = max(worst_one, dp), max(worst_own, own)
+            if dp > max(5e-14, 4 * own) or step % max(1, nsteps // 12) == 0 or step == nsteps:
+                print("step %4d: one step engine - oracle %.3e voxel (worst so far %.3e); oracle under a one-ulp jitter %.3e (worst %.3e); free-running difference %.3e" % (
+                    step, dp, worst_one, own, worst_own, np.abs(got - free.state())[:, :3].max() / lat), flush=True)
+            prev = got
+        r, o = eng.result(0), free.result()
+        print("engine: steps %d num_touching_floor %s; oracle: steps %d" % (r.steps, getattr(r, "num_touching_floor", "?"), free.info().steps), flush=True)
