@@ -1282,7 +1282,8 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
             eng.write_result_xml(i, mine)
             text = open(mine).read()
             identical += text == ref_text
-            if text != ref_text and saved < 4:          # keep a few differing pairs for inspection
+            ta, tb = dict(tag.findall(ref_text)), dict(tag.findall(text))
+            if any(ta[k3] != tb.get(k3) for k3 in ta if not k3.startswith("ConvexHull")) and saved < 4:     # keep a few differing pairs for inspection (hull volumes aside: -1 from a reference without qhull)
                 saved += 1
                 out = os.path.join(REPO, "gpurun_out", "refcampaign")
                 os.makedirs(out, exist_ok=True)
