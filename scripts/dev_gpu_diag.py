@@ -1243,7 +1243,7 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
         os.makedirs(os.path.join(tmp, d))
     paths = []
     for k in range(count):
-        shape = tuple(int(n) for n in rng.randint(2, maxdim, size=3))
+        shape = tuple(int(n) for n in rng.randint(9 if "big" in sys.argv[1:] else 2, maxdim, size=3))      # big: 9 .. maxdim - 1 per axis (the 768- / 1024-thread variants, tiles)
         sim_p = Sim(dt_frac=float(np.round(rng.uniform(0.3, 0.95), 2)), simulation_time=float(np.round(rng.uniform(0.05, 0.25), 2)),
                     fitness_eval_init_time=float(np.round(rng.uniform(0.0, 0.02), 3)), self_collisions_enabled=bool(rng.randint(2)))
         env_p = Env(frequency=float(np.round(rng.uniform(2, 8), 1)), gravity_enabled=int(rng.randint(2)), temp_enabled=int(rng.randint(2)),
