@@ -1304,6 +1304,7 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
         time.sleep(0.005)
     tag = re.compile(r"<(\w+)>\s*([-+0-9.eE]+|nan|inf|-inf|-nan)\s*</\1>")
     identical, worst, worst_of, missing, steps, saved, differing, significant, sig_files = 0, 0.0, None, 0, 0, 0, {}, {}, set()
+    hull_checked, hull_worst = 0, 0.0
     with engine.Engine(variant, 0) as eng:
         eng.add_vxa_files(paths)
         names = [eng.fitness_file_name(i) for i in range(count)]
@@ -1319,6 +1320,25 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
             eng.write_result_xml(i, mine)
             text = open(mine).read()
             identical += text == ref_text
+            if variant == 1:
+                # <ConvexHullVolumeStart> (the reference prints -1 without qhull): against scipy's qhull over the corners of the lattice cells the
+                # robot fills, each coordinate printed with six significant digits as the reference hands them over (LW/VX_MeshUtil.cpp:806)
+                from scipy.spatial import ConvexHull
+                m = vo.parse_vxa(paths[i], 1)
+                cells = np.argwhere(np.asarray(m["structure"]).reshape(m["nz"], m["ny"], m["nx"]) > 0)
+                if cells is not None and len(cells) == eng.dims(i)["nvox"]:
+                    lat_d = m["lattice_dim"]
+                    corners = set()
+                    for z, y, x in cells:
+                        for dz in (0, 1):
+                            for dy in (0, 1):
+                                for dx in (0, 1):
+                                    corners.add((x + dx, y + dy, z + dz))
+                    pts = np.array([[float("%g" % (c * lat_d)) for c in p3] for p3 in corners])
+                    want_h = ConvexHull(pts).volume
+                    got_h = eng.result(i).hull_volume_start
+                    hull_checked += 1
+                    hull_worst = max(hull_worst, abs(got_h - want_h) / want_h)
             ta, tb = dict(tag.findall(ref_text)), dict(tag.findall(text))
             if any(ta[k3] != tb.get(k3) for k3 in ta if not k3.startswith("ConvexHull")) and saved < 4:     # keep a few differing pairs for inspection (hull volumes aside: -1 from a reference without qhull)
                 saved += 1
@@ -1346,6 +1366,8 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
     print("variant %d seed %d: %d robots, %d steps in all; reference files missing %d; byte-identical %d of %d; worst relative tag difference %.3e %s" % (
         variant, seed, count, steps, missing, identical, count - missing, worst, worst_of), flush=True)
     print("   files in which a tag's TEXT differs, by tag: %s" % differing, flush=True)
+    if variant == 1:
+        print("   ConvexHullVolumeStart against scipy's qhull over the filled cells' corners: %d robots, worst relative difference %.3e" % (hull_checked, hull_worst), flush=True)
     print("   ... of those, differences that are neither NaN against NaN nor noise around zero (< 1e-9 on both sides) nor a hull volume: %s in files %s" % (
         significant, sorted(sig_files)), flush=True)
 
