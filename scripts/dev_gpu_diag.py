@@ -1257,6 +1257,18 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
         if rng.randint(2):
             layers["<Stiffness>"] = np.round(10 ** rng.uniform(6.0, 8.0, size=shape), 0)
         rich = "rich" in sys.argv[1:] and variant == 0          # more of the _voxcad writer's switches: development layers, sticky floor, growth amplitude, hard-wired constants
+        if "stops" in sys.argv[1:]:          # the other stop conditions (a step count; a number of actuation periods), afterlife, mid-life freeze, floor slope
+            kind = int(rng.randint(3))
+            if kind == 1:
+                sim_p.stop_condition = 1; sim_p.simulation_time = int(rng.randint(50, 400))
+            elif kind == 2:
+                sim_p.stop_condition = 3; sim_p.simulation_time = float(np.round(rng.uniform(0.3, 1.5), 2))
+            if variant == 0 and rng.randint(3) == 0:
+                sim_p.afterlife_time = float(np.round(rng.uniform(0.01, 0.05), 3))
+            if variant == 0 and rng.randint(4) == 0:
+                sim_p.mid_life_freeze_time = float(np.round(rng.uniform(0.01, 0.04), 3))
+            if rng.randint(3) == 0:
+                env_p.floor_slope = float(np.round(rng.uniform(0.0, 20.0), 1))
         if rich:
             env_p.sticky_floor = int(rng.randint(2))
             sim_p.min_temp_fact = float(np.round(rng.uniform(0.1, 0.6), 2))
@@ -1283,7 +1295,7 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
                     old_t = text[text.index("<" + tname + ">"):text.index("</" + tname + ">")]
                     text = text.replace(old_t, "<" + tname + ">" + str(rng.choice(choices)), 1)
             open(paths[-1], "w").write(text)
-    if "rich" in sys.argv[1:]:
+    if "rich" in sys.argv[1:] or "stops" in sys.argv[1:]:
         # the engine refuses what it does not support (velocity-adjusted development: the reference reads past its trace there): leave those out
         keep = []
         for pth in paths:
