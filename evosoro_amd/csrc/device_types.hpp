@@ -30,7 +30,9 @@ enum RobotFlags { RF_SELF_COL = 1, RF_GRAV = 2, RF_FLOOR = 4, RF_TEMP = 8, RF_ST
 
 enum { VXH_ORDER_MAX_STEPS = 128,    // launches of at most this many steps are dispatched "robots due for a broad-phase run first" (kernels_fused.hpp)
        VXH_ORDER_HORIZON = 32 };     // ... and what a longer launch calls "due" when it leaves the flags for the launch behind it
-enum { VXH_RIMG_CAP = 2048 };     // entries of a saved contact-row image (the LDS pool holds at most 24 KB / 12 B)
+enum { VXH_RIMG_CAP = 2048 };
+// pair kernel (kernels_pair.hpp; compiled with -DVXH_PAIR only: the developer library): threads, voxel slots, wavefronts, voxel wavefronts
+enum { VXH_PAIR_T = 512, VXH_PAIR_NV = 1024, VXH_PAIR_NW = 8, VXH_PAIR_NVW = 16 };     // entries of a saved contact-row image (the LDS pool holds at most 24 KB / 12 B)
 
 struct DRobot {               // constant per robot
     int vox_begin, nvox, surf_begin, nsurf, flags, stop_type, excl_wpr;
@@ -97,7 +99,8 @@ struct DTile {
 #define VXH_HD
 #endif
 enum { VXH_TILE_BLOCK = 256,          // worker threads of a tile's workgroup = most voxels a tile can own
-       VXH_TILE_THREADS = 320,        // ... plus the service wavefront (per-robot barrier and control block, concurrent with the bond phase)
+       VXH_TILE_THREADS = 256,        // threads of its workgroup: four wavefronts, one per SIMD, 512 registers each (rounds 2-5: 320, a fifth wavefront
+                                      // for the per-robot barrier and the control block -- now the last worker wavefront's job; kernels_tiled.hpp)
        VXH_TILE_HASH_BITS = 9, VXH_TILE_HASH = 512,   // broad-phase: LDS hash set of the contact partners owned by other tiles
        VXH_TILE_MAX_TILES = 256,      // most tiles of one robot (its max-|v|^2 words are polled by one wavefront)
        VXH_TILE_MV_STRIDE = 512,      // granules between the max-|v|^2 words of two tiles: 4 KB, so that the wavefronts polling them

@@ -18,15 +18,12 @@
 
 #include "engine.hpp"
 #include "kernels.hpp"
+#include "launch.hpp"
 
 namespace vxh {
 
 namespace {
 
-void hip_check(hipError_t e, const char* what)
-{
-    if (e != hipSuccess) throw std::runtime_error(std::string("HIP: ") + what + ": " + hipGetErrorString(e));
-}
 #define HIP_OK(call) hip_check((call), #call)
 
 }  // namespace
@@ -504,6 +501,9 @@ void Engine::check_option(const std::string& key, double value) const
         // a robot that changed kernels in the middle of a run would read stale history -- ADVICE round 4)
         if ((key == "wide" || key == "wide_two_tiles" || key == "fused" || key == "pair_sel") && value != 0 && value != 1) throw std::invalid_argument(key + ": 0 or 1");
         if (key == "pair" && value != 0 && value != 1 && value != 2) throw std::invalid_argument("pair: 0, 1 or 2");
+#ifndef VXH_PAIR
+        if (key == "pair" && value != 0) throw std::invalid_argument("pair: k_robot_pair is compiled into the developer library only (make -C evosoro_amd/csrc prof: -DVXH_PAIR)");
+#endif
         if (key == "col_cap" && !(value >= 0 && value <= 1e6)) throw std::invalid_argument("col_cap out of range");
         if (key == "tiled" && value != 0 && value != 1 && value != 2) throw std::invalid_argument("tiled: 0, 1 or 2");
         if (key == "tile_small" && value != 0 && value != 1) throw std::invalid_argument("tile_small: 0 or 1");
@@ -556,17 +556,6 @@ struct HostStages {
     }
     void print(const char* head) { if (on) std::fprintf(stderr, "%s:%s\n", head, line.c_str()); }
 };
-}
-
-// Workgroups of a k_tile_steps instance one CU keeps resident at `lds` bytes of dynamic LDS, by the runtime's own occupancy rule.
-static long long tile_workgroups_per_cu(int tabg, int mesh, size_t lds)
-{
-    const void* f = mesh == 2 ? (tabg ? (const void*)k_tile_steps<true, true, true> : (const void*)k_tile_steps<false, true, true>)
-                  : mesh == 1 ? (tabg ? (const void*)k_tile_steps<true, true, false> : (const void*)k_tile_steps<false, true, false>)
-                              : (tabg ? (const void*)k_tile_steps<true, false, false> : (const void*)k_tile_steps<false, false, false>);
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, VXH_TILE_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); n = 1; }
-    return std::max(1, n);
 }
 
 void Engine::prepare()
@@ -1389,78 +1378,17 @@ void Engine::prepare()
 
 void Engine::reset() { if (!robots_.empty()) prepare(); }
 
-// The opt-in to more than 64 KB of dynamic LDS is per function AND per device (engines on several devices and threads may live in
-// one process): the largest size granted on each device is remembered per kernel, under a lock.
-static void grant_dynamic_lds(const void* kernel, size_t (&granted)[64], size_t lds)
-{
-    static std::mutex lock;
-    int dev = 0;
-    hip_check(hipGetDevice(&dev), "hipGetDevice");
-    std::lock_guard<std::mutex> hold(lock);
-    if (dev < 0 || dev >= 64 || lds > granted[dev]) {
-        hip_check(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(dynamic LDS)");
-        if (dev >= 0 && dev < 64) granted[dev] = lds;
-    }
-}
-
-template <int BLOCK, int NACC, bool FLUID, bool TABG>
-static void launch_variant(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters,
-                           const unsigned long long* order_in, unsigned long long* order_out)
-{
-    static size_t granted[64] = {};
-    grant_dynamic_lds((const void*)k_robot_steps<BLOCK, NACC, FLUID, TABG>, granted, lds);
-    hipLaunchKernelGGL((k_robot_steps<BLOCK, NACC, FLUID, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8), order_in, order_out);
-}
-
-template <bool TABG, bool MESH, bool FLUID = false>
-static void launch_tiles(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
-{
-    static size_t granted[64] = {};
-    grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH, FLUID>, granted, lds);
-    hipLaunchKernelGGL((k_tile_steps<TABG, MESH, FLUID>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
-}
-
-template <bool FLUID, bool TABG>
-static void launch_sized(const DBatch& B, int block, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters,
-                         const unsigned long long* order_in, unsigned long long* order_out)
-{
-    if (block == 256) launch_variant<256, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters, order_in, order_out);
-    else if (block == 512) launch_variant<512, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters, order_in, order_out);
-    else if (block == 768) launch_variant<768, 2, FLUID, TABG>(B, list, count, lds, s, cap, iters, order_in, order_out);
-    else launch_variant<1024, 1, FLUID, TABG>(B, list, count, lds, s, cap, iters, order_in, order_out);
-}
-
-template <int BLOCK, bool MESH, bool TABG>
-static void launch_wide(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles)
-{
-    static size_t granted[64] = {};
-    grant_dynamic_lds((const void*)k_robot_wide<BLOCK, MESH, TABG>, granted, lds);
-    hipLaunchKernelGGL((k_robot_wide<BLOCK, MESH, TABG>), dim3(count), dim3(BLOCK), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8), two_tiles);
-}
-
-template <bool TABG, bool SEL>
-static void launch_pair(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters)
-{
-    static size_t granted[64] = {};
-    grant_dynamic_lds((const void*)k_robot_pair<TABG, SEL>, granted, lds);
-    hipLaunchKernelGGL((k_robot_pair<TABG, SEL>), dim3(count), dim3(VXH_PAIR_T), lds, s, B, B.robot, list, cap, iters, (int)(lds / 8));
-}
-
 static void launch_group(const DBatch& B, int block, bool fluid, bool tabg, bool wide, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles = 0, int pair = 0,
                          const unsigned long long* order_in = nullptr, unsigned long long* order_out = nullptr)
 {
-    if (pair) {
-        if (pair == 2) { if (tabg) launch_pair<true, true>(B, list, count, lds, s, cap, iters); else launch_pair<false, true>(B, list, count, lds, s, cap, iters); }
-        else { if (tabg) launch_pair<true, false>(B, list, count, lds, s, cap, iters); else launch_pair<false, false>(B, list, count, lds, s, cap, iters); }
-        return;
-    }
-    if (wide) {
-        if (fluid) { if (tabg) launch_wide<512, true, true>(B, list, count, lds, s, cap, iters, two_tiles); else launch_wide<512, true, false>(B, list, count, lds, s, cap, iters, two_tiles); }
-        else { if (tabg) launch_wide<512, false, true>(B, list, count, lds, s, cap, iters, two_tiles); else launch_wide<512, false, false>(B, list, count, lds, s, cap, iters, two_tiles); }
-        return;
-    }
-    if (fluid) { if (tabg) launch_sized<true, true>(B, block, list, count, lds, s, cap, iters, order_in, order_out); else launch_sized<true, false>(B, block, list, count, lds, s, cap, iters, order_in, order_out); }
-    else { if (tabg) launch_sized<false, true>(B, block, list, count, lds, s, cap, iters, order_in, order_out); else launch_sized<false, false>(B, block, list, count, lds, s, cap, iters, order_in, order_out); }
+#ifdef VXH_PAIR
+    if (pair) { launch_pair_group(B, tabg, pair == 2, list, count, lds, s, cap, iters); return; }
+#else
+    (void)pair;                               // (check_option refuses `pair` in a library built without -DVXH_PAIR)
+#endif
+    if (wide) { launch_wide_group(B, fluid, tabg, list, count, lds, s, cap, iters, two_tiles); return; }
+    if (fluid) launch_fused_mesh(B, block, tabg, list, count, lds, s, cap, iters, order_in, order_out);
+    else launch_fused_land(B, block, tabg, list, count, lds, s, cap, iters, order_in, order_out);
 }
 
 // A call in two halves: advance_launch enqueues every kernel of the call and returns; advance_finish waits for the device, reads
@@ -1561,12 +1489,7 @@ void Engine::advance_launch(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters)
             for (const auto& L : D.tile_launches) {
                 ++tile_gen_;
-                if (L.mesh == 2) { if (L.tabg) launch_tiles<true, true, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
-                                   else launch_tiles<false, true, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_); }
-                else if (L.mesh) { if (L.tabg) launch_tiles<true, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
-                              else launch_tiles<false, true>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_); }
-                else if (L.tabg) launch_tiles<true, false>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
-                else launch_tiles<false, false>(B, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                launch_tile_group(B, L.tabg != 0, L.mesh, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
                 ++launches; ++tile_launch_count;
             }
         HIP_OK(hipEventRecord(D.tile_t1, D.tile_stream));

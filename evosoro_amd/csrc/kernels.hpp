@@ -910,7 +910,7 @@ __device__ __forceinline__ void latch_cm(const DBatch& B, const DRobot& R, DRobo
 // mass keeps the reference's summation order (thread 0 adds voxel after voxel; the products come from all threads); the extrema
 // and counts are order-free.  Every expression that the host used to evaluate is written with explicit roundings (no contraction),
 // so the numbers are those of the host path bit for bit (option host_results = 1 keeps that path for cross-checks).
-__global__ __launch_bounds__(256) void k_results(DBatch B, DResult* __restrict__ out)
+static __global__ __launch_bounds__(256) void k_results(DBatch B, DResult* __restrict__ out)
 {
 #pragma clang fp contract(off)      // every product and sum below is rounded on its own, like on the host (HIP's *_rn arithmetic helpers would not
                                     // do: they are plain operators compiled where they are DEFINED, with contraction on)
@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void rebuild_rows(const DBatch& B, const DRobot& R, D
     }
 }
 
-__global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap, int begin_new_step)
+static __global__ __launch_bounds__(256) void k_step_begin(DBatch B, long long step_cap, int begin_new_step)
 {
     const int r = blockIdx.x;
     if (!B.streamed[r]) return;             // (stepped by the resident kernel)
@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void stream_bond(const DBatch& B, const DRobot& R, co
 // Fluid drag of the streaming path (robots in a fluid that do not fit the resident kernel): the surface mesh of the step,
 // one thread per vertex, then one thread per facet; k_voxels adds up each voxel's facets.  Launched between k_step_begin
 // and k_bonds: the strains read here are those of the previous step, the poses and momenta those at the start of this one.
-__global__ __launch_bounds__(256) void k_mesh_vertices(DBatch B)
+static __global__ __launch_bounds__(256) void k_mesh_vertices(DBatch B)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B.n_mv) return;
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_mesh_vertices(DBatch B)
     B.mesh_pos[i] = now.x; B.mesh_pos[tm + i] = now.y; B.mesh_pos[2u * tm + i] = now.z;
 }
 
-__global__ __launch_bounds__(256) void k_facets(DBatch B)
+static __global__ __launch_bounds__(256) void k_facets(DBatch B)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= B.n_facet) return;
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_facets(DBatch B)
 
 // blocks [0, bond_blocks): one thread per bond slot; blocks beyond: collision-list rebuilds (reb_robot/reb_i0 tables),
 // which overlap with the bond work of the other robots
-__global__ __launch_bounds__(256) void k_bonds(DBatch B, int bond_blocks, const int* __restrict__ reb_robot, const int* __restrict__ reb_i0)
+static __global__ __launch_bounds__(256) void k_bonds(DBatch B, int bond_blocks, const int* __restrict__ reb_robot, const int* __restrict__ reb_i0)
 {
     if ((int)blockIdx.x >= bond_blocks) {
         __shared__ double sh[4 * 512 + 256];
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_bonds(DBatch B, int bond_blocks, const 
     else stream_bond<2>(B, R, rs, r, tid, v1, bc);
 }
 
-__global__ __launch_bounds__(256) void k_voxels(DBatch B)
+static __global__ __launch_bounds__(256) void k_voxels(DBatch B)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= B.nv) return;
@@ -1226,6 +1226,8 @@ __global__ __launch_bounds__(256) void k_voxels(DBatch B)
 }  // namespace vxh
 
 #include "kernels_fused.hpp"
+#ifdef VXH_PAIR      // measured 20-30 % slower than the kernels it replaces (DESIGN.md "Pair path"): kept for A/B in the developer library (make prof)
 #include "kernels_pair.hpp"
+#endif
 #include "kernels_wide.hpp"
 #include "kernels_tiled.hpp"

@@ -19,7 +19,7 @@
 
 namespace vxh {
 
-enum { VXH_PAIR_T = 512, VXH_PAIR_NV = 1024, VXH_PAIR_NW = 8, VXH_PAIR_NVW = 16 };
+// (VXH_PAIR_T / _NV / _NW / _NVW: device_types.hpp -- the host sizes the schedule with them whether or not the kernel is compiled in)
 
 // IniCM latch + EndOfLifetimePosteriorY + trace point from the pose tile (fused_latch_cm with two voxels per lane)
 __device__ __forceinline__ void pair_latch_cm(const DRobot& R, DRobotState& rs, const double* ps, double* sh, const DVoxClass* vct, int cls0, int cls1,

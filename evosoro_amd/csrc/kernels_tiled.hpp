@@ -332,11 +332,18 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     __shared__ FusedCtl s_ctl[2];
     __shared__ unsigned long long s_mvbits;
     __shared__ double s_box[12 + 6 * (NT / 64)];
-    __shared__ int s_div, s_divprev, s_abort, s_xhn, s_pool, s_done;
-    static_assert(3 * sizeof(DRobotState) + 2 * sizeof(FusedCtl) + sizeof(double) + sizeof(double) * (12 + 6 * (NT / 64)) + 6 * sizeof(int) + 32 <= VXH_TILE_STATIC_LDS, "static LDS bound");
+    __shared__ double s_dtp[2];               // rs.dt_prev as the control of step `it` left it (slot it & 1): what the horizon update of that step needs, while the
+                                              // next step's control, on another wavefront, already overwrites the field
+    __shared__ int s_div, s_divprev, s_abort, s_xhn, s_pool, s_done, s_snap;
+    static_assert(3 * sizeof(DRobotState) + 2 * sizeof(FusedCtl) + sizeof(double) + sizeof(double) * (12 + 6 * (NT / 64)) + 2 * sizeof(double) + 7 * sizeof(int) + 32 <= VXH_TILE_STATIC_LDS, "static LDS bound");
+    static_assert(sizeof(DRobotState) % 4 == 0 && sizeof(DRobotState) / 4 <= 64, "a wavefront copies the control block one dword per lane");
 
     const int tid = threadIdx.x;
-    const bool svc = tid >= BLOCK;            // the service wavefront: per-robot barrier, control block
+    // Two wavefronts also SERVE the robot (round 6; rounds 2-5: a fifth wavefront): the last one (it holds voxels only in tiles of more than
+    // 192) resolves the per-robot barrier and takes the collision-horizon decision; the one before it -- when it holds no voxel either,
+    // else the last one again -- runs the serial control of the NEXT step; both beside the voxel phase of the wavefronts that hold voxels.
+    constexpr int SVC0 = BLOCK - 64;
+    const bool svc = tid >= SVC0;
     const int ti = __builtin_amdgcn_readfirstlane(tile_list[blockIdx.x]);
     const DTile& T = tiles[ti];
     const int r = T.robot;
@@ -382,8 +389,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     const int xs_own = T.xoff + tid;          // exchange slot of my owned voxel
     const size_t mvbuf = (size_t)VXH_TILE_MV_STRIDE * B.n_tiles;
 
-    if (svc) __builtin_amdgcn_s_setprio(3);   // its few instructions sit on the critical path of the whole robot; it shares a SIMD with a worker
-    if (tid == 0) { rs = B.rstate[r]; s_div = 0; s_divprev = 0; s_abort = 0; s_pool = 0; s_done = 0; s_mvbits = 0; s_xhn = B.rstate[r].col_tiled ? B.tile_xhn[ti] : 0; }
+    if (tid == 0) { rs = B.rstate[r]; s_div = 0; s_divprev = 0; s_abort = 0; s_pool = 0; s_done = 0; s_snap = 0; s_mvbits = 0; s_xhn = B.rstate[r].col_tiled ? B.tile_xhn[ti] : 0; }
     bool codes_live = B.rstate[r].col_tiled != 0;      // contact rows built by this kernel (else: every partner from memory until the next broad-phase)
     for (int e = tid; e < VXH_TILE_XH; e += NT) xh[e] = B.tile_xh[(size_t)ti * VXH_TILE_XH + e];
     const DBondClass* bct;
@@ -456,13 +462,25 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     if (valid && fluid) { my_ff = B.tile_ffirst[T.vox_off + tid]; my_fc = (int)B.tile_fcount[T.vox_off + tid]; }
     d3 lm_bak = lm, am_bak = am;              // momenta before the last committed voxel phase (a diverged step is undone)
     // the halo voxels are spread over the worker threads from the last one down: wave 0, which owns the first voxels, gets them last
-    const int hslot0 = svc ? (1 << 30) : BLOCK - 1 - tid;
+    const int hslot0 = BLOCK - 1 - tid;
     const int hv0 = hslot0 < n_halo ? B.tile_vox[T.vox_off + n_own + hslot0] : 0;      // my (first) halo voxel: its exchange slot
     __syncthreads();
-    const bool ctl_thread = tid == BLOCK;     // first lane of the service wavefront
+    const int nvw = (n_own + 63) >> 6;        // wavefronts that hold voxels
+    const int ctl0 = n_own <= SVC0 - 64 ? SVC0 - 64 : SVC0;
+    const bool ctl_wave = (tid & ~63) == ctl0, ctl_thread = tid == ctl0;      // the wavefront of the next step's control, its first lane
+    const bool hz_thread = tid == SVC0;       // the lane that takes the horizon decision: first of the wavefront that resolves the per-robot barrier
+    // snapshots of the control block by the whole control wavefront, a dword per lane (one LDS round trip instead of ten on one lane)
+    auto snapshot = [&](bool two) {
+        const int l = tid - ctl0;
+        if (l < (int)(sizeof(DRobotState) / 4)) {
+            const int a = ((const int*)&rs_bak)[l], b = ((const int*)&rs)[l];
+            if (two) ((int*)&rs_bak2)[l] = a;
+            ((int*)&rs_bak)[l] = b;
+        }
+    };
     if (tid == 0)   // the pending max |v|^2 of the last step before this launch travels like a step's: every tile publishes the robot-wide value
         st_gran2(B.tile_mv + (size_t)ring * mvbuf + (size_t)ti * VXH_TILE_MV_STRIDE, 1, __longlong_as_double((long long)rs.maxvel2_bits), tile_tag(gen, 0, 1));
-    if (ctl_thread) fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]);
+    if (ctl_thread) { fused_control_begin(R, rs, step_cap, iters > 0, s_ctl[0]); s_dtp[0] = rs.dt_prev; }
     // my contact row: its length, and a copy in LDS when the rows were built by this kernel and fit
     int ccnt = 0, roff = -1;
     auto rows_to_lds = [&]() {                // (every thread calls: workgroup barriers inside)
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     // finished the previous one), reduce, note a divergence, else take the collision-horizon decision of the step
     constexpr int MVC = VXH_TILE_MAX_TILES / 64;
     auto robot_barrier = [&](const unsigned long long* mvq, unsigned tag, unsigned long long (&mg)[2 * MVC], bool go, FusedCtl& K, double dt_prev) {
-        const int lane = tid - BLOCK;
+        const int lane = tid - SVC0;
         int spins = 0;
 #ifdef VXH_PHASE_TIMING
         int polls = 0;
@@ -513,7 +531,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 if (lane + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(lane + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
         }
 #ifdef VXH_PHASE_TIMING
-        if (B.prof && ctl_thread) { atomicAdd(&B.prof[120], (unsigned long long)polls); atomicAdd(&B.prof[121], 1ull); atomicAdd(&B.prof[122], __builtin_readcyclecounter() - tp0); }
+        if (B.prof && hz_thread) { atomicAdd(&B.prof[120], (unsigned long long)polls); atomicAdd(&B.prof[121], 1ull); atomicAdd(&B.prof[122], __builtin_readcyclecounter() - tp0); }
 #endif
         double mvmax = 0.0;                   // max |v|^2 over the tiles; a negative word marks a tile in which a bond diverged
         bool neg = false;
@@ -522,7 +540,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             if (lane + 64 * c < k_tiles) { const double m = gran2_value(mg[2 * c], mg[2 * c + 1]); neg = neg || m < 0.0; mvmax = m > mvmax ? m : mvmax; }
         neg = __any(neg) != 0;
         mvmax = wave_max_nonneg(mvmax);
-        if (ctl_thread && !s_abort) {
+        if (hz_thread && !s_abort) {
             s_divprev = neg ? 1 : 0;
             if (!neg) {
                 rs.maxvel2_bits = (unsigned long long)__double_as_longlong(mvmax);
@@ -550,16 +568,15 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         // not at the end of the launch (the control block written back needs the reduced max |v|^2)
         const bool speculate = can_speculate && go && !K.latch && !K.eol && !K.trace;
         int spins = 0;
-        // the service wavefront requests the robot's max-|v|^2 words at once (tiles lane, lane + 64, ...)
-        unsigned long long mg[2 * MVC];
         const unsigned long long* const mvq = B.tile_mv + (size_t)ring * mvbuf + (size_t)T.tile0 * VXH_TILE_MV_STRIDE;
-        if (svc) {
+        // the serving wavefront's request of the robot's max-|v|^2 words (tiles lane, lane + 64, ...)
+        auto request_mv = [&](unsigned long long (&mg)[2 * MVC]) {
 #pragma unroll
             for (int c = 0; c < MVC; ++c) {
                 mg[2 * c] = mg[2 * c + 1] = 0;
-                if (tid - BLOCK + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(tid - BLOCK + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
+                if (tid - SVC0 + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(tid - SVC0 + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
             }
-        }
+        };
         // ---- 1. halo poses of this step: every worker wave waits for the granules of its own halo voxels
         if (go) {
             for (int h = hslot0; h < n_halo; h += BLOCK) {
@@ -597,7 +614,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             }
         }
         if constexpr (FLUID) {
-            if (go && fluid && !svc) {
+            if (go && fluid) {
                 // ---- 1b. fluid drag, staging: pose and strains (of the PREVIOUS step's bonds) of every voxel my part of the drag mesh averages
                 // over -- mine, a neighbour tile's, or a diagonal neighbour's that is no halo voxel: ONE protocol, the exchange buffer of this
                 // step -- one voxel per lane, one memory round trip for all of them
@@ -631,7 +648,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             if (go && fluid) {                 // (uniform over the workgroup: its barrier)
                 // ---- 1c. the surface mesh (LW/VX_MeshUtil.cpp:388-428, as k_mesh_vertices / fused_drag): every vertex my facets use = mean over
                 // the voxels touching that lattice corner of Pos + R(Angle) * corner offset, summed in corner-code order
-                if (!svc) {
+                {
                     const double nom = R.lat;
                     for (int i = tid; i < n_mv; i += BLOCK) {
                         d3 part = mk3(0, 0, 0);
@@ -659,24 +676,9 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             }
         }
 
-        // ---- 2. workers: bond phase, every bond with an owned end, all axes in one round.  Service wavefront, on steps that do
-        // not speculate: the per-robot barrier
+        // ---- 2. bond phase, every bond with an owned end, all axes in one round
         bool div = false;
-        double dt_prev_spec = 0.0;             // (service wavefront, speculating step: rs.dt_prev as it was before the next step's control overwrote it)
-        if (svc) {
-            if (!speculate) { robot_barrier(mvq, tag, mg, go, K, rs.dt_prev); VXH_TT_MARK(2) }
-            else {
-                // Speculating step: the NEXT step's control now, while the workers are in the bond phase and this wavefront has nothing
-                // to do (it shares no field with the horizon update but dt_prev, handed over by value; nothing a worker reads before
-                // the next step: K stays, Knext is written).  Until round 3 it ran after barrier (B), in front of the per-robot
-                // barrier -- 4 k cycles of one lane's serial work (two snapshots of the control block, the stop rule, a sincos) with
-                // the workers done with their 5.7 k-cycle voxel phase and waiting at (C) for this wavefront: a third of the step.
-                // If the barrier then reports that the robot stopped a step ago, the control block goes back two snapshots instead of one.
-                dt_prev_spec = rs.dt_prev;
-                if (ctl_thread) { rs_bak2 = rs_bak; rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
-                VXH_TT_MARK(7)
-            }
-        } else if (go && !s_abort) {
+        if (go && !s_abort) {
             if constexpr (FLUID) {
                 if (fluid) {
                     // ---- 2a. fluid drag of my facets (LW/VX_Sim.cpp:1516-1597; facet_drag_force), each on its voxel's velocity at the start of the step
@@ -723,6 +725,9 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             VXH_TT_MARK(1)
         }
         if (div) s_div = 1;
+        // on steps that do not speculate (rare: latch, end of launch, trace point; robots without the horizon rule) the serving wavefront
+        // resolves the per-robot barrier here, behind its bonds
+        if (svc && !speculate) { unsigned long long mg[2 * MVC]; request_mv(mg); robot_barrier(mvq, tag, mg, go, K, s_dtp[it & 1]); VXH_TT_MARK(2) }
         __syncthreads();                       // (B)
         VXH_TT_MARK(3)
         VXH_TS(2, tid == 0)
@@ -769,13 +774,19 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             if (valid) {
                 // the six bond forces in the order of the fused kernel of the robot's size class: up to 768 voxels the bonds in which
                 // the voxel is the negative end first (+X +Y +Z), then those in which it is the positive end; above, +X -X +Y -Y +Z -Z
-                double a6[6];
-                const bool two_tiles = R.nvox <= 768;
+                // (all 36 values requested before the first sum, ONE branch on the order: with the order chosen per component the compiler
+                // emitted six load-wait-branch-add rounds, 1.2 k cycles of a 5.4 k-cycle phase -- round 6)
+                double a6[6], pq[6][6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const double* q = pl + c * no + tid;
-                    const double pX = q[0], nX = q[6 * no], pY = q[12 * no], nY = q[18 * no], pZ = q[24 * no], nZ = q[30 * no];
-                    a6[c] = two_tiles ? ((pX + pY) + pZ) + ((nX + nY) + nZ) : ((((pX + nX) + pY) + nY) + pZ) + nZ;
+                for (int d = 0; d < 6; ++d)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) pq[d][c] = pl[(6 * d + c) * no + tid];
+                if (R.nvox <= 768) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) a6[c] = ((pq[0][c] + pq[2][c]) + pq[4][c]) + ((pq[1][c] + pq[3][c]) + pq[5][c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) a6[c] = ((((pq[0][c] + pq[1][c]) + pq[2][c]) + pq[3][c]) + pq[4][c]) + pq[5][c];
                 }
                 d3 F = mk3(a6[0], a6[1], a6[2]), M = mk3(a6[3], a6[4], a6[5]);
                 VXH_TV(0)
@@ -805,40 +816,57 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 }
                 VXH_TV(3)
             }
-            if (svc && attempt == 0) {
-                if (speculate) {
-                    // the per-robot barrier of this step, behind the voxel phase of the workers: the words are requested afresh (the
-                    // copies requested at the top of the step are from before the other tiles published them)
-#pragma unroll
-                    for (int c = 0; c < MVC; ++c)
-                        if (tid - BLOCK + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(tid - BLOCK + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
-                    const bool neg = robot_barrier(mvq, tag, mg, go, K, dt_prev_spec);
-                    VXH_TT_MARK(2)
-                    VXH_TS(5, ctl_thread)
+            if (tid < 64 * nvw) {
+                // the tile's max |v|^2 goes out with the last wavefront to finish its voxels, not behind the workgroup barrier (only the
+                // wavefronts that hold voxels take part: one, in a tile of 64 voxels -- no LDS round trips at all then)
+                vel2 = wave_max_nonneg(vel2);
+                if ((tid & 63) == 0) {
+                    unsigned long long bits = (unsigned long long)__double_as_longlong(vel2);
+                    bool last = true;
+                    if (nvw > 1) {
+                        atomicMax(&s_mvbits, bits);
+                        last = atomicAdd(&s_done, 1) == nvw - 1;
+                        if (last) { bits = s_mvbits; s_mvbits = 0; s_done = 0; }
+                    }
+                    if (last) {
+                        double mv = (R.flags & RF_SELF_COL) ? __longlong_as_double((long long)bits) : 0.0;   // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
+                        if (diverged_here) mv = -1.0;
+                        st_gran2(B.tile_mv + (size_t)ringn * mvbuf + (size_t)ti * VXH_TILE_MV_STRIDE, 1, mv, tagn);
+                        VXH_TS(7, true)
+                    }
+                }
+            }
+            if (attempt == 0) {
+                // Speculating step: the NEXT step's control -- one lane's serial work (the stop rule, a sincos; the two snapshots of the control
+                // block by the whole wavefront) beside the voxel phase; it shares no field with the horizon update but dt_prev (s_dtp), and
+                // nothing anyone reads before the next step: K stays, Knext is written.  (Rounds 3-5: on a fifth wavefront beside the bond
+                // phase; a workgroup of four leaves every wavefront 512 registers, i.e. nothing in scratch -- round 6.)  If the barrier then
+                // reports that the robot stopped a step ago, the control block goes back two snapshots instead of one.
+                // A step that does not speculate: the same control, one snapshot.
+                if (ctl_wave && !s_abort) {
+                    snapshot(speculate);
                     if (ctl_thread) {
-                        if (neg) rs_bak = rs_bak2;
+                        __hip_atomic_store(&s_snap, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (LDS operations of one wavefront: in order)
+                        fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);
+                        s_dtp[(it + 1) & 1] = rs.dt_prev;
+                    }
+                    VXH_TT_MARK(7)
+                }
+                if (svc && speculate) {
+                    // ... and the per-robot barrier of this step
+                    unsigned long long mg[2 * MVC];
+                    request_mv(mg);
+                    const bool neg = robot_barrier(mvq, tag, mg, go, K, s_dtp[it & 1]);
+                    VXH_TT_MARK(2)
+                    VXH_TS(5, hz_thread)
+                    if (hz_thread) {
+                        // (the control wavefront took this step's snapshot right behind barrier (B), long ago; the flag makes it certain)
+                        for (int spins = 0; __hip_atomic_load(&s_snap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != it + 1 && !__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) && spins < 4096; ++spins) __builtin_amdgcn_s_sleep(1);
+                        if (neg) { const DRobotState two = rs_bak2; rs_bak = two; }
                         else {   // the snapshot of this step carries the horizon update as well
                             rs_bak.maxvel2_bits = rs.maxvel2_bits; rs_bak.max_disp = rs.max_disp; rs_bak.rebuilds = rs.rebuilds;
                             rs_bak.col_tiled = rs.col_tiled; rs_bak.rebuild_now = rs.rebuild_now;
                         }
-                    }
-                } else {
-                    // next step's control, off the critical path
-                    if (ctl_thread && !s_abort) { rs_bak = rs; fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); }
-                    VXH_TT_MARK(7)
-                }
-            }
-            if (!svc) {
-                // the tile's max |v|^2 goes out with the last worker wave to finish, not behind the workgroup barrier
-                vel2 = wave_max_nonneg(vel2);
-                if ((tid & 63) == 0) {
-                    atomicMax(&s_mvbits, (unsigned long long)__double_as_longlong(vel2));
-                    if (atomicAdd(&s_done, 1) == BLOCK / 64 - 1) {
-                        double mv = (R.flags & RF_SELF_COL) ? __longlong_as_double((long long)s_mvbits) : 0.0;   // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
-                        if (diverged_here) mv = -1.0;
-                        s_mvbits = 0; s_done = 0;
-                        st_gran2(B.tile_mv + (size_t)ringn * mvbuf + (size_t)ti * VXH_TILE_MV_STRIDE, 1, mv, tagn);
-                        VXH_TS(7, true)
                     }
                 }
             }

@@ -86,8 +86,11 @@ def build(force=False):
     src = os.path.join(_HERE, "csrc")
     newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
     newest = max(newest, os.path.getmtime(os.path.join(_HERE, "..", "include", "vxhip.h")))
+    dev_lib = os.path.join(_HERE, "libvxhip_prof.so")     # developer library (phase timers, the opt-in pair kernel): what the A/B tests and scripts load
     if force or not os.path.exists(LIB_PATH) or not os.path.exists(CLI_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        subprocess.check_call(["make", "-C", src], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", src, "-j2", "all", "prof"], stdout=subprocess.DEVNULL)
+    elif not os.path.exists(dev_lib) or os.path.getmtime(dev_lib) < newest:
+        subprocess.check_call(["make", "-C", src, "prof"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 

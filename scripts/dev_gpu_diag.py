@@ -1102,6 +1102,35 @@ if __name__ == "__main__" and "swimhash" in sys.argv[1:]:
         print("%s swimhash %s (%d swimmers, 500 steps, kernel of most voxel-steps %d)" % (os.path.basename(engine.LIB_PATH), h.hexdigest()[:24], n, eng.counters().dominant_block), flush=True)
 
 
+if __name__ == "__main__" and "tileab" in sys.argv[1:]:
+    # round 6: the tiled kernel's workloads in one process, for same-box A/B of two libraries (scripts/ab_lib.py <lib> tileab; scripts/r6_ab.sh):
+    # configs[4], one 64-robot shard of configs[2] with and without tile_small, an 11^3 swimmer; us per step over a window past a pre-advance
+    from collections import OrderedDict
+    def window(variant, mats, env, opts, pre, steps, extra=None, tag=""):
+        tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+        sim = Sim(dt_frac=0.9, simulation_time=1.0, fitness_eval_init_time=0.005, self_collisions_enabled=True)
+        with engine.Engine(variant, 0) as eng:
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            for i, m in enumerate(mats):
+                ind = workloads.make_individual(i, m, extra(i) if extra else None)
+                write_voxelyze_file(sim, env, ind, tmp, "w")
+                eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "w--id_%05i.vxa" % i))
+            eng.step(pre)
+            c0 = eng.counters(); eng.step(steps); c1 = eng.counters()
+            print("tileab %-34s %s: %.3f us per step (kernel %d)" % (tag, opts, 1e6 * (c1.kernel_seconds - c0.kernel_seconds) / steps, c1.dominant_block), flush=True)
+    env_w = Env()
+    env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
+    env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    shard = [workloads.random_material((10, 10, 10), i) for i in range(64)]
+    for rep in range(2):
+        window(engine.VOXCAD, [workloads.full_material(20, 1)], Env(), {}, 300, 2000, tag="1 x 20^3 (configs[4])")
+        window(engine.VOXCAD, shard, Env(), {"tile_small": 1}, 300, 600, tag="64 x 10^3 random")
+        window(engine.VOXCAD, shard, Env(), {}, 300, 600, tag="64 x 10^3 random")
+        window(engine.VOXCAD_LAND_WATER, [workloads.full_material(11, 1)], env_w, {}, 200, 600, tag="1 x 11^3 swimmer",
+               extra=lambda i: OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(70 + i).uniform(-1, 1, size=(11, 11, 11)), 3))]))
+
+
 if __name__ == "__main__" and "bigswim" in sys.argv[1:]:
     # round 5: swimmers above 1024 voxels (full 11^3 and 14^3 lattices in a fluid) on the tiled kernel (fluid tiles) against the streaming kernels
     from collections import OrderedDict

@@ -1,5 +1,6 @@
 """Static census of one kernel's gfx950 ISA by instruction class and by source line (no GPU needed).
-    hipcc ... --cuda-device-only -S -gline-tables-only engine.hip -o /tmp/engine_g.s   (scripts/isa_census.sh does it)
+    cd evosoro_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -disable-machine-licm --cuda-device-only -S -gline-tables-only launch_tiled.hip -o /tmp/tiled_g.s
+    (one translation unit per kernel family: launch_fused_land / _mesh, launch_wide, launch_tiled, engine = streaming kernels)
     python scripts/isa_census.py /tmp/engine_g.s 'k_robot_stepsILi768ELi2ELb0ELb0E' [--lines N] [--cls mov,cnd,...]
 Every VALU wave-instruction costs a SIMD four cycles whether it is an FMA or a move, so for an FP64-issue-bound kernel the
 non-FP64 share of the vector stream is pure overhead; this shows where it comes from."""

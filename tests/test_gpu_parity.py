@@ -1189,13 +1189,23 @@ def test_the_second_pose_tile_of_the_wide_kernel_changes_no_bit(eng_mod, golden_
             assert all(a[k] == b[k] for k in a if k != "reserved"), n
 
 
-def test_pair_kernel_steps_like_the_resident_kernels(eng_mod, tmp_path, kernel_path):
+def test_pair_kernel_steps_like_the_resident_kernels(eng_mod, tmp_path, kernel_path, monkeypatch):
     """k_robot_pair (option pair: 512 threads, two voxels and up to two bonds per axis per lane; off by default since it measured slower)
     adds the bond forces in the order of k_robot_steps<1024> -- +X and -X, then +Y, -Y, +Z, -Z -- so a robot of 769-1024 voxels must
     come out BIT FOR BIT as that kernel steps it, self-collision, broad-phase runs and the IniCM latch included; a robot of 513-768
     voxels (pair = 2) within the 1e-12 voxel the kernels of different summation order agree to.  Also against the oracle."""
     if kernel_path != "auto":
         pytest.skip("the test sets the kernel options itself")
+    # round 6: the kernel is compiled into the developer library only (-DVXH_PAIR, `make prof`); libvxhip.so refuses the option
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        with pytest.raises(eng_mod.VxhError):
+            eng.set_option("pair", 1)
+        eng.set_option("pair", 0)
+    dev_lib = os.path.join(os.path.dirname(eng_mod.LIB_PATH), "libvxhip_prof.so")
+    if not os.path.exists(dev_lib):
+        pytest.skip("developer library not built (make -C evosoro_amd/csrc prof)")
+    monkeypatch.setattr(eng_mod, "LIB_PATH", dev_lib)
+    monkeypatch.setattr(eng_mod, "_lib", None)
     from evosoro_amd import workloads
     from evosoro_amd.base import Sim, Env
     from oracle import vxoracle as vo
