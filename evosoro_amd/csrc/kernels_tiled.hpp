@@ -505,11 +505,29 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     // robots whose lists are rebuilt every step (no horizon logic) cannot speculate on "no rebuild due"
     const bool can_speculate = !(R.flags & RF_SELF_COL) || (R.flags & RF_HORIZON_COL) != 0;
 
-    // the service wavefront's part of a step: wait until every tile of the robot has published its max |v|^2 for this step (= has
-    // finished the previous one), reduce, note a divergence, else take the collision-horizon decision of the step
+    // The serving wavefront's part of a step: wait until every tile of the robot has published its max |v|^2 for this step (= has
+    // finished the previous one), reduce, note a divergence, else take the collision-horizon decision of the step -- UpdateCollisions,
+    // VX_Sim.cpp:1729-1755; the arithmetic of step_control_horizon (kernels.hpp), operation for operation.  What the decision reads of the
+    // control block is fetched BEFORE the wait (nobody else writes those fields between two workgroup barriers) and what it leaves is stored
+    // without being read back: behind the last poll stand a wave reduction, a square root, a division and stores -- the workgroup waits at
+    // barrier (C) for exactly this lane (round 6; before: a dozen dependent LDS round trips, ~1 us).  `spec`: the step's snapshot of the
+    // control block (taken by the control wavefront right behind barrier (B)) gets the same values.
     constexpr int MVC = VXH_TILE_MAX_TILES / 64;
-    auto robot_barrier = [&](const unsigned long long* mvq, unsigned tag, unsigned long long (&mg)[2 * MVC], bool go, FusedCtl& K, double dt_prev) {
+    auto robot_barrier = [&](const unsigned long long* mvq, unsigned tag, bool go, FusedCtl& K, int it, bool spec) {
         const int lane = tid - SVC0;
+        unsigned long long mg[2 * MVC];
+#pragma unroll
+        for (int c = 0; c < MVC; ++c) {
+            mg[2 * c] = mg[2 * c + 1] = 0;
+            if (lane + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(lane + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
+        }
+        // (while the words travel) the decision's inputs
+        const double pre_disp = rs.max_disp, pre_dtp = s_dtp[it & 1], lat = R.lat, half_reach = (R.col_horizon - 1.0) / 2;
+        const int pre_reb = rs.rebuilds, pre_ct = rs.col_tiled, kflags = K.flags;
+        const bool self_col = (R.flags & RF_SELF_COL) != 0, by_horizon = (R.flags & RF_HORIZON_COL) != 0;
+        bool aborted = __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        if (spec && hz_thread)     // (the snapshot this lane will patch is in place: the control wavefront took it right behind barrier (B); the flag makes it certain)
+            for (int w = 0; __hip_atomic_load(&s_snap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != it + 1 && w < 4096; ++w) __builtin_amdgcn_s_sleep(1);
         int spins = 0;
 #ifdef VXH_PHASE_TIMING
         int polls = 0;
@@ -525,7 +543,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 if (lane + 64 * c < k_tiles) ok = ok && (unsigned)(mg[2 * c] >> 32) == tag && (unsigned)(mg[2 * c + 1] >> 32) == tag;
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > VXH_TILE_SPIN_LIMIT) { s_abort = 1; break; }
+            if (++spins > VXH_TILE_SPIN_LIMIT) { s_abort = 1; aborted = true; break; }
 #pragma unroll
             for (int c = 0; c < MVC; ++c)
                 if (lane + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(lane + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
@@ -540,12 +558,27 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             if (lane + 64 * c < k_tiles) { const double m = gran2_value(mg[2 * c], mg[2 * c + 1]); neg = neg || m < 0.0; mvmax = m > mvmax ? m : mvmax; }
         neg = __any(neg) != 0;
         mvmax = wave_max_nonneg(mvmax);
-        if (hz_thread && !s_abort) {
+        if (hz_thread && !aborted) {
             s_divprev = neg ? 1 : 0;
             if (!neg) {
-                rs.maxvel2_bits = (unsigned long long)__double_as_longlong(mvmax);
-                if (go) fused_control_horizon(R, rs, K, dt_prev);
-            }
+                unsigned long long mvb = (unsigned long long)__double_as_longlong(mvmax);
+                double disp = pre_disp;
+                int reb = pre_reb, ct = pre_ct;
+                if (go) {
+                    int rebuild = 0;
+                    if (self_col) {                  // (fused_control_horizon -> step_control_horizon with c.go = 1)
+                        const double mv = vsqrt_nn(mvmax);
+                        disp += fabs(vdiv(mv * pre_dtp, lat));
+                        mvb = 0ull;
+                        if (!by_horizon || disp > half_reach) { rebuild = 1; disp = 0.0; reb += 1; ct = 0; }
+                    }
+                    rs.rebuild_now = rebuild; K.rebuild = rebuild;
+                    if (rebuild) K.flags = kflags | 8;
+                    if (spec) rs_bak.rebuild_now = rebuild;
+                }
+                rs.maxvel2_bits = mvb; rs.max_disp = disp; rs.rebuilds = reb; rs.col_tiled = ct;
+                if (spec) { rs_bak.maxvel2_bits = mvb; rs_bak.max_disp = disp; rs_bak.rebuilds = reb; rs_bak.col_tiled = ct; }   // the snapshot of this step carries the horizon update as well
+            } else if (spec) { const DRobotState two = rs_bak2; rs_bak = two; }      // the robot stopped a step ago: back two snapshots instead of one
         }
         return neg;
     };
@@ -569,14 +602,6 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         const bool speculate = can_speculate && go && !K.latch && !K.eol && !K.trace;
         int spins = 0;
         const unsigned long long* const mvq = B.tile_mv + (size_t)ring * mvbuf + (size_t)T.tile0 * VXH_TILE_MV_STRIDE;
-        // the serving wavefront's request of the robot's max-|v|^2 words (tiles lane, lane + 64, ...)
-        auto request_mv = [&](unsigned long long (&mg)[2 * MVC]) {
-#pragma unroll
-            for (int c = 0; c < MVC; ++c) {
-                mg[2 * c] = mg[2 * c + 1] = 0;
-                if (tid - SVC0 + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(tid - SVC0 + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
-            }
-        };
         // ---- 1. halo poses of this step: every worker wave waits for the granules of its own halo voxels
         if (go) {
             for (int h = hslot0; h < n_halo; h += BLOCK) {
@@ -727,7 +752,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         if (div) s_div = 1;
         // on steps that do not speculate (rare: latch, end of launch, trace point; robots without the horizon rule) the serving wavefront
         // resolves the per-robot barrier here, behind its bonds
-        if (svc && !speculate) { unsigned long long mg[2 * MVC]; request_mv(mg); robot_barrier(mvq, tag, mg, go, K, s_dtp[it & 1]); VXH_TT_MARK(2) }
+        if (svc && !speculate) { robot_barrier(mvq, tag, go, K, it, false); VXH_TT_MARK(2) }
         __syncthreads();                       // (B)
         VXH_TT_MARK(3)
         VXH_TS(2, tid == 0)
@@ -854,20 +879,9 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 }
                 if (svc && speculate) {
                     // ... and the per-robot barrier of this step
-                    unsigned long long mg[2 * MVC];
-                    request_mv(mg);
-                    const bool neg = robot_barrier(mvq, tag, mg, go, K, s_dtp[it & 1]);
+                    robot_barrier(mvq, tag, go, K, it, true);
                     VXH_TT_MARK(2)
                     VXH_TS(5, hz_thread)
-                    if (hz_thread) {
-                        // (the control wavefront took this step's snapshot right behind barrier (B), long ago; the flag makes it certain)
-                        for (int spins = 0; __hip_atomic_load(&s_snap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != it + 1 && !__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) && spins < 4096; ++spins) __builtin_amdgcn_s_sleep(1);
-                        if (neg) { const DRobotState two = rs_bak2; rs_bak = two; }
-                        else {   // the snapshot of this step carries the horizon update as well
-                            rs_bak.maxvel2_bits = rs.maxvel2_bits; rs_bak.max_disp = rs.max_disp; rs_bak.rebuilds = rs.rebuilds;
-                            rs_bak.col_tiled = rs.col_tiled; rs_bak.rebuild_now = rs.rebuild_now;
-                        }
-                    }
                 }
             }
             VXH_TT_MARK(5)

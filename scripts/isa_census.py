@@ -26,11 +26,12 @@ def classify(op):
 
 def main():
     path, pat = sys.argv[1], sys.argv[2]
-    nlines = 40; want = None
+    nlines = 40; want = None; root = False
     a = sys.argv[3:]
     while a:
         if a[0] == "--lines": nlines = int(a[1]); a = a[2:]
         elif a[0] == "--cls": want = set(a[1].split(",")); a = a[2:]
+        elif a[0] == "--root": root = True; a = a[1:]      # attribute an instruction to the OUTERMOST call site (the line of the kernel that the inlined code belongs to)
         else: a = a[1:]
     files = {}
     inside = False
@@ -51,6 +52,10 @@ def main():
             if s.startswith(".loc"):
                 p = s.split()
                 cur = (files.get(int(p[1]), p[1]), int(p[2]))
+                if root:
+                    sites = re.findall(r"([\w.]+):(\d+):\d+ \]", s) or re.findall(r"@\[ \S*?([\w.]+):(\d+):\d+", s)
+                    allsites = re.findall(r"@\[ \S*?/?([\w.]+\.h(?:pp)?):(\d+):\d+", s)
+                    if allsites: cur = (allsites[-1][0], int(allsites[-1][1]))
                 continue
             if not s or s.startswith((";", ".", "//")) or s.endswith(":"): continue
             op = s.split()[0]
