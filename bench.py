@@ -300,7 +300,9 @@ def binding(key, voxel_steps_per_s):
         return None
     flops = row["fp64_flop_per_voxel_step"] * voxel_steps_per_s
     out = {"bound": "fp64-issue", "achieved": flops, "peak": FP64_PEAK_FLOPS, "unit": "FLOP/s", "frac": flops / FP64_PEAK_FLOPS,
-           "fp64_flop_per_voxel_step": row["fp64_flop_per_voxel_step"], "live": True,
+           "fp64_flop_per_voxel_step": row["fp64_flop_per_voxel_step"],
+           "live": False,     # (the rate is this run's; the flops per voxel-step are a stored count -- advisor, round 5)
+           "live_part": "voxel-steps/s", "stored_part": "flops and vector instructions per voxel-step",
            "source": "%s (flops per voxel-step: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of this workload) x this run's voxel-steps/s" % src}
     if row.get("valu_inst_per_voxel_step"):
         out["valu_issue_frac"] = row["valu_inst_per_voxel_step"] * voxel_steps_per_s / VALU_ISSUE_PER_S
@@ -504,6 +506,42 @@ def mixed_generation(engine, device, count=512, lattice=10, sim_time=0.5, init_t
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def shard_of_population(engine, paths, device, parts, steps, init_time=INIT_CM_TIME):
+    """BASELINE configs[2] AS STATED -- a population of 512 sharded across 8 GPUs -- measured on ONE GPU: shard 0 of the cost-balanced (greedy
+    LPT on voxels, evosoro_amd/parallel.py shard_by_cost: what rank 0 of an 8-rank run steps) of the bench population, with the engine's
+    default kernels and with the option tile_small; the 8-GPU strong rate is then a projection from a measurement, not from a model
+    (round-5 review, task 2).  Every shard holds the same number of voxels to within a robot, so the projection is `parts` x this shard."""
+    from evosoro_amd import parallel
+    costs = [engine.inspect_vxa(p).nvox for p in paths]
+    shards = parallel.shard_by_cost(costs, parts)
+    loads = [sum(costs[i] for i in sh) for sh in shards]
+    mine = shards[0]
+    out = {"workload": "configs[2] as stated: shard 0 of %d (greedy LPT by voxels) of the population of %d random 10x10x10 robots = what ONE of %d GPUs steps"
+                       % (parts, len(paths), parts),
+           "robots": len(mine), "shard_voxels_min_max": [min(loads), max(loads)], "steps": steps}
+    for label, options in (("default_kernels", {}), ("tile_small", {"tile_small": 1})):
+        with engine.Engine(engine.VOXCAD, device) as eng:
+            for k, val in options.items():
+                eng.set_option(k, val)
+            for i in mine:
+                eng.add_vxa_file(paths[i])
+            dims = [eng.dims(i) for i in range(len(mine))]
+            nvox = sum(d["nvox"] for d in dims)
+            eng.step(int(max(init_time / d["dt"] for d in dims)) + 32 + 200)
+            elapsed, host = timed_steps(eng, steps)
+            c1 = eng.counters()
+            out[label] = {"value": nvox * steps / elapsed, "unit": "voxel-timesteps/s", "us_per_step": elapsed / steps * 1e6,
+                          "us_per_step_host_clock": host / steps * 1e6, "kernel": kernel_name(c1.dominant_block),
+                          "projected_%d_gpu_strong_value" % parts: sum(loads) * steps / elapsed,
+                          "binding": binding("shard8" if not options else "shard8_tiles", nvox * steps / elapsed)}
+    out["voxels"] = nvox
+    best = max(("default_kernels", "tile_small"), key=lambda k: out[k]["value"])
+    out["faster"] = best
+    out["projection_note"] = ("projected strong value = voxels of the WHOLE population x steps / this shard's time (all %d shards are LPT-balanced to within "
+                              "%.2f %% of voxels; no data-path collective; the fitness gather is outside the timed steps)" % (parts, 100.0 * (max(loads) - min(loads)) / max(loads)))
+    return out
+
+
 def side_workload(engine, key, device):
     """the other_configs entries by key (also what scripts/unit_workload.py runs under the FP64 instruction counters)"""
     from evosoro_amd.base import Env
@@ -536,6 +574,8 @@ def main():
     ap.add_argument("--lattice", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="K",
+                    help="time shard 0 of K (greedy LPT by voxels) of the population instead of the whole of it: BASELINE configs[2] as one of K GPUs sees it")
     args = ap.parse_args()
 
     import numpy as np
@@ -654,6 +694,12 @@ def main():
         # (sized for the largest time step a robot can have, ten times the usual one: nothing is run to its stop condition)
         sim_time = max(0.5, INIT_CM_TIME + (args.steps + args.warmup + 1100) * 7.2e-4)
         paths = make_population(tmp, n_local, rank * n_local, shape, sim_time, INIT_CM_TIME)
+        all_local_paths = paths
+        if args.shard_of > 1:
+            # (--shard-of K: this rank steps shard 0 of K of its population -- what one of K GPUs sees of BASELINE configs[2])
+            picked = parallel.shard_by_cost([engine.inspect_vxa(p).nvox for p in paths], args.shard_of)[0]
+            paths = [paths[i] for i in picked]
+            n_local = len(paths)
         eng, clocks, local_vs, nvox, nbond, c0, c1, pre = run_population(paths)
         elapsed_max, host_max, total_vs = reduce_stats(clocks, local_vs)
         ranks = gather_ranks(clocks[0] / args.steps * 1e3)          # (outside every timed region)
@@ -729,13 +775,15 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "clock": "hip_event",           # (what `value` and `ms_per_step` are priced on; `host_clock` = the contract's bracket, beside it)
                 "timing": "HIP events on the engine's own stream around the timed steps (first event in front of the call's first launch, last "
                           "behind its last), max over ranks; host_clock = perf_counter between the barrier + torch.cuda.synchronize() pairs",
                 "host_clock": {"ms_per_step": host_max / args.steps * 1e3, "value": total_vs / host_max},
                 "ranks": ranks,
-                "config": {"workload": "population of %d random %dx%dx%d soft robots per GPU (BASELINE configs[2], "
-                                       "pop-512 of 10x10x10), self-collision on, DtFrac 0.9, evosoro default materials"
-                                       % (n_local, shape[0], shape[1], shape[2]),
+                "config": {"workload": ("population of %d random %dx%dx%d soft robots per GPU (BASELINE configs[2], "
+                                        "pop-512 of 10x10x10), self-collision on, DtFrac 0.9, evosoro default materials"
+                                        % (n_local, shape[0], shape[1], shape[2]))
+                                       + ((" -- shard 0 of %d (greedy LPT by voxels) of a population of %d" % (args.shard_of, len(all_local_paths))) if args.shard_of > 1 else ""),
                            "robots_per_gpu": n_local, "voxels_per_gpu": nvox, "bonds_per_gpu": nbond,
                            "pre_advanced_steps": pre + max(args.warmup, 1),
                            "large_angle_bonds": large / max(1, total_b),
@@ -786,6 +834,8 @@ def main():
                     side_workload(engine, "cfg1", local_rank), side_workload(engine, "cfg3", local_rank), side_workload(engine, "cfg4", local_rank),
                     side_workload(engine, "dense", local_rank), side_workload(engine, "mixed", local_rank),
                 ]
+                if n_local == 512 and args.lattice == 10 and args.shard_of <= 1:
+                    out["other_configs"].append(shard_of_population(engine, all_local_paths, local_rank, 8, 1024))
                 for entry in out["other_configs"]:
                     entry.pop("_voxel_steps_process", None)
             if world == 1 and not args.no_cpu_baseline:

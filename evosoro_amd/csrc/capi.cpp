@@ -262,32 +262,36 @@ int vxh_write_result_xml(const vxh_engine* ce, int robot, const char* path_or_nu
     if (path.empty()) { e->last_error = "no FitnessFileName in the .vxa and no path given"; return VXH_ERR_IO; }
     std::string text;
     std::vector<double> ex_end;       // land_water: angle excesses of the final mesh (the curvatures file below; its first value is <ShapeComplexityEnd>)
+    std::FILE* curv_file = nullptr;   // <CurvaturesTmpFile>, opened before anything is computed (unwritable: both tags stay -1, like the reference)
     rc = guarded(e, [&] {
         double shape_start = -1.0, shape_end = -1.0;
-        if (m.vxa.variant == 1 && m.nmv > 0) {
-            std::vector<double> ex_start;
-            vxh::mesh_angle_excess(m, nullptr, nullptr, nullptr, ex_start);
-            ex_end = e->impl->angle_excess(robot, true);
-            shape_start = vxh::shape_complexity_as_the_reference_prints_it(m, ex_start);
-            shape_end = vxh::shape_complexity_as_the_reference_prints_it(m, ex_end);
+        // (only when <CurvaturesTmpFile> is named AND can be opened for writing: the reference returns -1 before it computes anything
+        // otherwise, LW/VX_MeshUtil.cpp:1022-1032 -- advisor, round 5)
+        if (m.vxa.variant == 1 && m.nmv > 0 && !m.vxa.curvatures_tmp_file.empty()) {
+            curv_file = std::fopen(m.vxa.curvatures_tmp_file.c_str(), "wb");
+            if (curv_file) {
+                std::vector<double> ex_start;
+                vxh::mesh_angle_excess(m, nullptr, nullptr, nullptr, ex_start);
+                ex_end = e->impl->angle_excess(robot, true);
+                shape_start = vxh::shape_complexity_as_the_reference_prints_it(m, ex_start);
+                shape_end = vxh::shape_complexity_as_the_reference_prints_it(m, ex_end);
+            }
         }
         text = vxh::result_xml(m, res, e->impl->trace_of(robot), shape_start, shape_end);
     });
+    // land_water: the final mesh's per-vertex angle excesses into <CurvaturesTmpFile>, tab-separated with the stream's six
+    // significant digits, as CVX_MeshUtil::computeShapeComplexity leaves them for curvatureEntropy.py (LW/VX_MeshUtil.cpp:1016-1031;
+    // the reference then runs that script -- absent from its repository -- and removes the file; here the file stays)
+    if (curv_file) {
+        for (double v : ex_end) std::fprintf(curv_file, "%g\t", v);
+        std::fclose(curv_file);
+    }
     if (rc != VXH_OK) return rc;
     std::FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) { e->last_error = "cannot write " + path; return VXH_ERR_IO; }
     const bool ok = std::fwrite(text.data(), 1, text.size(), f) == text.size();
     std::fclose(f);
     if (!ok) { e->last_error = "short write to " + path; return VXH_ERR_IO; }
-    // land_water: the final mesh's per-vertex angle excesses into <CurvaturesTmpFile>, tab-separated with the stream's six
-    // significant digits, as CVX_MeshUtil::computeShapeComplexity leaves them for curvatureEntropy.py (LW/VX_MeshUtil.cpp:1016-1031;
-    // the reference then runs that script -- absent from its repository -- and removes the file; here the file stays)
-    if (m.vxa.variant == 1 && !m.vxa.curvatures_tmp_file.empty() && m.nmv > 0) {
-        if (std::FILE* c = std::fopen(m.vxa.curvatures_tmp_file.c_str(), "wb")) {      // (an unwritable path: skipped, like the reference's `return -1`)
-            for (double v : ex_end) std::fprintf(c, "%g\t", v);
-            std::fclose(c);
-        }
-    }
     return VXH_OK;
 }
 

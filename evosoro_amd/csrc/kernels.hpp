@@ -403,16 +403,20 @@ __device__ __forceinline__ BondOut bond_compute_xframe(const DBatch& B, const DB
     // ExtendPerc = x/NomDistance are only ever compared with constants, so the comparisons are made on the
     // cross-multiplied form (no division); the sign cases keep the IEEE outcome of the quotient (x < 0: quotient <= 0,
     // x == 0: +inf or NaN).
+    // (Round 6: written as lane masks -- bitwise operators on the comparisons' results -- instead of nested ifs: the compiler had turned
+    // every `if` into a save-exec / branch pair, a dozen scalar round trips at the head of a chain that issues one instruction per ~7
+    // cycles; the same truth table, NaN cases included: rel.x unordered -> neither xpos nor xneg -> the reference's `else` arm.)
     bool small = (H.flags & 1u) != 0, changed = false;
     {
         const double t = fabs(rel.z) + fabs(rel.y);
-        bool turn_lt, turn_gt;      // SmallTurn < BEND ; SmallTurn > HYST*BEND
-        if (rel.x > 0) { turn_lt = t < VXH_SA_BOND_BEND_RAD * rel.x; turn_gt = t > (VXH_HYST * VXH_SA_BOND_BEND_RAD) * rel.x; }
-        else if (rel.x < 0) { turn_lt = true; turn_gt = false; }
-        else { turn_lt = false; turn_gt = t > 0; }
+        const bool xpos = rel.x > 0, xneg = rel.x < 0;
+        const bool turn_lt = (xpos & (t < VXH_SA_BOND_BEND_RAD * rel.x)) | xneg;                                  // SmallTurn < BEND
+        const bool turn_gt = (xpos & (t > (VXH_HYST * VXH_SA_BOND_BEND_RAD) * rel.x)) | (!xpos & !xneg & (t > 0));   // SmallTurn > HYST * BEND
         const bool ext_lt = rel.x < VXH_SA_BOND_EXT_PERC * nom_dist, ext_gt = rel.x > (VXH_HYST * VXH_SA_BOND_EXT_PERC) * nom_dist;
-        if (!small && new2w > B.small_angle_w && turn_lt && ext_lt) { small = true; changed = true; }
-        else if (small && (!(new2w > B.smallish_angle_w) || turn_gt || ext_gt)) { small = false; changed = true; }
+        const bool to_small = !small & (new2w > B.small_angle_w) & turn_lt & ext_lt;
+        const bool to_large = small & (!(new2w > B.smallish_angle_w) | turn_gt | ext_gt);
+        changed = to_small | to_large;
+        small = (small | to_small) & !to_large;
     }
     // (Round 4, measured: a wavefront whose 64 bonds are of both modes runs both branches below, and in the bench population 6 % of the
     // bonds are small-angle, so nearly every wavefront does.  The ceiling of sorting the bonds by mode -- every bond forced large-angle, the

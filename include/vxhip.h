@@ -77,7 +77,9 @@ typedef struct vxh_result {
  * meeting in the vertex, exactly as CVX_MeshUtil::computeShapeComplexity forms it (LW/VX_MeshUtil.cpp:956-1014) before handing the
  * vector to curvatureEntropy.py through <CurvaturesTmpFile> (:1016-1036).  That script is not in the reference repository: its call fails,
  * the reference reads ONE number back from the file it wrote itself, and <ShapeComplexityStart/End> are the first vertex's angle excess
- * as printed (six digits) -- which is what vxh_write_result_xml prints too (-1 without a <CurvaturesTmpFile>, as the reference).  The
+ * as printed (six digits) -- which is what vxh_write_result_xml prints too: the tags EMULATE THE REFERENCE'S FAILURE MODE, they are not
+ * an entropy (with the script installed a reference user gets the entropy instead); -1 without a <CurvaturesTmpFile> or when that file
+ * cannot be opened for writing, where the reference returns -1 before computing anything (:1024-1032).  The
  * vector is what can be computed and pinned: at_end = 0 the rest state (what
  * computeInitialShapeComplexity sees, voxelyzeMain/main.cpp:65), 1 the state after the last step (computeFinalShapeComplexity, :117).
  * `count_out` receives the number of mesh vertices (0 for a _voxcad robot); at most `capacity` values are written.

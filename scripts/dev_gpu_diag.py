@@ -5,6 +5,7 @@ built by `make -C evosoro_amd/csrc prof`), whole-generation wall clock.  Uses or
 import os
 import sys
 import time
+import shutil
 import tempfile
 
 import numpy as np
@@ -1102,33 +1103,57 @@ if __name__ == "__main__" and "swimhash" in sys.argv[1:]:
         print("%s swimhash %s (%d swimmers, 500 steps, kernel of most voxel-steps %d)" % (os.path.basename(engine.LIB_PATH), h.hexdigest()[:24], n, eng.counters().dominant_block), flush=True)
 
 
-if __name__ == "__main__" and "tileab" in sys.argv[1:]:
-    # round 6: the tiled kernel's workloads in one process, for same-box A/B of two libraries (scripts/ab_lib.py <lib> tileab; scripts/r6_ab.sh):
-    # configs[4], one 64-robot shard of configs[2] with and without tile_small, an 11^3 swimmer; us per step over a window past a pre-advance
-    from collections import OrderedDict
-    def window(variant, mats, env, opts, pre, steps, extra=None, tag=""):
-        tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
-        sim = Sim(dt_frac=0.9, simulation_time=1.0, fitness_eval_init_time=0.005, self_collisions_enabled=True)
-        with engine.Engine(variant, 0) as eng:
-            for k, v in opts.items():
-                eng.set_option(k, v)
-            for i, m in enumerate(mats):
-                ind = workloads.make_individual(i, m, extra(i) if extra else None)
-                write_voxelyze_file(sim, env, ind, tmp, "w")
-                eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "w--id_%05i.vxa" % i))
-            eng.step(pre)
-            c0 = eng.counters(); eng.step(steps); c1 = eng.counters()
-            print("tileab %-34s %s: %.3f us per step (kernel %d)" % (tag, opts, 1e6 * (c1.kernel_seconds - c0.kernel_seconds) / steps, c1.dominant_block), flush=True)
+def _window(variant, mats, env, opts, pre, steps, extra=None, tag="", label="tileab"):
+    """us per step of a population over `steps` steps past a pre-advance of `pre` (kernel time by the engine's events), for same-box A/B"""
+    tmp = tempfile.mkdtemp(); os.makedirs(os.path.join(tmp, "voxelyzeFiles"))
+    sim = Sim(dt_frac=0.9, simulation_time=1.0, fitness_eval_init_time=0.005, self_collisions_enabled=True)
+    with engine.Engine(variant, 0) as eng:
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        for i, m in enumerate(mats):
+            ind = workloads.make_individual(i, m, extra(i) if extra else None)
+            write_voxelyze_file(sim, env, ind, tmp, "w")
+            eng.add_vxa_file(os.path.join(tmp, "voxelyzeFiles", "w--id_%05i.vxa" % i))
+        eng.step(pre)
+        c0 = eng.counters(); eng.step(steps); c1 = eng.counters()
+        print("%s %-34s %s: %.3f us per step (kernel %d)" % (label, tag, opts, 1e6 * (c1.kernel_seconds - c0.kernel_seconds) / steps, c1.dominant_block), flush=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _water():
     env_w = Env()
     env_w.add_param("fluid_environment", 1, "<FluidEnvironment>")
     env_w.add_param("aggregate_drag_coefficient", 750.0, "<AggregateDragCoefficient>")
+    return env_w
+
+
+def _phase_layer(shape, seed0):
+    from collections import OrderedDict
+    return lambda i: OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(seed0 + i).uniform(-1, 1, size=shape), 3))])
+
+
+if __name__ == "__main__" and "tileab" in sys.argv[1:]:
+    # round 6: the tiled kernel's workloads in one process, for same-box A/B of two libraries (scripts/ab_lib.py <lib> tileab; scripts/r6_ab.sh):
+    # configs[4], one 64-robot shard of configs[2] with and without tile_small, an 11^3 swimmer; us per step over a window past a pre-advance
     shard = [workloads.random_material((10, 10, 10), i) for i in range(64)]
     for rep in range(2):
-        window(engine.VOXCAD, [workloads.full_material(20, 1)], Env(), {}, 300, 2000, tag="1 x 20^3 (configs[4])")
-        window(engine.VOXCAD, shard, Env(), {"tile_small": 1}, 300, 600, tag="64 x 10^3 random")
-        window(engine.VOXCAD, shard, Env(), {}, 300, 600, tag="64 x 10^3 random")
-        window(engine.VOXCAD_LAND_WATER, [workloads.full_material(11, 1)], env_w, {}, 200, 600, tag="1 x 11^3 swimmer",
-               extra=lambda i: OrderedDict([("<PhaseOffset>", np.round(np.random.RandomState(70 + i).uniform(-1, 1, size=(11, 11, 11)), 3))]))
+        _window(engine.VOXCAD, [workloads.full_material(20, 1)], Env(), {}, 300, 2000, tag="1 x 20^3 (configs[4])")
+        _window(engine.VOXCAD, shard, Env(), {"tile_small": 1}, 300, 600, tag="64 x 10^3 random")
+        _window(engine.VOXCAD, shard, Env(), {}, 300, 600, tag="64 x 10^3 random")
+        _window(engine.VOXCAD_LAND_WATER, [workloads.full_material(11, 1)], _water(), {}, 200, 600, tag="1 x 11^3 swimmer", extra=_phase_layer((11, 11, 11), 70))
+
+
+if __name__ == "__main__" and "kab" in sys.argv[1:]:
+    # round 6: every kernel family's main workload in one process, for same-box A/B of a change to shared device code (bond_compute, voxel_update):
+    # headline (512 random 10^3, k_robot_steps<768>), dense 10^3 (<1024>), configs[1] and [3] (k_robot_wide), configs[4] (k_tile_steps)
+    bench = [workloads.random_material((10, 10, 10), i) for i in range(512)]
+    for rep in range(2):
+        _window(engine.VOXCAD, bench, Env(), {}, 900, 1000, tag="512 x 10^3 random (headline)", label="kab")
+        _window(engine.VOXCAD, [workloads.full_material(10, 1 + i) for i in range(512)], Env(), {}, 300, 500, tag="512 x 10^3 dense", label="kab")
+        _window(engine.VOXCAD, [workloads.random_material((6, 6, 6), i) for i in range(64)], Env(), {}, 300, 1500, tag="64 x 6^3 (configs[1])", label="kab")
+        _window(engine.VOXCAD_LAND_WATER, [workloads.random_material((8, 8, 8), i) for i in range(64)], _water(), {}, 300, 1000, tag="64 x 8^3 swimmers (configs[3])",
+                extra=_phase_layer((8, 8, 8), 0), label="kab")
+        _window(engine.VOXCAD, [workloads.full_material(20, 1)], Env(), {}, 300, 2000, tag="1 x 20^3 (configs[4])", label="kab")
 
 
 if __name__ == "__main__" and "bigswim" in sys.argv[1:]:

@@ -43,6 +43,19 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_on_the_stub():
     assert out["host_clock"]["ms_per_step"] >= out["ms_per_step"] * 0.999 and out["host_clock"]["value"] > 0
 
 
+def test_shard_of_times_one_cost_balanced_shard_of_the_population_on_the_stub():
+    """`--shard-of K` (round 6): BASELINE configs[2] is stated as a population sharded over 8 GPUs; one GPU measures what one of them
+    steps -- shard 0 of K by greedy LPT on voxels (evosoro_amd/parallel.py shard_by_cost) -- and the line says so."""
+    small = ["--steps", "6", "--warmup", "2", "--robots-per-gpu", "8", "--lattice", "4", "--no-cpu-baseline", "--no-other-configs"]
+    proc = _run([sys.executable, os.path.join(REPO, "tests", "bench_stub_runner.py"), "--gpus", "1", "--shard-of", "4"] + small, {})
+    assert proc.returncode == 0, proc.stderr.decode()[-3000:]
+    out = _line(proc)
+    assert out["n_gpus"] == 1 and out["config"]["robots_per_gpu"] == 2 and "shard 0 of 4" in out["config"]["workload"]
+    assert out["value"] > 0 and out["clock"] == "hip_event"
+    whole = _line(_run([sys.executable, os.path.join(REPO, "tests", "bench_stub_runner.py"), "--gpus", "1"] + small, {}))
+    assert whole["config"]["robots_per_gpu"] == 8 and whole["config"]["voxels_per_gpu"] > 3 * out["config"]["voxels_per_gpu"]
+
+
 def test_no_default_group_collective_overlaps_a_timed_region(tmp_path):
     """The N > 1 run, traced (VXH_BENCH_TRACE): on a GPU node the default group is RCCL, whose collectives are kernels that spin on
     the device until every rank has arrived -- so no collective of the DEFAULT group may be in flight, on any rank, while any rank

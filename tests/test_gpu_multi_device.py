@@ -52,6 +52,32 @@ def test_two_engines_behind_one_handle(golden_dir):
         assert _val(two.result(2), "cur_cm") == _val(want[2], "cur_cm")
 
 
+def test_eight_engines_behind_one_handle(golden_dir):
+    """The shape of the first real 8-GPU contact (round-5 review, task 7): a handle over EIGHT engines -- here eight times the one device of
+    the box: eight streams, eight host threads, the population partitioned eight ways by cost -- more robots than engines, and fewer
+    in a second batch; every result equal to the single engine's, bit for bit."""
+    from evosoro_amd import engine as eng_mod
+    names = NAMES + ["rand6_col", "probe6", "soft5_init0", "rand6_nocol"]      # 11 robots on 8 engines
+    paths = [os.path.join(golden_dir, "vxa", n + ".vxa") for n in names]
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as one:
+        one.set_option("tiled", 0)             # (engines that share a device do not tile: their tiles could not all be co-resident)
+        one.add_vxa_files(paths)
+        one.run()
+        want = [one.result(i) for i in range(len(paths))]
+        want_state = [one.state(i) for i in range(len(paths))]
+    with eng_mod.Engine(eng_mod.VOXCAD, (0,) * 8) as eight:
+        eight.add_vxa_files(paths)
+        eight.run()
+        for i, n in enumerate(names):
+            assert _same(eight.result(i), want[i]), (i, n)
+            assert np.array_equal(eight.state(i), want_state[i]), (i, n)
+        eight.clear()
+        eight.add_vxa_files(paths[:3])                   # fewer robots than engines: five of them stay idle
+        eight.run()
+        for i in range(3):
+            assert _same(eight.result(i), want[i]), i
+
+
 def test_cli_over_a_device_list(golden_dir, tmp_path):
     import subprocess
     from evosoro_amd import engine as eng_mod
