@@ -1,6 +1,9 @@
 // k_tile_steps: one translation unit (launch.hpp)
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
 #include "kernels.hpp"
 #include "launch.hpp"
 
@@ -10,9 +13,45 @@ namespace vxh {
 template <bool TABG, bool MESH, bool FLUID>
 static size_t (&granted_lds())[64] { static size_t table[64] = {}; return table; }
 
+// k_tile_steps must keep NOTHING in scratch (round 6).  Its tiles exchange poses through relaxed agent-scope stores and polled loads, and
+// every scratch access queues behind those in the wavefront's one in-order memory counter (a reload right after the publication waited
+// for the write-through stores to be acknowledged: ~1 us of a 7.9-us step, rounds 2-5).  And it is where round 5's unexplained abort
+// lived: a build of the FLUID variant with ~500 bytes of scratch per lane stored granules through address registers reloaded from scratch
+// whose upper lanes had never been written (rocgdb, precise memory: lanes 48-62 of the faulting global_store's address pair held garbage
+// -- a slot filled under a narrower lane mask than the one it was read back under), a memory access fault at the first step (HISTORY
+// "Round 6").  Four wavefronts per workgroup leave every wavefront 512 registers, the compiler spills into the upper 256 (AGPRs), and
+// this check keeps it that way: a build that needs scratch again is refused with VXH_ERR_HIP before it is launched.
+// (VXH_TILE_SCRATCH_LIMIT: bytes per lane tolerated, default 0; the GPU test sets -1 to see the refusal.)
+template <bool TABG, bool MESH, bool FLUID>
+static void refuse_scratch()
+{
+    static std::mutex lock;
+    static long bytes[64];
+    static bool known[64] = {};
+    int dev = 0;
+    hip_check(hipGetDevice(&dev), "hipGetDevice");
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    long have;
+    {
+        std::lock_guard<std::mutex> hold(lock);
+        if (!known[dev]) {
+            hipFuncAttributes attr;
+            hip_check(hipFuncGetAttributes(&attr, (const void*)k_tile_steps<TABG, MESH, FLUID>), "hipFuncGetAttributes(k_tile_steps)");
+            bytes[dev] = (long)attr.localSizeBytes; known[dev] = true;
+        }
+        have = bytes[dev];
+    }
+    const char* env = std::getenv("VXH_TILE_SCRATCH_LIMIT");
+    const long limit = env ? std::atol(env) : 0;
+    if (have > limit)
+        throw std::runtime_error("HIP: k_tile_steps<" + std::to_string((int)TABG) + ", " + std::to_string((int)MESH) + ", " + std::to_string((int)FLUID) + "> was compiled with " +
+                                 std::to_string(have) + " bytes of scratch per lane (limit " + std::to_string(limit) + "): refused, see evosoro_amd/csrc/launch_tiled.hip");
+}
+
 template <bool TABG, bool MESH, bool FLUID>
 static void launch_tiles(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
 {
+    refuse_scratch<TABG, MESH, FLUID>();
     grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH, FLUID>, granted_lds<TABG, MESH, FLUID>(), lds);
     hipLaunchKernelGGL((k_tile_steps<TABG, MESH, FLUID>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
 }

@@ -361,3 +361,31 @@ def test_swimmers_on_tiles_do_not_depend_on_the_tiling(golden_dir):
         eng.add_vxa_file(paths[1])
         eng.step(10)
         assert eng.counters().dominant_block == 1
+
+
+def test_a_tile_kernel_that_needs_scratch_is_refused_before_it_is_launched(golden_dir, monkeypatch):
+    """Round 6 (the round-5 review's task 5): the round-5 abort of the FLUID tile kernel was a build with ~500 bytes of scratch per lane whose
+    granule stores took their addresses from scratch slots filled under a narrower lane mask (rocgdb: a memory access fault at the first
+    step).  k_tile_steps now keeps nothing in scratch -- four wavefronts, 512 registers each -- and every launch checks it
+    (hipFuncGetAttributes, launch_tiled.hip): with the tolerated size forced below zero the call comes back as VXH_ERR_HIP with a message,
+    nothing is launched, and the engine is still usable once the limit is back."""
+    from evosoro_amd import engine as eng_mod
+    path = os.path.join(golden_dir, "vxa", "rand6_col.vxa")
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 2)
+        eng.set_option("tiles_per_robot", 3)
+        eng.add_vxa_file(path)
+        monkeypatch.setenv("VXH_TILE_SCRATCH_LIMIT", "-1")
+        with pytest.raises(eng_mod.VxhError) as err:
+            eng.step(10)
+        assert "scratch" in str(err.value) and "status -5" in str(err.value)          # VXH_ERR_HIP
+        monkeypatch.delenv("VXH_TILE_SCRATCH_LIMIT")
+        eng.reset()
+        eng.step(10)                            # (the product build: 0 bytes, launched)
+        tiled = eng.state(0)
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 0)
+        eng.set_option("wide", 0)
+        eng.add_vxa_file(path)
+        eng.step(10)
+        assert np.abs(eng.state(0)[:, :8] - tiled[:, :8]).max() < 1e-12
