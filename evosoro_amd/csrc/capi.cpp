@@ -306,6 +306,33 @@ int vxh_get_angle_excess(const vxh_engine* ce, int robot, int at_end, double* ou
     });
 }
 
+int vxh_get_mesh(const vxh_engine* ce, int robot, int at_end, double* verts3, int vert_capacity, int* n_verts, int* facets3, int facet_capacity, int* n_facets)
+{
+    vxh_engine* e = const_cast<vxh_engine*>(ce);
+    if (bad_robot(e, robot) || !n_verts || !n_facets || (vert_capacity > 0 && !verts3) || (facet_capacity > 0 && !facets3)) return VXH_ERR_ARG;
+    return guarded(e, [&] {
+        vxh::MeshShape sh;
+        e->impl->shape(robot, at_end != 0, sh);
+        *n_verts = (int)(sh.verts.size() / 3); *n_facets = (int)(sh.facets.size() / 3);
+        for (int k = 0; k < 3 * std::min(*n_verts, vert_capacity); ++k) verts3[k] = sh.verts[k];
+        for (int k = 0; k < 3 * std::min(*n_facets, facet_capacity); ++k) facets3[k] = sh.facets[k];
+    });
+}
+
+int vxh_get_shape_descriptors(const vxh_engine* ce, int robot, int at_end, double* robot_volume, double* hull_volume, double* shape_complexity)
+{
+    vxh_engine* e = const_cast<vxh_engine*>(ce);
+    if (bad_robot(e, robot)) return VXH_ERR_ARG;
+    return guarded(e, [&] {
+        vxh::MeshShape sh;
+        e->impl->shape(robot, at_end != 0, sh);
+        const bool none = sh.verts.empty();
+        if (robot_volume) *robot_volume = none ? -1.0 : sh.robot_volume;
+        if (hull_volume) *hull_volume = none ? -1.0 : sh.hull_volume;
+        if (shape_complexity) *shape_complexity = none ? -1.0 : vxh::shape_complexity_as_the_reference_prints_it(e->impl->robot(robot), sh.angle_excess);
+    });
+}
+
 int vxh_inspect_angle_excess(const char* xml, size_t len, int variant, double* out, int capacity, int* count_out, char* errbuf, size_t errcap)
 {
     if (!xml || !count_out || (capacity > 0 && !out) || (variant != VXH_VOXCAD && variant != VXH_VOXCAD_LAND_WATER)) return VXH_ERR_ARG;

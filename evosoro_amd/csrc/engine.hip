@@ -214,6 +214,7 @@ int Engine::append(std::vector<RobotModel>&& built)
 std::vector<RobotModel> Engine::build_vxa(const char* data, size_t len) const
 {
     VxaModel vxa = read_vxa(data, len, variant_);
+    if (shape_descriptors_) vxa.want_mesh = true;
     if (!vxa.unsupported.empty()) {
         std::string msg = "unsupported .vxa feature(s):";
         for (const auto& u : vxa.unsupported) msg += " [" + u + "]";
@@ -247,6 +248,7 @@ std::vector<RobotModel> Engine::build_vxa_files(const std::vector<std::string>& 
                 ss << in.rdbuf();
                 const std::string text = ss.str();
                 VxaModel vxa = read_vxa(text.data(), text.size(), variant_);
+                if (shape_descriptors_) vxa.want_mesh = true;
                 if (!vxa.unsupported.empty()) {
                     std::string msg = "unsupported .vxa feature(s):";
                     for (const auto& u : vxa.unsupported) msg += " [" + u + "]";
@@ -302,6 +304,7 @@ std::vector<RobotModel> Engine::build_models(std::vector<VxaModel>&& models) con
 std::vector<VxaModel> Engine::models_from_arrays(const char* template_vxa, size_t len, const vxh_robot_arrays* in, int n, bool round_like_text) const
 {
     VxaModel base = read_vxa(template_vxa, len, variant_);
+    if (shape_descriptors_) base.want_mesh = true;
     if (!base.unsupported.empty()) {
         std::string msg = "unsupported .vxa feature(s):";
         for (const auto& u : base.unsupported) msg += " [" + u + "]";
@@ -484,6 +487,7 @@ void Engine::check_option(const std::string& key, double value) const
     if (key == "dbg") return;                 // physics-skipping what-if switches: developer library only
 #endif
     if (key == "host_results") return;
+    if (key == "shape_descriptors") { if (value != 0 && value != 1) throw std::invalid_argument("shape_descriptors: 0 or 1"); return; }
     if (key == "steps_per_launch") { if (!(value >= 1 && value <= 200000)) throw std::invalid_argument("steps_per_launch out of range"); return; }
     if (key == "graph_steps") { if (!(value >= 0 && value <= 1e6)) throw std::invalid_argument("graph_steps out of range"); return; }
     if (key == "tiled" || key == "tiles_per_robot" || key == "tile_small" || key == "wide" || key == "wide_two_tiles" || key == "col_cap" || key == "fused" || key == "pair" || key == "pair_sel") {
@@ -520,6 +524,7 @@ void Engine::set_option(const std::string& key, double value)
     if (key == "dbg") { dbg_ = (int)value; dev_->B.dbg = dbg_; drop_graph(); return; }
 #endif
     if (key == "host_results") { host_results_ = value != 0; reduced_downloaded_ = false; }
+    else if (key == "shape_descriptors") shape_descriptors_ = value != 0;      // (robots added FROM NOW ON carry the surface mesh)
     else if (key == "steps_per_launch") steps_per_launch_ = (int)value;
     else if (key == "graph_steps") { graph_steps_ = (int)value; drop_graph(); }
     else {
@@ -1739,6 +1744,17 @@ std::vector<double> Engine::angle_excess(int robot, bool at_end)
     if (H.steps == 0 || (int)H.strain.size() != 6 * M.nvox) mesh_angle_excess(M, nullptr, nullptr, nullptr, out);
     else mesh_angle_excess(M, H.pos.data(), H.quat.data(), H.strain.data(), out);
     return out;
+}
+
+void Engine::shape(int robot, bool at_end, MeshShape& out)
+{
+    const RobotModel& M = robots_[robot];
+    if (!at_end) { mesh_shape(M, nullptr, nullptr, nullptr, out); return; }
+    if (!prepared_) throw std::logic_error("the final mesh requested before vxh_run/vxh_step");
+    if (!state_downloaded_) download();
+    const HostState& H = host_[robot];
+    if (H.steps == 0 || (int)H.strain.size() != 6 * M.nvox) mesh_shape(M, nullptr, nullptr, nullptr, out);
+    else mesh_shape(M, H.pos.data(), H.quat.data(), H.strain.data(), out);
 }
 
 void Engine::bond_modes(long long* large_angle, long long* total)

@@ -58,6 +58,7 @@ public:
     void counters(vxh_counters* out) const { *out = counters_; }
     int cm_trace(int robot, double* out4n, int capacity);      // returns the number of points recorded
     std::vector<double> angle_excess(int robot, bool at_end);  // land_water: discrete curvature of every mesh vertex, rest state / current state
+    void shape(int robot, bool at_end, struct MeshShape& out); // the surface mesh and its descriptors, rest state / current state
     void bond_modes(long long* large_angle, long long* total);   // SmallAngle flags of every bond, downloaded
     void set_option(const std::string& key, double value);
     void check_option(const std::string& key, double value) const;   // throws what set_option would throw, changes nothing
@@ -108,6 +109,8 @@ private:
     // 769-1024 voxels without a surface mesh (1), also instead of <768> for those of 513-768 (2).  OFF by default: bit-identical to <1024>, but
     // measured 20-30 % slower (round 5, DESIGN.md section 4 "Pair path": two wavefronts per SIMD do not hide the latency of a dependent FP64 chain)
     int pair_ = 0;
+    bool shape_descriptors_ = false;           // _voxcad robots added from now on carry the deformable surface mesh (voxelyze --computeShapeDescriptors): they are
+                                               // stepped by the MESH kernel variants, which record the directional strains the final mesh needs
     bool pair_sel_ = false;                    // ... with the rotation-vector factor in select form (kernels.hpp rotvec_factor<SEL>; A/B switch)
     int col_cap_ = 0;                          // partners a contact row can hold; 0 = every other surface voxel (unbounded, like the reference)
     bool tile_small_ = false;                  // also tile large robots the resident kernel could take when the population is small (see prepare())
@@ -139,6 +142,7 @@ public:
     int cm_trace(int robot, double* out4n, int capacity);
     const std::vector<double>& trace_of(int robot);
     std::vector<double> angle_excess(int robot, bool at_end);
+    void shape(int robot, bool at_end, struct MeshShape& out);
     void bond_modes(long long* large_angle, long long* total);
     int n_devices() const { return (int)engines_.size(); }
 
@@ -170,5 +174,9 @@ const std::vector<double>& empty_trace();
 double convex_hull_volume(const std::vector<double>& xyz);   // results.cpp: what stands in for the reference's external qhull
 // results.cpp: per-vertex angle excess of the surface mesh (LW/VX_MeshUtil.cpp:956-1014); pos / quat / strain null = the rest state
 void mesh_angle_excess(const RobotModel& model, const double* pos, const double* quat, const double* strain, std::vector<double>& out);
+// results.cpp: everything CVX_MeshUtil knows of a robot's surface mesh in one state (voxelyzeMain/main.cpp:65-88,113-126): vertex positions,
+// facets (vertex triples), enclosed volume, volume of the convex hull, per-vertex angle excesses
+struct MeshShape { std::vector<double> verts; std::vector<int> facets; double robot_volume = 0, hull_volume = 0; std::vector<double> angle_excess; };
+void mesh_shape(const RobotModel& model, const double* pos, const double* quat, const double* strain, MeshShape& out);
 
 }  // namespace vxh

@@ -213,6 +213,11 @@ std::vector<double> EngineSet::angle_excess(int robot, bool at_end)
     flush_pending(); distribute();
     return engines_[where_[robot].first]->angle_excess(where_[robot].second, at_end);
 }
+void EngineSet::shape(int robot, bool at_end, MeshShape& out)
+{
+    flush_pending(); distribute();
+    engines_[where_[robot].first]->shape(where_[robot].second, at_end, out);
+}
 void EngineSet::bond_modes(long long* large_angle, long long* total)
 {
     flush_pending(); distribute();

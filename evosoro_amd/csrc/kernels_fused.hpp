@@ -866,6 +866,33 @@ __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotSta
 }
 __device__ __forceinline__ void fused_control_horizon(const DRobot& R, DRobotState& rs, FusedCtl& K) { fused_control_horizon(R, rs, K, rs.dt_prev); }
 
+// The same decision in two halves (round 6; k_robot_steps): the control lane stands between barriers (C) and (A) with the whole workgroup
+// waiting for it, so what the decision reads of the control block -- everything but the step's max |v|^2, which the voxel phase is still
+// collecting -- is fetched BEFORE (C), right behind the next step's control (this lane's own stores), and what it leaves is stored without
+// being read back: behind (C) stand one LDS read, a square root, a division and stores instead of six dependent LDS round trips.
+// The arithmetic is step_control_horizon's (kernels.hpp; UpdateCollisions, VX_Sim.cpp:1729-1755), operation for operation: same bits.
+struct HorizonInputs { double max_disp, dt_prev; int go, rebuilds, steps, flags; };
+__device__ __forceinline__ HorizonInputs fused_horizon_prefetch(const DRobotState& rs, const FusedCtl& K)
+{
+    HorizonInputs in;
+    in.max_disp = rs.max_disp; in.dt_prev = rs.dt_prev; in.go = K.go; in.rebuilds = rs.rebuilds; in.steps = rs.steps; in.flags = K.flags;
+    return in;
+}
+__device__ __forceinline__ void fused_horizon_decide(const DRobot& R, DRobotState& rs, FusedCtl& K, const HorizonInputs& in)
+{
+    int rebuild = 0;
+    if (in.go && (R.flags & RF_SELF_COL)) {
+        const double mv = vsqrt_nn(__longlong_as_double((long long)rs.maxvel2_bits));
+        double disp = in.max_disp + fabs(vdiv(mv * in.dt_prev, R.lat));
+        rs.maxvel2_bits = 0ull;
+        if (!(R.flags & RF_HORIZON_COL) || disp > (R.col_horizon - 1.0) / 2) { rebuild = 1; disp = 0.0; rs.rebuilds = in.rebuilds + 1; rs.col_tiled = 0; rs.reb_step = in.steps; }
+        rs.max_disp = disp;
+    }
+    rs.rebuild_now = rebuild;
+    K.rebuild = rebuild;
+    if (rebuild) K.flags = in.flags | 8;
+}
+
 // Dispatch order of SHORT launches (a call of a few dozen steps: one launch, two robots per CU one after the other).  A broad-phase run
 // is ~42 us, a sixth of a 20-step launch, and the launch ends with its slowest CU: with the robots in their fixed list order the last
 // workgroups to be dispatched -- which land on the CUs that a run has already delayed -- bring runs of their own four times out of five
@@ -1265,7 +1292,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
         // X / Y chunks with one Y chunk fewer on this wavefront, 25.2 -> 26.0 us per step: that slot is issue-bound on every SIMD; or
         // during the Z slot, which leaves this wavefront idle, 25.3 -> 25.45: the developer timers show this wavefront last at barrier
         // (C), but the voxel wavefronts sharing its SIMD finish at the same time with or without it.)
-        if (ctl_thread) fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext);
+        HorizonInputs hz = {0.0, 0.0, 0, 0, 0, 0};
+        if (ctl_thread) { fused_control_begin(R, rs, step_cap, it + 1 < iters, Knext); hz = fused_horizon_prefetch(rs, Knext); }
         if ((R.flags & RF_SELF_COL) && !VXH_DBG(2)) {            // SS.MaxVoxVel for the collision horizon (VX_Sim.cpp:1625-1649)
             vel2 = wave_max_nonneg(vel2);       // (DPP: VALU speed)
             if ((tid & 63) == 0) atomicMax(&rs.maxvel2_bits, (unsigned long long)__double_as_longlong(vel2));
@@ -1277,7 +1305,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK + 255) / 256) void k_robot_steps(DBat
             ps[4 * BLOCK + tid] = S.ang.w; ps[5 * BLOCK + tid] = S.ang.x; ps[6 * BLOCK + tid] = S.ang.y; ps[7 * BLOCK + tid] = S.ang.z;
         }
         VXH_T_MARK(5)
-        if (ctl_thread) { fused_control_horizon(R, rs, Knext); s_div = 0; }
+        if (ctl_thread) { fused_horizon_decide(R, rs, Knext, hz); s_div = 0; }
         __syncthreads();                       // (A) control + every voxel's published pose visible
         VXH_T_MARK(0)
     }

@@ -267,7 +267,7 @@ RobotModel build_robot(const VxaModel& vxa)
     }
     r.nsurf = (int)r.surf.size();
 
-    if (m.variant == 1) {   // deformable surface mesh (fluid drag; RobotVolume tags of every land_water robot)
+    if (m.want_mesh) {      // deformable surface mesh (fluid drag; RobotVolume tags of every land_water robot; _voxcad: --computeShapeDescriptors)
         const int tx = nx + 1, ty = ny + 1, tz = nz + 1;
         std::vector<std::vector<int>> comps((size_t)tx * ty * tz);
         auto d3 = [&](int X, int Y, int Z) { return (size_t)Z * tx * ty + (size_t)Y * tx + X; };

@@ -236,6 +236,17 @@ double robot_hull_volume(const RobotModel& M, const double* pos, const double* q
     return convex_hull_volume(vert);
 }
 
+void mesh_shape(const RobotModel& M, const double* pos, const double* quat, const double* strain, MeshShape& out)
+{
+    out = MeshShape();
+    if (M.nmv == 0) return;
+    mesh_vertices(M, pos, quat, strain, out.verts);
+    out.facets.assign(M.facet_vert.begin(), M.facet_vert.end());
+    out.robot_volume = robot_volume(M, pos, quat, strain);
+    out.hull_volume = robot_hull_volume(M, pos, quat, strain);
+    mesh_angle_excess(M, pos, quat, strain, out.angle_excess);
+}
+
 void compute_result(const RobotModel& M, const HostState& S, vxh_result* r)
 {
     std::memset(r, 0, sizeof(*r));

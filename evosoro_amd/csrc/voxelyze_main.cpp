@@ -1,7 +1,7 @@
 // `voxelyze` command line, drop-in for the reference headless simulator
 // (evosoro/_voxcad/voxelyzeMain/main.cpp:9-133; land_water: evosoro/_voxcad_land_water/voxelyzeMain/main.cpp).
 //   voxelyze -f <file.vxa> [-f <more.vxa> ...] [--list <file with one .vxa path per line>] [-p]
-//            [--land-water] [--device N | --devices N,M,...] [--computeShapeDescriptors (accepted, ignored)]
+//            [--land-water] [--device N | --devices N,M,...] [--computeShapeDescriptors (with -p and one file: the reference's console report of the surface mesh)]
 //            [--direct | --broker | --broker-stat | --broker-quit]
 // Writes each robot's result XML to the <FitnessFileName> of its .vxa.  Exit code follows the reference's
 // inverted convention: 1 = completed, 0 = failed (main.cpp:28,57,132).  Several -f / --list entries are
@@ -144,12 +144,53 @@ int connect_to(const std::string& path)
 }
 
 // ---- one robot (or several) stepped by this process: the round-1..3 command line
-int run_direct(const std::vector<std::string>& files, int variant, std::vector<int> devices, bool print_scrn)
+// What the reference prints of its deformable surface mesh under -p --computeShapeDescriptors (voxelyzeMain/main.cpp:72-88,113-126:
+// mesh size, robot volume, convex-hull volume, shape complexity, then CVX_MeshUtil::printAllMeshInfo, VX_MeshUtil.cpp:733-772: vertices,
+// facets as vertex triples, facet normals = the normalised cross product of two edges, Utils/Mesh.cpp:585-591), in the stream's default
+// six significant digits.  The hull volume is computed here; the reference needs the external `qhull` and prints -1 without it.
+void print_shape(vxh_engine* e, bool at_end)
+{
+    int nv = 0, nf = 0;
+    if (vxh_get_mesh(e, 0, at_end ? 1 : 0, nullptr, 0, &nv, nullptr, 0, &nf) != VXH_OK) return;
+    std::vector<double> vert((size_t)3 * (nv > 0 ? nv : 1));
+    std::vector<int> fac((size_t)3 * (nf > 0 ? nf : 1));
+    if (vxh_get_mesh(e, 0, at_end ? 1 : 0, vert.data(), nv, &nv, fac.data(), nf, &nf) != VXH_OK) return;
+    double vol = -1, hull = -1, cplx = -1;
+    vxh_get_shape_descriptors(e, 0, at_end ? 1 : 0, &vol, &hull, &cplx);
+    const char* when = at_end ? "Final" : "Init";
+    if (!at_end) std::cout << "Robot mesh has " << nv << " vertices and " << nf << " facets" << std::endl;
+    std::cout << when << " robot volume: " << vol << std::endl
+              << when << " convex hull volume: " << hull << std::endl << std::endl
+              << when << " shape complexity: " << cplx << std::endl;
+    const char* bar = " -----------------------------------------------------------";
+    std::cout << bar << std::endl << "| \t\tPRINTING DEFORMABLE MESH VERTICES \t\t\t\t  |" << std::endl << bar << std::endl;
+    for (int i = 0; i < nv; ++i) std::cout << vert[(size_t)3 * i] << " " << vert[(size_t)3 * i + 1] << " " << vert[(size_t)3 * i + 2] << std::endl;
+    std::cout << bar << std::endl;
+    std::cout << " ---------------------------------------------------------------------" << std::endl
+              << "| \tPRINTING DEFORMABLE MESH FACETS (TERNS OF VERTICES INDICES) \t|" << std::endl
+              << " ---------------------------------------------------------------------" << std::endl;
+    for (int f = 0; f < nf; ++f) std::cout << fac[(size_t)3 * f] << " " << fac[(size_t)3 * f + 1] << " " << fac[(size_t)3 * f + 2] << std::endl;
+    std::cout << bar << std::endl;
+    std::cout << bar << std::endl << "| \t\tPRINTING DEFORMABLE MESH NORMALS \t\t\t\t  |" << std::endl << bar << std::endl;
+    for (int f = 0; f < nf; ++f) {
+        const double* a = &vert[(size_t)3 * fac[(size_t)3 * f]]; const double* b = &vert[(size_t)3 * fac[(size_t)3 * f + 1]]; const double* c = &vert[(size_t)3 * fac[(size_t)3 * f + 2]];
+        const double ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2], wx = c[0] - a[0], wy = c[1] - a[1], wz = c[2] - a[2];
+        double nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+        const double l = std::sqrt(nx * nx + ny * ny + nz * nz);
+        if (l > 0) { nx /= l; ny /= l; nz /= l; }      // (Vec3D::Normalized: a null vector stays null)
+        std::cout << nx << " " << ny << " " << nz << std::endl;
+    }
+    std::cout << bar << std::endl;
+}
+
+int run_direct(const std::vector<std::string>& files, int variant, std::vector<int> devices, bool print_scrn, bool shape = false)
 {
     vxh_engine* e = nullptr;
     if (devices.empty()) devices.push_back(0);
     int rc = vxh_create_multi(&e, variant, devices.data(), (int)devices.size());     // several devices: the batch is partitioned by cost
     if (rc != VXH_OK) { std::fprintf(stderr, "voxelyze: %s\n", vxh_strerror(rc)); return 0; }
+    shape = shape && print_scrn && files.size() == 1;      // (_voxcad: the descriptors only ever reach the console, main.cpp:72-88 -- the result file has no such tags)
+    if (shape) vxh_set_option(e, "shape_descriptors", 1);
     for (const std::string& f : files) {
         rc = vxh_add_vxa_file(e, f.c_str(), nullptr);
         if (rc != VXH_OK) {
@@ -175,6 +216,7 @@ int run_direct(const std::vector<std::string>& files, int variant, std::vector<i
         std::cout << "\nImporting Environment into simulator...\n" << "Simulation import return message:\n";
         if (nbond > 0) std::cout << "At least one bond creation failed during import.\n";
         std::cout << "Completed Simulation Import: " << nvox << " Voxels, " << nbond << "Bonds.\n" << "\n";
+        if (shape) print_shape(e, false);
         for (long long done = 0;; done += 100) {
             if (done > 0) { rc = vxh_step(e, 100); if (rc != VXH_OK) break; }
             if (nvox == 0) { rc = vxh_run(e); break; }
@@ -194,6 +236,7 @@ int run_direct(const std::vector<std::string>& files, int variant, std::vector<i
             std::cout << "Vox[0]  TempPer: " << (float)per << std::endl;
             std::cout << "Vox[0]  phaseOffset: " << (float)ph << std::endl;
         }
+        if (rc == VXH_OK && shape) print_shape(e, true);
         if (rc == VXH_OK) { vxh_get_result(e, 0, &res); std::cout << "Ended at: " << res.cur_time << std::endl; }
     } else
         rc = vxh_run(e);
@@ -394,7 +437,7 @@ int run_through_broker(const std::string& file, int variant, const char* self)
 int main(int argc, char* argv[])
 {
     std::vector<std::string> files;
-    bool print_scrn = false, direct = false, broker = false;
+    bool print_scrn = false, direct = false, broker = false, shape = false;
     int variant = VXH_VOXCAD;
     std::vector<int> devices;
     std::string control;
@@ -409,7 +452,7 @@ int main(int argc, char* argv[])
         else if (!std::strcmp(argv[i], "-p")) print_scrn = true;
         else if (!std::strcmp(argv[i], "--land-water")) variant = VXH_VOXCAD_LAND_WATER;
         else if ((!std::strcmp(argv[i], "--device") || !std::strcmp(argv[i], "--devices")) && i + 1 < argc) devices = parse_devices(argv[++i]);
-        else if (!std::strcmp(argv[i], "--computeShapeDescriptors")) {}
+        else if (!std::strcmp(argv[i], "--computeShapeDescriptors")) shape = true;
         else if (!std::strcmp(argv[i], "--direct")) direct = true;
         else if (!std::strcmp(argv[i], "--broker")) broker = true;
         else if (!std::strcmp(argv[i], "--broker-quit")) control = "QUIT";
@@ -437,5 +480,5 @@ int main(int argc, char* argv[])
             std::fprintf(stderr, "voxelyze: no broker reachable at %s; stepping in this process\n", socket_path().c_str());
         }
     }
-    return run_direct(files, variant, devices, print_scrn);
+    return run_direct(files, variant, devices, print_scrn, shape);
 }

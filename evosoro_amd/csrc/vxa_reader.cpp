@@ -233,6 +233,7 @@ VxaModel read_vxa(const char* data, size_t len, int variant)
         if (const XmlNode* f = ga->child("FitnessFileName")) m.fitness_file_name = f->text;
         if (const XmlNode* f = ga->child("CurvaturesTmpFile")) m.curvatures_tmp_file = f->text;
     }
+    m.want_mesh = m.variant == 1;
     if (!(m.stop_type >= 0 && m.stop_type <= 3)) m.unsupported.push_back("StopConditionType>3");
 
     // ---- Environment (VX_Environment.cpp:123-234; LW/VX_Environment.cpp:190-191)

@@ -30,6 +30,8 @@ struct Material {
 // everything of a .vxa that reaches the time-stepper
 struct VxaModel {
     int variant = 0;                    // 0 _voxcad, 1 _voxcad_land_water
+    bool want_mesh = false;             // build the deformable surface mesh (every land_water robot: fluid drag, RobotVolume tags; a _voxcad robot of an engine
+                                        // with option shape_descriptors: what voxelyzeMain/main.cpp:65-88,113-126 computes under --computeShapeDescriptors)
     // Simulator
     double dt_frac = 0.9, bond_damping_z = 0.1, col_damping_z = 1.0, slow_damping_z = 0.001;
     bool self_col_enabled = false;

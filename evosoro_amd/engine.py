@@ -16,7 +16,7 @@ CLI_PATH = os.path.join(_HERE, "voxelyze")
 VOXCAD, VOXCAD_LAND_WATER = 0, 1
 ROBOT_PENDING, ROBOT_FINISHED, ROBOT_DIVERGED, ROBOT_EMPTY, ROBOT_COL_OVERFLOW = 0, 1, 2, 3, 4
 
-EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_inspect_constants", "vxh_inspect_angle_excess", "vxh_get_angle_excess", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_create_multi", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims", "vxh_voxel_actuation",
+EXPORTS = ["vxh_inspect_vxa_buffer", "vxh_inspect_constants", "vxh_inspect_angle_excess", "vxh_get_angle_excess", "vxh_get_mesh", "vxh_get_shape_descriptors", "vxh_plan_tiles_buffer", "vxh_convex_hull_volume", "vxh_create", "vxh_create_multi", "vxh_destroy", "vxh_add_vxa_file", "vxh_add_vxa_buffer", "vxh_add_vxa_files", "vxh_add_robots", "vxh_num_robots", "vxh_robot_dims", "vxh_voxel_actuation",
            "vxh_run", "vxh_step", "vxh_reset", "vxh_clear", "vxh_get_result", "vxh_write_result_xml",
            "vxh_fitness_file_name", "vxh_get_state", "vxh_get_cm_trace", "vxh_get_counters", "vxh_count_bond_modes", "vxh_set_option", "vxh_strerror",
            "vxh_last_error", "vxh_version", "vxh_device_count"]
@@ -115,6 +115,9 @@ def load_library():
         lib.vxh_inspect_constants.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, P, I, P, I, ctypes.c_char_p, ctypes.c_size_t]
         lib.vxh_inspect_angle_excess.argtypes = [ctypes.c_char_p, ctypes.c_size_t, I, P, I, ctypes.POINTER(I), ctypes.c_char_p, ctypes.c_size_t]
         lib.vxh_get_angle_excess.argtypes = [P, I, I, P, I, ctypes.POINTER(I)]
+    if hasattr(lib, "vxh_get_mesh"):
+        lib.vxh_get_mesh.argtypes = [P, I, I, P, I, ctypes.POINTER(I), P, I, ctypes.POINTER(I)]
+        lib.vxh_get_shape_descriptors.argtypes = [P, I, I, ctypes.POINTER(D), ctypes.POINTER(D), ctypes.POINTER(D)]
     lib.vxh_convex_hull_volume.argtypes = [ctypes.POINTER(ctypes.c_double), I]
     lib.vxh_convex_hull_volume.restype = D
     lib.vxh_create.argtypes = [ctypes.POINTER(P), I, I]
@@ -369,6 +372,21 @@ class Engine(object):
         out = np.zeros(max(count.value, 1))
         self._check(self._lib.vxh_get_angle_excess(self._h, robot, 1 if at_end else 0, out.ctypes.data, count.value, ctypes.byref(count)))
         return out[:count.value]
+
+    def mesh(self, robot, at_end=True):
+        """(vertices [n, 3], facets [m, 3]) of the robot's deformable surface mesh (land_water robots; _voxcad robots added under the option
+        shape_descriptors): rest state or current state, in the reference's vertex and facet order"""
+        nv, nf = ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.vxh_get_mesh(self._h, robot, 1 if at_end else 0, None, 0, ctypes.byref(nv), None, 0, ctypes.byref(nf)))
+        verts, facets = np.zeros((max(nv.value, 1), 3)), np.zeros((max(nf.value, 1), 3), dtype=np.int32)
+        self._check(self._lib.vxh_get_mesh(self._h, robot, 1 if at_end else 0, verts.ctypes.data, nv.value, ctypes.byref(nv), facets.ctypes.data, nf.value, ctypes.byref(nf)))
+        return verts[:nv.value], facets[:nf.value]
+
+    def shape_descriptors(self, robot, at_end=True):
+        """(robot volume, convex-hull volume, shape complexity as the reference binary prints it) of that mesh; -1 each without a mesh"""
+        vol, hull, cplx = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.vxh_get_shape_descriptors(self._h, robot, 1 if at_end else 0, ctypes.byref(vol), ctypes.byref(hull), ctypes.byref(cplx)))
+        return vol.value, hull.value, cplx.value
 
     def bond_modes(self):
         """(bonds in the large-angle branch, bonds) of the whole batch right now"""

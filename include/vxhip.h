@@ -86,6 +86,17 @@ typedef struct vxh_result {
  * vxh_write_result_xml also writes the final vector to the robot's <CurvaturesTmpFile>, tab-separated, six significant digits. */
 int  vxh_get_angle_excess(const vxh_engine* e, int robot, int at_end, double* out, int capacity, int* count_out);
 /* ... of the rest state straight from a .vxa text, host-only (no GPU needed) */
+/* The deformable surface mesh of a robot that carries one -- every land_water robot; a _voxcad robot added to an engine whose option
+ * "shape_descriptors" was 1 -- and what CVX_MeshUtil derives from it: what voxelyzeMain/main.cpp:65-88,113-126 computes and, under -p,
+ * prints with --computeShapeDescriptors (computeAndStoreQHullStart/End, computeAndStoreRobotVolumeStart/End,
+ * computeInitial/FinalShapeComplexity, printAllMeshInfo; VX_MeshUtil.cpp:733-772,775-1076).  at_end 0 = the rest state right after the
+ * import, 1 = the current state.  vxh_get_mesh: vertex positions (v + DrawOffset) in the reference's vertex order, facets as vertex
+ * triples in its facet order; counts are returned even when the capacities are 0.  vxh_get_shape_descriptors: enclosed volume (signed
+ * tetrahedra), volume of the convex hull of the vertices (own incremental hull where the reference shells out to qhull), and the
+ * shape complexity AS THE REFERENCE BINARY PRINTS IT (see vxh_get_angle_excess: the first vertex's angle excess; -1 without a
+ * <CurvaturesTmpFile>).  A robot without a mesh: counts 0, descriptors -1. */
+int  vxh_get_mesh(const vxh_engine*, int robot, int at_end, double* verts3, int vert_capacity, int* n_verts, int* facets3, int facet_capacity, int* n_facets);
+int  vxh_get_shape_descriptors(const vxh_engine*, int robot, int at_end, double* robot_volume, double* hull_volume, double* shape_complexity);
 int  vxh_inspect_angle_excess(const char* xml, size_t len, int variant, double* out, int capacity, int* count_out, char* errbuf, size_t errcap);
 /* volume of the convex hull of n points (x, y, z per point): the computation behind hull_volume_*, exposed for testing */
 double vxh_convex_hull_volume(const double* xyz, int n);
@@ -207,8 +218,9 @@ int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long 
  *                       oversized class tables) are stepped by the multi-workgroup kernel; 2 = every robot it supports (tests).
  *                       With the default, which kernel steps a robot depends on the robot alone, so its result is the same, bit for
  *                       bit, whatever batch it is in.
- *   "tile_small"        1 = also tile large robots (more than 512 voxels) when the population occupies at most a quarter of the CUs:
- *                       6-14 % faster there (64 or fewer robots of 10x10x10 per GPU), at the price that such a robot's last bits then
+ *   "tile_small"        1 = also tile large robots (more than 512 voxels) when the population occupies at most a quarter of the CUs
+ *                       (measured in round 6 on one 64-robot shard of the bench population: 14.0 us per step against 12.0 with the default
+ *                       kernels -- it no longer pays there; kept for A/B), at the price that such a robot's last bits then
  *                       depend on the population it is evaluated in (the two kernels agree to 1e-12 voxel, not to the bit).  Default 0.
  *   "tiles_per_robot"   > 0 requests a tile count (tests).
  *   "wide"              1 (default) = robots of up to 512 voxels and 1023 bonds are stepped by the wide kernel (one lane per bond, all
@@ -233,6 +245,9 @@ int  vxh_count_bond_modes(const vxh_engine* e, long long* large_angle_out, long 
  *                       small n is paid for: 20 steps at a time run at ~35 us per step where 1000 at a time run at ~30.5 (512 robots
  *                       of 10x10x10).
  *   "graph_steps"       streaming kernels: step rounds per captured hipGraph (0 = plain launches)
+ *   "shape_descriptors" 1 = _voxcad robots added FROM NOW ON carry the deformable surface mesh land_water robots always carry (they are stepped
+ *                       by the kernel variants that record the directional strains the deformed mesh needs): vxh_get_mesh /
+ *                       vxh_get_shape_descriptors then answer for them -- `voxelyze --computeShapeDescriptors`.  Default 0.
  *   "host_results"      1 = vxh_get_result evaluates every tag on the host from the downloaded voxel state instead of from the
  *                       device-side reductions (cross-checks; the numbers are the same) */
 int  vxh_set_option(vxh_engine* e, const char* key, double value);

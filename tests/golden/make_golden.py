@@ -218,6 +218,9 @@ def main():
         if name == "soft5_init0":       # what the reference prints with -p (voxelyzeMain/main.cpp:60-63,92-104,128): the CLI's only diagnostic
             with open(os.path.join(exp_dir, name + ".p.txt"), "wb") as f:
                 subprocess.run(["timeout", "900", refbin[case["variant"]], "-f", vxa, "-p"], check=False, stdout=f, stderr=subprocess.DEVNULL)
+            # ... and with -p --computeShapeDescriptors (main.cpp:65-88,113-126: mesh size, volumes, shape complexity, printAllMeshInfo before and after the run)
+            with open(os.path.join(exp_dir, name + ".pcsd.txt"), "wb") as f:
+                subprocess.run(["timeout", "900", refbin[case["variant"]], "-f", vxa, "-p", "--computeShapeDescriptors"], check=False, stdout=f, stderr=subprocess.DEVNULL)
         if case.get("early", True):     # (skipped for the 10^3 robots: 700 voxels x 9 snapshots would be 0.7 MB each)
             subprocess.run(["timeout", "900", probe[case["variant"]], "-f", vxa, "-o",
                             os.path.join(exp_dir, name + ".early.bin"), "-max", "200", "-every", "25", "-noresult"],

@@ -182,6 +182,50 @@ def test_cli_progress_output_is_the_references(eng_mod, golden_dir, tmp_path):
         len(os.listdir(tmp_path / "golden_run" / "fitnessFiles")) == 1
 
 
+def test_cli_shape_descriptor_report_is_the_references(eng_mod, golden_dir, tmp_path):
+    """`voxelyze -f x.vxa -p --computeShapeDescriptors` (round 6): what the reference's _voxcad command line computes and prints of its
+    deformable surface mesh (voxelyzeMain/main.cpp:65-88,113-126; CVX_MeshUtil::printAllMeshInfo, VX_MeshUtil.cpp:733-772): mesh size,
+    robot volume, shape complexity, every vertex, every facet (vertex triple) and every facet normal -- right after the import and again
+    after the run.  Golden: the reference binary's own stdout for the same file (tests/golden/expected/soft5_init0.pcsd.txt, make_golden.py).
+    Text and integers equal; numbers to the six digits the stream prints (1.5e-6 relative, 1e-9 absolute: a normal's zero component is
+    rounding noise around 1e-16 on both sides); the lines the reference's missing `qhull` produces are skipped, and where it prints
+    -1 for the hull volume the engine prints the hull it computes (>= the robot's own volume)."""
+    import subprocess
+    for d in ("fitnessFiles", "tempFiles"):
+        os.makedirs(tmp_path / "golden_run" / d)
+    proc = subprocess.run([eng_mod.CLI_PATH, "-f", os.path.join(golden_dir, "vxa", "soft5_init0.vxa"), "-p", "--computeShapeDescriptors"], cwd=tmp_path,
+                          timeout=600, stdout=subprocess.PIPE)
+    assert proc.returncode == 1
+    got = proc.stdout.decode().splitlines()
+    noise = ("CVX_MeshUtil ERROR", "ERROR: CVX_MeshUtil", "[V_MeshUtil.cpp]", "WARNING: CVX_MeshUtil")
+    want = [ln for ln in open(os.path.join(golden_dir, "expected", "soft5_init0.pcsd.txt")).read().splitlines() if not ln.startswith(noise)]
+    assert len(got) == len(want), (len(got), len(want), got[:14])
+    assert want[6].startswith("Robot mesh has 205 vertices and 444 facets") and sum(1 for ln in want if "PRINTING DEFORMABLE MESH" in ln) == 6
+    volumes = {}
+    for k, (g, w) in enumerate(zip(got, want)):
+        if "convex hull volume: " in w:
+            assert g.split(": ")[0] == w.split(": ")[0] and float(w.split(": ")[1]) == -1.0     # (no qhull on the box that made the golden file)
+            volumes[g.split(" ")[0] + " hull"] = float(g.split(": ")[1])
+            continue
+        if ": " in w and w.split(": ")[0] in ("Time", "CM", "Vox[0]  Scale", "Vox[0]  TempAmp", "Vox[0]  TempPer", "Vox[0]  phaseOffset", "Ended at",
+                                              "Init robot volume", "Final robot volume", "Init shape complexity", "Final shape complexity"):
+            assert g.split(": ")[0] == w.split(": ")[0], (k, g, w)
+            a, b = float(g.split(": ")[1]), float(w.split(": ")[1])
+            assert abs(a - b) <= 1.5e-6 * abs(b) + 1e-12, (k, g, w)
+            if "robot volume" in w:
+                volumes[w.split(" ")[0] + " robot"] = a
+            continue
+        gt, wt = g.split(), w.split()
+        if len(wt) == 3 and all(t.lstrip("-").isdigit() for t in wt):       # a facet: three vertex indices
+            assert gt == wt, (k, g, w)
+        elif len(wt) == 3 and not w.startswith(("|", " -")):                # a vertex or a normal
+            for a, b in zip(map(float, gt), map(float, wt)):
+                assert abs(a - b) <= 1.5e-6 * abs(b) + 1e-9, (k, g, w)
+        else:
+            assert g == w, (k, g, w)
+    assert volumes["Init hull"] >= volumes["Init robot"] * (1 - 1e-9) > 0 and volumes["Final hull"] >= volumes["Final robot"] * (1 - 1e-9) > 0
+
+
 def test_options_changed_between_runs_of_one_engine(eng_mod, golden_dir):
     """A captured step graph holds the kernel arguments of the moment of capture: switching the stepping kernels on ONE engine
     between runs (streaming with a graph -> resident -> streaming again) must leave nothing stale behind -- the streaming runs
