@@ -460,6 +460,22 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     }
     int my_ff = 0, my_fc = 0;                 // fluid: my voxel's facets among the tile's
     if (valid && fluid) { my_ff = B.tile_ffirst[T.vox_off + tid]; my_fc = (int)B.tile_fcount[T.vox_off + tid]; }
+    // The voxel update on TWO wavefronts (round 6) when one wavefront holds all the tile's voxels (the 4x4x4 tiles of configs[4], the tiles
+    // of a swimmer above 1024 voxels): translation -- force sum, contacts, floor, linear integration: voxel_update_lin -- on thread i,
+    // rotation + actuation -- moment sum, quaternion update, new scale: voxel_update_ang -- on thread 64 + i, whose wavefront would idle;
+    // the two halves never read each other's results within a step (voxel_update is one behind the other: same operations, same bits) and
+    // each keeps its momentum in registers and publishes its part of the pose.  (Round 3 measured this split slower -- with 236-368 bytes of
+    // scratch per lane, whose reloads queued behind the publication's write-through stores; the kernel has no scratch any more.)
+    const bool split = n_own <= 64;
+    const int av = split ? tid - 64 : tid;                         // the voxel whose rotation half this thread runs
+    const bool do_ang = split ? (tid >= 64 && av < n_own) : valid;
+    const int gva = do_ang ? (split ? B.tile_vox[T.vox_off + av] : gv) : R.vox_begin;
+    const DVoxClass& Ca = vct[do_ang ? B.vclass[gva] : 0];
+    if (split) {
+        am = mk3(0, 0, 0);
+        if (do_ang) { am = mk3(ANGMOM(0, gva), ANGMOM(1, gva), ANGMOM(2, gva)); amp_damp = B.amp_damp[gva]; }
+    }
+    const int xs_ang = T.xoff + av;           // exchange slot of that voxel
     d3 lm_bak = lm, am_bak = am;              // momenta before the last committed voxel phase (a diverged step is undone)
     // the halo voxels are spread over the worker threads from the last one down: wave 0, which owns the first voxels, gets them last
     const int hslot0 = BLOCK - 1 - tid;
@@ -796,50 +812,67 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
             double vel2 = 0;
             const unsigned tagn = tile_tag(gen, ep, it + 2);
             VXH_TV_BEGIN
-            if (valid) {
-                // the six bond forces in the order of the fused kernel of the robot's size class: up to 768 voxels the bonds in which
-                // the voxel is the negative end first (+X +Y +Z), then those in which it is the positive end; above, +X -X +Y -Y +Z -Z
-                // (all 36 values requested before the first sum, ONE branch on the order: with the order chosen per component the compiler
-                // emitted six load-wait-branch-add rounds, 1.2 k cycles of a 5.4 k-cycle phase -- round 6)
-                double a6[6], pq[6][6];
+            // the six bond forces / moments in the order of the fused kernel of the robot's size class: up to 768 voxels the bonds in which the
+            // voxel is the negative end first (+X +Y +Z), then those in which it is the positive end; above, +X -X +Y -Y +Z -Z.  (All 18 values
+            // requested before the first sum, ONE branch on the order: with the order chosen per component the compiler emitted six
+            // load-wait-branch-add rounds, 1.2 k cycles of a 5.4 k-cycle phase -- round 6)
+            auto six_sums = [&](int c0, int vox) {
+                double pq[6][3];
 #pragma unroll
                 for (int d = 0; d < 6; ++d)
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) pq[d][c] = pl[(6 * d + c) * no + tid];
+                    for (int c = 0; c < 3; ++c) pq[d][c] = pl[(6 * d + c0 + c) * no + vox];
+                d3 out;
                 if (R.nvox <= 768) {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) a6[c] = ((pq[0][c] + pq[2][c]) + pq[4][c]) + ((pq[1][c] + pq[3][c]) + pq[5][c]);
+                    out = mk3(((pq[0][0] + pq[2][0]) + pq[4][0]) + ((pq[1][0] + pq[3][0]) + pq[5][0]), ((pq[0][1] + pq[2][1]) + pq[4][1]) + ((pq[1][1] + pq[3][1]) + pq[5][1]),
+                              ((pq[0][2] + pq[2][2]) + pq[4][2]) + ((pq[1][2] + pq[3][2]) + pq[5][2]));
                 } else {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) a6[c] = ((((pq[0][c] + pq[1][c]) + pq[2][c]) + pq[3][c]) + pq[4][c]) + pq[5][c];
+                    out = mk3(((((pq[0][0] + pq[1][0]) + pq[2][0]) + pq[3][0]) + pq[4][0]) + pq[5][0], ((((pq[0][1] + pq[1][1]) + pq[2][1]) + pq[3][1]) + pq[4][1]) + pq[5][1],
+                              ((((pq[0][2] + pq[1][2]) + pq[2][2]) + pq[3][2]) + pq[4][2]) + pq[5][2]);
                 }
-                d3 F = mk3(a6[0], a6[1], a6[2]), M = mk3(a6[3], a6[4], a6[5]);
+                return out;
+            };
+            if (valid) {
+                // ---- translation half: voxel_update_lin (kernels.hpp; CVXS_Voxel::EulerStep / CalcTotalForce, VXS_Voxel.cpp:169-427)
+                d3 F = six_sums(0, tid);
                 VXH_TV(0)
-                VoxState S;
-                S.pos = mk3(ps[tid], ps[np + tid], ps[2 * np + tid]); S.scale = ps[3 * np + tid];
-                S.ang = mkq(ps[4 * np + tid], ps[5 * np + tid], ps[6 * np + tid], ps[7 * np + tid]);
-                S.lm = lm; S.am = am;
+                d3 pos = mk3(ps[tid], ps[np + tid], ps[2 * np + tid]);
+                const double scale = ps[3 * np + tid];
+                d3 lmv = lm;
                 if (!diverged_here) {
-                    const d3 vel = S.lm * C.mass_inv;
+                    const d3 vel = lmv * C.mass_inv;
                     F = F + (vel * (-R.slow_z)) * C.c_lin;
                     const FetchTile fetch{ps, px, np, tid, codes_live, pose};
+                    VoxState S; S.pos = pos; S.scale = scale;
                     F = tile_contacts(B, R, fetch, F, S, gv, row, ccnt, roff, rc_code, rc_a1);
                     VXH_TV(1)
-                    vel2 = voxel_update(B, R, C, gv, pose, K.time, K.act_sin, K.act_cos, K.prenatal_c, F, M, vel, S, row, 0, FLUID, drag,
-                                        pht[tid], pht[no + tid], amp_damp);
+                    vel2 = voxel_update_lin(B, R, C, gv, pose, F, vel, pos, lmv, scale, row, 0, FLUID, drag);
                 }
                 VXH_TV(2)
-                lm_new = S.lm; am_new = S.am;
+                lm_new = lmv;
                 // out at once: the neighbours' next bond phase waits for exactly these granules (the pose tile keeps the old pose until
                 // every voxel of the tile has read its contact partners, and until the step is known to stand)
-                p8[0] = S.pos.x; p8[1] = S.pos.y; p8[2] = S.pos.z; p8[3] = S.scale; p8[4] = S.ang.w; p8[5] = S.ang.x; p8[6] = S.ang.y; p8[7] = S.ang.z;
+                p8[0] = pos.x; p8[1] = pos.y; p8[2] = pos.z;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_own, nx, p8[k], tagn);
+                for (int k = 0; k < 3; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_own, nx, p8[k], tagn);
                 if constexpr (xstrain) {       // ... and the strains this step's bonds left: the next step's mesh is built from them
 #pragma unroll
                     for (int k = 0; k < 6; ++k) st_gran2(xqn + (size_t)(16 + 2 * k) * nx + xs_own, nx, sl[k * no + tid], tagn);
                 }
                 VXH_TV(3)
+            }
+            if (do_ang) {
+                // ---- rotation half: voxel_update_ang (angular integration, quaternion update, actuation -> new scale)
+                const d3 M = six_sums(3, av);
+                double scale = ps[3 * np + av];
+                dq ang = mkq(ps[4 * np + av], ps[5 * np + av], ps[6 * np + av], ps[7 * np + av]);
+                d3 amv = am;
+                if (!diverged_here)
+                    voxel_update_ang(B, R, Ca, gva, K.time, K.act_sin, K.act_cos, K.prenatal_c, M, amv, ang, scale, pht[av], pht[no + av], amp_damp);
+                am_new = amv;
+                p8[3] = scale; p8[4] = ang.w; p8[5] = ang.x; p8[6] = ang.y; p8[7] = ang.z;
+#pragma unroll
+                for (int k = 3; k < 8; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_ang, nx, p8[k], tagn);
             }
             if (tid < 64 * nvw) {
                 // the tile's max |v|^2 goes out with the last wavefront to finish its voxels, not behind the workgroup barrier (only the
@@ -907,7 +940,11 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         lm = lm_new; am = am_new;
         if (valid) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ps[k * np + tid] = p8[k];
+            for (int k = 0; k < 3; ++k) ps[k * np + tid] = p8[k];
+        }
+        if (do_ang) {
+#pragma unroll
+            for (int k = 3; k < 8; ++k) ps[k * np + av] = p8[k];
         }
         ring = ringn;
         (void)ringp;
@@ -941,12 +978,13 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         SCALE(b1, gv) = ps[3 * np + tid];
         QUAT(0, gv) = ps[4 * np + tid]; QUAT(1, gv) = ps[5 * np + tid]; QUAT(2, gv) = ps[6 * np + tid]; QUAT(3, gv) = ps[7 * np + tid];
         LINMOM(0, gv) = lm.x; LINMOM(1, gv) = lm.y; LINMOM(2, gv) = lm.z;
-        ANGMOM(0, gv) = am.x; ANGMOM(1, gv) = am.y; ANGMOM(2, gv) = am.z;
+        if (!split) { ANGMOM(0, gv) = am.x; ANGMOM(1, gv) = am.y; ANGMOM(2, gv) = am.z; }
         if constexpr (mesh) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) B.strain[(unsigned)k * nv + (unsigned)gv] = sl[k * no + tid];
         }
     }
+    if (split && do_ang) { ANGMOM(0, gva) = am.x; ANGMOM(1, gva) = am.y; ANGMOM(2, gva) = am.z; }
     for (int b = tid; b < nb; b += NT) {
         if ((bent[b] & 1023) >= n_own) continue;                  // a bond is written back by the tile that owns its negative end
         const int slot = B.tile_bslot[T.bond_off + b];

@@ -66,7 +66,7 @@ std::string socket_path()
 {
     if (const char* p = std::getenv("VXH_BROKER_SOCKET")) if (*p) return p;
     std::string dir;
-    if (const char* x = std::getenv("XDG_RUNTIME_DIR")) { struct stat st; if (*x && ::stat(x, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == getuid() && ::access(x, W_OK) == 0) dir = x; }
+    if (const char* x = std::getenv("XDG_RUNTIME_DIR")) { struct stat st; if (*x && ::stat(x, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & 077) == 0 && ::access(x, W_OK) == 0) dir = x; }   // (0700 like the fallback: advisor, round 5)
     if (dir.empty()) {
         dir = "/tmp/vxhip-" + std::to_string((long)getuid());
         ::mkdir(dir.c_str(), 0700);
@@ -391,6 +391,7 @@ bool spawn_broker(const std::string& path, const char* self)
                 const int log = (logp && *logp) ? ::open(logp, O_CREAT | O_WRONLY | O_APPEND, 0600) : -1;
                 if (devnull >= 0) { ::dup2(devnull, 0); ::dup2(devnull, 1); ::dup2(log >= 0 ? log : devnull, 2); }
                 ::close(lk);
+                ::setenv("VXH_BROKER_SOCKET", path.c_str(), 1);   // (the broker listens where THIS client will look, whatever it would compute itself: a binary replaced in between -- advisor, round 5)
                 ::execl(self, self, "--broker", (char*)nullptr);
                 ::_exit(127);
             }
