@@ -1,7 +1,7 @@
 """GPU parity ledger (-m gpu): every golden case of tests/golden/manifest.json run to its stop condition on the engine, once per
 kernel path, and the outcome WRITTEN DOWN -- steps, the spread the reference algorithm itself shows under a one-ulp perturbation,
 the tolerance that follows from it, the error actually achieved against the reference binary's final state, and whether the strict
-1e-9-voxel bar held over the whole run -- as gpurun_out/r05_parity_<kernel path>.json (copied to profiles/ when a round is closed).
+1e-9-voxel bar held over the whole run -- as gpurun_out/r06_parity_<kernel path>.json (copied to profiles/ when a round is closed).
 Asserts the tolerance for every case and a floor on the number of cases that meet the strict bar.
 
 Stated tolerance: max(1e-9 voxel, 20 x spread) -- tests/test_gpu_parity.py's.  For most of round 3 it carried a third term, 3e-13 voxel
@@ -96,7 +96,7 @@ def test_parity_ledger(golden_dir, manifest, kernel_path):
               "rows": rows}
     for out_dir in (os.path.join(REPO, "gpurun_out"),):
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "r05_parity_%s.json" % kernel_path), "w") as f:
+        with open(os.path.join(out_dir, "r06_parity_%s.json" % kernel_path), "w") as f:
             json.dump(ledger, f, indent=1)
     print("parity ledger [%s]: %d cases, %d within the strict 1e-9 voxel bar over the whole run (%d within 1e-12), %d within tolerance" % (
         kernel_path, len(rows), strict, tight, ledger["within_tolerance"]))
