@@ -1467,3 +1467,16 @@ if __name__ == "__main__" and "onestepfile" in sys.argv[1:]:
             prev = got
         r, o = eng.result(0), free.result()
         print("engine: steps %d num_touching_floor %s; oracle: steps %d" % (r.steps, getattr(r, "num_touching_floor", "?"), free.info().steps), flush=True)
+
+
+if __name__ == "__main__" and "swimtiles" in sys.argv[1:]:
+    # round 6: BASELINE configs[3] (64 random 8^3 swimmers) on the wide kernel against the same robots cut into k tiles each (k_tile_steps FLUID)
+    swimmers = [workloads.random_material((8, 8, 8), i) for i in range(64)]
+    for rep in range(2):
+        _window(engine.VOXCAD_LAND_WATER, swimmers, _water(), {}, 300, 1000, tag="64 x 8^3 swimmers", extra=_phase_layer((8, 8, 8), 0), label="swimtiles")
+        for k in (2, 3, 4):
+            _window(engine.VOXCAD_LAND_WATER, swimmers, _water(), {"tiled": 2, "tiles_per_robot": k}, 300, 1000, tag="64 x 8^3 swimmers", extra=_phase_layer((8, 8, 8), 0), label="swimtiles")
+    walkers = [workloads.random_material((8, 8, 8), i) for i in range(64)]
+    _window(engine.VOXCAD, walkers, Env(), {}, 300, 1000, tag="64 x 8^3 walkers", label="swimtiles")
+    for k in (2, 4):
+        _window(engine.VOXCAD, walkers, Env(), {"tiled": 2, "tiles_per_robot": k}, 300, 1000, tag="64 x 8^3 walkers", label="swimtiles")
