@@ -531,12 +531,24 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     constexpr int MVC = VXH_TILE_MAX_TILES / 64;
     auto robot_barrier = [&](const unsigned long long* mvq, unsigned tag, bool go, FusedCtl& K, int it, bool spec) {
         const int lane = tid - SVC0;
-        unsigned long long mg[2 * MVC];
+        // TWO requests of the words in flight, half a round trip apart (round 6): a word that arrives just behind one request is seen by the
+        // other a quarter of a microsecond later instead of a whole round trip later.  Every lane always asks (a lane beyond the robot's tiles
+        // for the last tile's word again): without a branch around the loads the compiler can wait for the OLDER request alone.
+        unsigned long long mg[2 * MVC], mh[2 * MVC];
+        auto request = [&](unsigned long long (&m)[2 * MVC]) {
 #pragma unroll
-        for (int c = 0; c < MVC; ++c) {
-            mg[2 * c] = mg[2 * c + 1] = 0;
-            if (lane + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(lane + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
-        }
+            for (int c = 0; c < MVC; ++c) {
+                const unsigned long long* q = mvq + (size_t)min(lane + 64 * c, k_tiles - 1) * VXH_TILE_MV_STRIDE;
+                m[2 * c] = ld_gran(q); m[2 * c + 1] = ld_gran(q + 1);
+            }
+        };
+        auto all_in = [&](const unsigned long long (&m)[2 * MVC]) {
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < MVC; ++c) ok = ok && (unsigned)(m[2 * c] >> 32) == tag && (unsigned)(m[2 * c + 1] >> 32) == tag;
+            return __all(ok) != 0;
+        };
+        request(mg);
         // (while the words travel) the decision's inputs
         const double pre_disp = rs.max_disp, pre_dtp = s_dtp[it & 1], lat = R.lat, half_reach = (R.col_horizon - 1.0) / 2;
         const int pre_reb = rs.rebuilds, pre_ct = rs.col_tiled, kflags = K.flags;
@@ -551,18 +563,17 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
 #endif
         for (;;) {
 #ifdef VXH_PHASE_TIMING
-            ++polls;
+            polls += 2;
 #endif
-            bool ok = true;
+            request(mh);                       // the second request goes out while the first is on its way
+            if (all_in(mg)) break;
+            request(mg);
+            if (all_in(mh)) {
 #pragma unroll
-            for (int c = 0; c < MVC; ++c)
-                if (lane + 64 * c < k_tiles) ok = ok && (unsigned)(mg[2 * c] >> 32) == tag && (unsigned)(mg[2 * c + 1] >> 32) == tag;
-            if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(1);
+                for (int c = 0; c < 2 * MVC; ++c) mg[c] = mh[c];
+                break;
+            }
             if (++spins > VXH_TILE_SPIN_LIMIT) { s_abort = 1; aborted = true; break; }
-#pragma unroll
-            for (int c = 0; c < MVC; ++c)
-                if (lane + 64 * c < k_tiles) { const unsigned long long* q = mvq + (size_t)(lane + 64 * c) * VXH_TILE_MV_STRIDE; mg[2 * c] = ld_gran(q); mg[2 * c + 1] = ld_gran(q + 1); }
         }
 #ifdef VXH_PHASE_TIMING
         if (B.prof && hz_thread) { atomicAdd(&B.prof[120], (unsigned long long)polls); atomicAdd(&B.prof[121], 1ull); atomicAdd(&B.prof[122], __builtin_readcyclecounter() - tp0); }
@@ -570,8 +581,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         double mvmax = 0.0;                   // max |v|^2 over the tiles; a negative word marks a tile in which a bond diverged
         bool neg = false;
 #pragma unroll
-        for (int c = 0; c < MVC; ++c)
-            if (lane + 64 * c < k_tiles) { const double m = gran2_value(mg[2 * c], mg[2 * c + 1]); neg = neg || m < 0.0; mvmax = m > mvmax ? m : mvmax; }
+        for (int c = 0; c < MVC; ++c) { const double m = gran2_value(mg[2 * c], mg[2 * c + 1]); neg = neg || m < 0.0; mvmax = m > mvmax ? m : mvmax; }      // (clamped lanes repeat the last tile's word: harmless to a maximum)
         neg = __any(neg) != 0;
         mvmax = wave_max_nonneg(mvmax);
         if (hz_thread && !aborted) {
