@@ -404,7 +404,7 @@ const char* vxh_strerror(int status)
 }
 
 const char* vxh_last_error(const vxh_engine* e) { return e ? e->last_error.c_str() : ""; }
-const char* vxh_version(void) { return "vxhip 0.3.0 (gfx950)"; }
+const char* vxh_version(void) { return "vxhip 0.4.0 (gfx950)"; }
 
 int vxh_device_count(void) { return vxh::hip_device_count(); }
 
