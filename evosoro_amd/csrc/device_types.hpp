@@ -108,7 +108,11 @@ enum { VXH_TILE_BLOCK = 256,          // worker threads of a tile's workgroup = 
        VXH_TILE_ROWPOOL = 1024,       // contact-row entries (partner code + pair stiffness) a tile keeps in LDS (rows beyond: read from memory)
        VXH_TILE_XH = 192,             // most contact partners owned by other tiles that a tile mirrors in LDS (the rest: fetched from memory)
        VXH_TILE_CH = 128,             // chunk of the whole-robot passes (latch, broad-phase) staged through LDS
-       VXH_TILE_STATIC_LDS = 1024 };   // upper bound of the kernel's static __shared__ variables
+       VXH_TILE_STATIC_LDS = 1024,    // upper bound of the kernel's static __shared__ variables
+       // the SMALL size class (round 6): tiles of at most one wavefront of owned voxels, two of mirrored ones and one bond per lane -- the 4x4x4
+       // tiles of configs[4], the tiles of a swimmer above 1024 voxels -- are stepped by kernel instances whose LDS plane strides are these
+       // constants instead of the tile's own counts
+       VXH_TILE_S_OWN = 64, VXH_TILE_S_HALO = 128, VXH_TILE_S_BONDS = 256 };
 struct TileLayout { int np, no, nbp, nmvp, nfp, nmxp, o_ps, o_pl, o_hl, o_pht, o_sl, o_sc, o_px, o_rc, o_tab, o_int, o_mesh, total; };
 VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doubles, bool mesh, int n_mv = 0, int n_f = 0, int n_mx = 0)
 {
@@ -122,12 +126,14 @@ VXH_HD inline TileLayout tile_layout(int n_own, int n_halo, int nb, int tab_doub
     L.o_sc = L.o_sl + (mesh ? 6 * L.no : 0);
     L.o_px = L.o_sc + 5 * VXH_TILE_CH + VXH_TILE_CH / 2;
     L.o_rc = L.o_px + 4 * VXH_TILE_XH;
-    L.o_tab = L.o_rc + VXH_TILE_ROWPOOL;
-    L.o_int = L.o_tab + ((tab_doubles + 1) & ~1);
+    // (round 6: the integer region in front of the class tables -- whose size is the robot's -- so that every offset up to here is a
+    // function of np / no / nbp alone: compile-time constants in the SMALL size class of the kernel, immediates of its LDS instructions)
+    L.o_int = L.o_rc + VXH_TILE_ROWPOOL;
+    L.o_tab = L.o_int + (3 * L.nbp + VXH_TILE_XH + 2 * VXH_TILE_HASH + VXH_TILE_ROWPOOL + 1) / 2;
     // a tile of a robot in a fluid: [3][nmvp] vertices of its part of the drag mesh, [3][nfp] drag of its facets, [3][no] velocities of its voxels,
     // [13][nmxp] position, quaternion and the six strains of every voxel its vertices average over
     L.nmvp = (n_mv + 1) & ~1; L.nfp = (n_f + 1) & ~1; L.nmxp = (n_mx + 1) & ~1;
-    L.o_mesh = L.o_int + (3 * L.nbp + VXH_TILE_XH + 2 * VXH_TILE_HASH + VXH_TILE_ROWPOOL + 1) / 2;
+    L.o_mesh = L.o_tab + ((tab_doubles + 1) & ~1);
     // ... and the constant tables of that mesh (copied once per launch): [3][nmvp] rest positions, [8][nmvp] ints voxel per corner code, [4][nfp] ints facets
     L.total = L.o_mesh + ((n_mv > 0 || n_f > 0) ? 3 * L.nmvp + 3 * L.nfp + 3 * L.no + 13 * L.nmxp + 3 * L.nmvp + 4 * L.nmvp + 2 * L.nfp : 0);
     return L;

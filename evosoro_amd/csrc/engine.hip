@@ -79,6 +79,7 @@ struct Engine::Device {
     // tiled path: the robots cut into tiles, packed into launches that fit the chip (all tiles of a robot in one launch)
     struct TileLaunch {
         int tabg = 0, mesh = 0, count = 0;   // template arguments of k_tile_steps (mesh: land_water robots, whose strains are part of the state)
+        int small = 0;                    // ... and SMALL: every tile of the launch within VXH_TILE_S_* (compile-time LDS strides)
         const int* list = nullptr;        // tile ids
         size_t lds = 0;
         std::vector<int> tile_ids, robots;
@@ -1128,7 +1129,7 @@ void Engine::prepare()
         auto k_latency = [&](const RobotModel& M) { return by_wave ? k_wave(M) : k_bonds(M); };
         long long sum_lat = 0;
         for (int r : cand) sum_lat += k_latency(robots_[r]);
-        struct Planned { int r; TilePlan plan; int tabg; size_t lds; int mesh; };
+        struct Planned { int r; TilePlan plan; int tabg; size_t lds; int mesh; int small; };
         // a robot in a fluid: per tile the mesh vertices its owned voxels' facets use and those facets (counts, for the LDS layout; the tables
         // themselves are filled when the exchange slots of the robot's voxels are known)
         auto in_fluid = [&](const RobotModel& M) { return variant_ == 1 && M.vxa.fluid_env && M.nmv > 0; };
@@ -1158,13 +1159,17 @@ void Engine::prepare()
             for (;;) {
                 TilePlan P = plan_tiles(M, k);
                 size_t lds = 0;
+                bool small = true;                                    // every tile within the SMALL size class: its kernel instances, its (fixed) layout
+                for (const auto& t : P.tiles) small = small && (int)t.own.size() <= VXH_TILE_S_OWN && (int)t.halo.size() <= VXH_TILE_S_HALO && (int)t.bond_v1.size() <= VXH_TILE_S_BONDS;
                 for (const auto& t : P.tiles) {
                     int n_mv = 0, n_f = 0, n_mx = 0;
                     tile_mesh_counts(M, t, n_mv, n_f, n_mx);
-                    lds = std::max(lds, (size_t)tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles, M.nmv > 0, n_mv, n_f, n_mx).total * 8);
+                    const TileLayout TL = small ? tile_layout(VXH_TILE_S_OWN, VXH_TILE_S_HALO, VXH_TILE_S_BONDS, tabg ? 0 : tab_doubles, M.nmv > 0, n_mv, n_f, n_mx)
+                                                : tile_layout((int)t.own.size(), (int)t.halo.size(), (int)t.bond_v1.size(), tabg ? 0 : tab_doubles, M.nmv > 0, n_mv, n_f, n_mx);
+                    lds = std::max(lds, (size_t)TL.total * 8);
                 }
                 if (P.k > VXH_TILE_MAX_TILES) break;                  // (left to the other kernels)
-                if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds, M.nmv > 0 ? (in_fluid(M) ? 2 : 1) : 0}); break; }
+                if (P.max_own <= VXH_TILE_BLOCK && P.max_local <= 1024 && lds <= lds_cap) { planned.push_back({r, std::move(P), tabg, lds, M.nmv > 0 ? (in_fluid(M) ? 2 : 1) : 0, small ? 1 : 0}); break; }
                 if (k >= M.nvox / 8) break;                           // cannot be tiled: left to the other kernels
                 k = std::min(std::max(k + 1, k * 5 / 4 + 1), std::max(1, M.nvox / 8));
             }
@@ -1172,17 +1177,17 @@ void Engine::prepare()
         // launches: all tiles of a robot in one launch, a launch no larger than what the chip keeps resident (the tiles of a
         // robot wait for each other).  How many workgroups of THIS kernel a CU holds is asked of the runtime (registers, wavefront
         // slots and LDS of the compiled code: five wavefronts of 256 vector registers are one workgroup per CU, whatever the LDS says)
-        for (int kind = 0; kind < 6; ++kind) {
-            const int tabg = kind & 1, mesh = kind >> 1;      // mesh: 0 _voxcad, 1 land_water on land, 2 land_water in a fluid
+        for (int kind = 0; kind < 12; ++kind) {
+            const int tabg = kind & 1, mesh = (kind >> 1) % 3, small = kind / 6;      // mesh: 0 _voxcad, 1 land_water on land, 2 land_water in a fluid
             Device::TileLaunch cur;
-            cur.tabg = tabg; cur.mesh = mesh;
+            cur.tabg = tabg; cur.mesh = mesh; cur.small = small;
             auto capacity = [&](size_t lds) { return (long long)D.n_cu * tile_workgroups_per_cu(tabg, mesh, lds); };
             for (auto& q : planned) {
-                if (q.tabg != tabg || q.mesh != mesh) continue;
+                if (q.tabg != tabg || q.mesh != mesh || q.small != small) continue;
                 const int k = q.plan.k;
                 if (k > capacity(q.lds)) continue;                    // more tiles than the chip holds: not tiled
                 const size_t lds = std::max(cur.lds, q.lds);
-                if (cur.count > 0 && cur.count + k > capacity(lds)) { D.tile_launches.push_back(cur); cur = Device::TileLaunch(); cur.tabg = tabg; cur.mesh = mesh; }
+                if (cur.count > 0 && cur.count + k > capacity(lds)) { D.tile_launches.push_back(cur); cur = Device::TileLaunch(); cur.tabg = tabg; cur.mesh = mesh; cur.small = small; }
                 cur.lds = std::max(cur.lds, q.lds);
                 const int tile0 = (int)h_tiles.size(), base = D.vox_begin[q.r];
                 for (int t = 0; t < k; ++t) {
@@ -1494,7 +1499,7 @@ void Engine::advance_launch(long long max_rounds)
         for (long long done = 0; done < todo || done == 0; done += iters)
             for (const auto& L : D.tile_launches) {
                 ++tile_gen_;
-                launch_tile_group(B, L.tabg != 0, L.mesh, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
+                launch_tile_group(B, L.tabg != 0, L.mesh, L.small != 0, L.list, L.count, L.lds, D.tile_stream, cap, iters, tile_gen_);
                 ++launches; ++tile_launch_count;
             }
         HIP_OK(hipEventRecord(D.tile_t1, D.tile_stream));

@@ -322,7 +322,7 @@ __device__ __forceinline__ int tile_rebuild(const DBatch& B, const DRobot& R, DR
 #endif
 
 
-template <bool TABG, bool MESH, bool FLUID = false>      // FLUID (implies MESH): the robots of the launch are in a fluid (drag mesh per tile, strains exchanged)
+template <bool TABG, bool MESH, bool FLUID = false, bool SMALL = false>      // FLUID (implies MESH): the robots of the launch are in a fluid (drag mesh per tile, strains exchanged)
 __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const DRobot* __restrict__ robots, const DTile* __restrict__ tiles,
                                                                  const int* __restrict__ tile_list, long long step_cap, int iters, unsigned gen)
 {
@@ -356,7 +356,11 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     static_assert(MESH || !FLUID, "a robot in a fluid is a land_water robot");
     const bool fluid = FLUID && T.n_f > 0;
     const int n_mv = FLUID ? T.n_mv : 0, n_f = FLUID ? T.n_f : 0, n_mx = FLUID ? T.n_mx : 0;
-    const TileLayout L = tile_layout(n_own, n_halo, nb, nbd + nvd, MESH, n_mv, n_f, n_mx);
+    // SMALL (every tile of the launch within VXH_TILE_S_*): the layout of the LARGEST such tile for all of them -- np, no, nbp and every
+    // offset in front of the class tables are compile-time constants, i.e. immediates of the LDS instructions instead of scalar registers
+    // (the kernel spilled ~250 of those into VGPR lanes and read them back ~250 times per step and wavefront)
+    const TileLayout L = SMALL ? tile_layout(VXH_TILE_S_OWN, VXH_TILE_S_HALO, VXH_TILE_S_BONDS, nbd + nvd, MESH, n_mv, n_f, n_mx)
+                               : tile_layout(n_own, n_halo, nb, nbd + nvd, MESH, n_mv, n_f, n_mx);
     const int np = L.np, no = L.no, nbp = L.nbp;
     double* const ps = lds + L.o_ps;          // [8][np] pose tile: owned voxels, then halo voxels
     double* const pl = lds + L.o_pl;          // [6 directions][6][no] bond force / minus bond moment on every owned voxel

@@ -37,7 +37,8 @@ void launch_fused_mesh(const DBatch& B, int block, bool tabg, const int* list, i
 // k_robot_wide<512, MESH, TABG> (kernels_wide.hpp)
 void launch_wide_group(const DBatch& B, bool mesh, bool tabg, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, int two_tiles);
 // k_tile_steps<TABG, MESH, FLUID> (kernels_tiled.hpp); mesh_kind: 0 = _voxcad, 1 = land_water robot on land, 2 = in a fluid
-void launch_tile_group(const DBatch& B, bool tabg, int mesh_kind, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen);
+// small: every tile of the launch within VXH_TILE_S_OWN / _HALO / _BONDS (device_types.hpp): the instances with compile-time LDS strides
+void launch_tile_group(const DBatch& B, bool tabg, int mesh_kind, bool small, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen);
 // workgroups of that k_tile_steps instance one CU keeps resident at `lds` bytes of dynamic LDS
 long long tile_workgroups_per_cu(int tabg, int mesh_kind, size_t lds);
 // threads of a tile's workgroup (the host sizes launches and LDS with the kernel's own constants)

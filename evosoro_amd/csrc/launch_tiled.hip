@@ -10,7 +10,7 @@
 namespace vxh {
 
 // (one table of granted dynamic-LDS sizes per kernel instance, shared by the launch and by the occupancy query: the limit only ever grows)
-template <bool TABG, bool MESH, bool FLUID>
+template <bool TABG, bool MESH, bool FLUID, bool SMALL>
 static size_t (&granted_lds())[64] { static size_t table[64] = {}; return table; }
 
 // k_tile_steps must keep NOTHING in scratch (round 6).  Its tiles exchange poses through relaxed agent-scope stores and polled loads, and
@@ -22,7 +22,7 @@ static size_t (&granted_lds())[64] { static size_t table[64] = {}; return table;
 // "Round 6").  Four wavefronts per workgroup leave every wavefront 512 registers, the compiler spills into the upper 256 (AGPRs), and
 // this check keeps it that way: a build that needs scratch again is refused with VXH_ERR_HIP before it is launched.
 // (VXH_TILE_SCRATCH_LIMIT: bytes per lane tolerated, default 0; the GPU test sets -1 to see the refusal.)
-template <bool TABG, bool MESH, bool FLUID>
+template <bool TABG, bool MESH, bool FLUID, bool SMALL>
 static void refuse_scratch()
 {
     static std::mutex lock;
@@ -36,7 +36,7 @@ static void refuse_scratch()
         std::lock_guard<std::mutex> hold(lock);
         if (!known[dev]) {
             hipFuncAttributes attr;
-            hip_check(hipFuncGetAttributes(&attr, (const void*)k_tile_steps<TABG, MESH, FLUID>), "hipFuncGetAttributes(k_tile_steps)");
+            hip_check(hipFuncGetAttributes(&attr, (const void*)k_tile_steps<TABG, MESH, FLUID, SMALL>), "hipFuncGetAttributes(k_tile_steps)");
             bytes[dev] = (long)attr.localSizeBytes; known[dev] = true;
         }
         have = bytes[dev];
@@ -44,24 +44,31 @@ static void refuse_scratch()
     const char* env = std::getenv("VXH_TILE_SCRATCH_LIMIT");
     const long limit = env ? std::atol(env) : 0;
     if (have > limit)
-        throw std::runtime_error("HIP: k_tile_steps<" + std::to_string((int)TABG) + ", " + std::to_string((int)MESH) + ", " + std::to_string((int)FLUID) + "> was compiled with " +
+        throw std::runtime_error("HIP: k_tile_steps<" + std::to_string((int)TABG) + ", " + std::to_string((int)MESH) + ", " + std::to_string((int)FLUID) + ", " + std::to_string((int)SMALL) + "> was compiled with " +
                                  std::to_string(have) + " bytes of scratch per lane (limit " + std::to_string(limit) + "): refused, see evosoro_amd/csrc/launch_tiled.hip");
 }
 
-template <bool TABG, bool MESH, bool FLUID>
+template <bool TABG, bool MESH, bool FLUID, bool SMALL>
 static void launch_tiles(const DBatch& B, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
 {
-    refuse_scratch<TABG, MESH, FLUID>();
-    grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH, FLUID>, granted_lds<TABG, MESH, FLUID>(), lds);
-    hipLaunchKernelGGL((k_tile_steps<TABG, MESH, FLUID>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
+    refuse_scratch<TABG, MESH, FLUID, SMALL>();
+    grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH, FLUID, SMALL>, granted_lds<TABG, MESH, FLUID, SMALL>(), lds);
+    hipLaunchKernelGGL((k_tile_steps<TABG, MESH, FLUID, SMALL>), dim3(count), dim3(VXH_TILE_THREADS), lds, s, B, B.robot, B.tiles, list, cap, iters, gen);
 }
 
-void launch_tile_group(const DBatch& B, bool tabg, int mesh_kind, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
+template <bool SMALL>
+static void launch_tile_group_of(const DBatch& B, bool tabg, int mesh_kind, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
 {
-    if (mesh_kind == 2) { if (tabg) launch_tiles<true, true, true>(B, list, count, lds, s, cap, iters, gen); else launch_tiles<false, true, true>(B, list, count, lds, s, cap, iters, gen); }
-    else if (mesh_kind) { if (tabg) launch_tiles<true, true, false>(B, list, count, lds, s, cap, iters, gen); else launch_tiles<false, true, false>(B, list, count, lds, s, cap, iters, gen); }
-    else if (tabg) launch_tiles<true, false, false>(B, list, count, lds, s, cap, iters, gen);
-    else launch_tiles<false, false, false>(B, list, count, lds, s, cap, iters, gen);
+    if (mesh_kind == 2) { if (tabg) launch_tiles<true, true, true, SMALL>(B, list, count, lds, s, cap, iters, gen); else launch_tiles<false, true, true, SMALL>(B, list, count, lds, s, cap, iters, gen); }
+    else if (mesh_kind) { if (tabg) launch_tiles<true, true, false, SMALL>(B, list, count, lds, s, cap, iters, gen); else launch_tiles<false, true, false, SMALL>(B, list, count, lds, s, cap, iters, gen); }
+    else if (tabg) launch_tiles<true, false, false, SMALL>(B, list, count, lds, s, cap, iters, gen);
+    else launch_tiles<false, false, false, SMALL>(B, list, count, lds, s, cap, iters, gen);
+}
+
+void launch_tile_group(const DBatch& B, bool tabg, int mesh_kind, bool small, const int* list, int count, size_t lds, hipStream_t s, long long cap, int iters, unsigned gen)
+{
+    if (small) launch_tile_group_of<true>(B, tabg, mesh_kind, list, count, lds, s, cap, iters, gen);
+    else launch_tile_group_of<false>(B, tabg, mesh_kind, list, count, lds, s, cap, iters, gen);
 }
 
 int tile_threads() { return VXH_TILE_THREADS; }
@@ -71,12 +78,12 @@ int tile_threads() { return VXH_TILE_THREADS; }
 // (queried with the kernel's dynamic-LDS limit already raised to `lds`, or it answers for the 64 KB default) is clamped to ONE -- four
 // wavefronts of up to 512 registers each fill the register files of a CU whatever the LDS says (round 6; rounds 2-5: five wavefronts of
 // 256, "two per CU by the registers" was already one in practice) -- and a failing query is reported once instead of silently read as 1.
-template <bool TABG, bool MESH, bool FLUID>
+template <bool TABG, bool MESH, bool FLUID, bool SMALL>
 static int occupancy_of(size_t lds)
 {
-    grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH, FLUID>, granted_lds<TABG, MESH, FLUID>(), lds);
+    grant_dynamic_lds((const void*)k_tile_steps<TABG, MESH, FLUID, SMALL>, granted_lds<TABG, MESH, FLUID, SMALL>(), lds);
     int n = 0;
-    const hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_tile_steps<TABG, MESH, FLUID>, VXH_TILE_THREADS, lds);
+    const hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_tile_steps<TABG, MESH, FLUID, SMALL>, VXH_TILE_THREADS, lds);
     if (err != hipSuccess) {
         (void)hipGetLastError();
         static bool told = false;
@@ -88,9 +95,10 @@ static int occupancy_of(size_t lds)
 
 long long tile_workgroups_per_cu(int tabg, int mesh, size_t lds)
 {
-    const int n = mesh == 2 ? (tabg ? occupancy_of<true, true, true>(lds) : occupancy_of<false, true, true>(lds))
-                : mesh == 1 ? (tabg ? occupancy_of<true, true, false>(lds) : occupancy_of<false, true, false>(lds))
-                            : (tabg ? occupancy_of<true, false, false>(lds) : occupancy_of<false, false, false>(lds));
+    // (the generic instances answer for their SMALL twins: same threads, same register budget)
+    const int n = mesh == 2 ? (tabg ? occupancy_of<true, true, true, false>(lds) : occupancy_of<false, true, true, false>(lds))
+                : mesh == 1 ? (tabg ? occupancy_of<true, true, false, false>(lds) : occupancy_of<false, true, false, false>(lds))
+                            : (tabg ? occupancy_of<true, false, false, false>(lds) : occupancy_of<false, false, false, false>(lds));
     return std::min(1, std::max(1, n));
 }
 
