@@ -246,7 +246,8 @@ struct DBatch {
     const int* tile_ffirst;           // [as tile_vox] per owned voxel: first facet (tile-local) ...
     const unsigned char* tile_fcount; // ... and their number
     int n_tmv, n_tf;
-    unsigned long long* xch;          // [3][xplanes][nx] poses (+ strains), a ring of three buffers, slot = step count mod 3: planes 2c / 2c+1 = low / high granule of component c
+    unsigned long long* xch;          // [3][nx / 64][xplanes][64] poses (+ strains), a ring of three buffers, slot = step count mod 3, the planes blocked by 64
+                                      // exchange slots (kernels_tiled.hpp xch_at): planes 2c / 2c+1 = low / high granule of component c
                                       // (pos xyz, scale, quaternion wxyz) of every voxel of a tiled robot, published by its owner
     unsigned long long* tile_mv;      // [3][total tiles][VXH_TILE_MV_STRIDE] first two words: low / high granule of the max |v|^2 of the tile's voxels in the step
                                       // that produced the published poses (negative: a bond of the tile diverged in that step)

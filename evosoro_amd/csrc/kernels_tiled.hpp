@@ -73,12 +73,21 @@ __device__ __forceinline__ double gran2_value(unsigned long long lo, unsigned lo
 { return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32))); }
 
 
+// Where the granules of exchange slot `xs` start in a buffer of the ring (round 6): the planes are BLOCKED by 64 slots -- [slot / 64][plane]
+// [slot % 64] -- so plane k of a slot is k * 64 granules behind its plane 0: an immediate displacement of the load / store instead of one
+// of sixteen 64-bit plane strides k * nx out of spilled scalar pairs.  A tile's owned voxels are one 64-aligned range of slots, so its
+// publication still fills whole lines plane by plane, and a wavefront polling consecutive slots still reads them coalesced.
+__device__ __forceinline__ const unsigned long long* xch_at(const unsigned long long* xq, unsigned planes, int xs)
+{ return xq + (size_t)((unsigned)xs >> 6) * (planes * 64u) + ((unsigned)xs & 63u); }
+__device__ __forceinline__ unsigned long long* xch_at(unsigned long long* xq, unsigned planes, int xs)
+{ return xq + (size_t)((unsigned)xs >> 6) * (planes * 64u) + ((unsigned)xs & 63u); }
+
 // position + scale of any voxel of the robot as its owner published it for the current step (broad-phase, latch, contact
 // partners the tile does not mirror).  Called behind the step's per-robot barrier, when every tile has stored these granules;
 // stored is not yet visible (nothing orders one wavefront's max-|v|^2 word behind another's pose granules), so this read, like
 // every read of the exchange buffer, goes by the tags and repeats until they are this step's (bounded: `abort_flag`).
 struct PoseFromXch {
-    const unsigned long long* xq; unsigned nx;          // xq = exchange buffer of the step: [16][nx]
+    const unsigned long long* xq; unsigned planes;      // xq = exchange buffer of the step (xch_at), granule planes per slot
     const int* xslot;                                   // exchange slot of every voxel (DBatch::xslot)
     unsigned tag; int* abort_flag;
     __device__ __forceinline__ void at(int xs, double& x, double& y, double& z, double& s) const
@@ -87,7 +96,7 @@ struct PoseFromXch {
         for (int spins = 0;; ++spins) {
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) g[k] = ld_gran(xq + (size_t)k * nx + xs);
+            for (int k = 0; k < 8; ++k) g[k] = ld_gran(xch_at(xq, planes, xs) + k * 64);
 #pragma unroll
             for (int k = 0; k < 8; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
             if (ok) break;
@@ -388,6 +397,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
     int* const fct = mvt + 8 * L.nmvp;        // fluid: [4][nfp] per facet: owner voxel, its three vertices
     const int nmvp = L.nmvp, nfp = L.nfp, nmxp = L.nmxp;
     const unsigned nx = B.nx;                 // exchange slots (every tile's owned voxels contiguous: its pose stores fill whole lines)
+    const unsigned xpl = (unsigned)B.xplanes;
     const size_t xbuf = (size_t)B.xplanes * nx;   // granules per exchange buffer (a ring of three): 16 planes of poses (+ 12 of strains when a tiled robot is in a fluid)
     constexpr bool xstrain = FLUID;           // my voxels' strains travel with their poses
     const int xs_own = T.xoff + tid;          // exchange slot of my owned voxel
@@ -440,13 +450,13 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         lm = mk3(LINMOM(0, gv), LINMOM(1, gv), LINMOM(2, gv));
         am = mk3(ANGMOM(0, gv), ANGMOM(1, gv), ANGMOM(2, gv));
         const double q8[8] = {POS(b0, 0, gv), POS(b0, 1, gv), POS(b0, 2, gv), SCALE(b0, gv), QUAT(0, gv), QUAT(1, gv), QUAT(2, gv), QUAT(3, gv)};
-        unsigned long long* const xq0 = B.xch + (size_t)ring * xbuf + xs_own;
+        unsigned long long* const xq0 = xch_at(B.xch + (size_t)ring * xbuf, xpl, xs_own);
         const unsigned tag1 = tile_tag(gen, 0, 1);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { ps[k * np + tid] = q8[k]; st_gran2(xq0 + (size_t)(2 * k) * nx, nx, q8[k], tag1); }
+        for (int k = 0; k < 8; ++k) { ps[k * np + tid] = q8[k]; st_gran2(xq0 + (2 * k) * 64, 64, q8[k], tag1); }
         if constexpr (xstrain) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) st_gran2(xq0 + (size_t)(16 + 2 * k) * nx, nx, sl[k * no + tid], tag1);
+            for (int k = 0; k < 6; ++k) st_gran2(xq0 + (16 + 2 * k) * 64, 64, sl[k * no + tid], tag1);
         }
     }
     if constexpr (FLUID) {
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 for (;;) {
                     bool ok = true;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) g[k] = ld_gran(xq + (size_t)k * nx + hv);
+                    for (int k = 0; k < 16; ++k) g[k] = ld_gran(xch_at(xq, xpl, hv) + k * 64);
 #pragma unroll
                     for (int k = 0; k < 16; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
                     if (__all(ok)) break;
@@ -657,7 +667,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 for (;;) {
                     bool ok = true;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) g[k] = ld_gran(xq + (size_t)k * nx + hv);
+                    for (int k = 0; k < 8; ++k) g[k] = ld_gran(xch_at(xq, xpl, hv) + k * 64);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
                     if (__all(ok)) break;
@@ -680,9 +690,9 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                     for (;;) {
                         bool ok = true;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) g[k] = ld_gran(xq + (size_t)k * nx + xs);                           // position
+                        for (int k = 0; k < 6; ++k) g[k] = ld_gran(xch_at(xq, xpl, xs) + k * 64);                       // position
 #pragma unroll
-                        for (int k = 0; k < 20; ++k) g[6 + k] = ld_gran(xq + (size_t)(8 + k) * nx + xs);                // quaternion, strains
+                        for (int k = 0; k < 20; ++k) g[6 + k] = ld_gran(xch_at(xq, xpl, xs) + (8 + k) * 64);            // quaternion, strains
 #pragma unroll
                         for (int k = 0; k < 26; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
                         if (ok) break;
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         __syncthreads();                       // (B)
         VXH_TT_MARK(3)
         VXH_TS(2, tid == 0)
-        const PoseFromXch pose{xq, nx, B.xslot, tag, &s_abort};
+        const PoseFromXch pose{xq, xpl, B.xslot, tag, &s_abort};
         if (!speculate) {
             if (s_abort) break;
             if (s_divprev) break;              // (undone below)
@@ -868,10 +878,10 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 // every voxel of the tile has read its contact partners, and until the step is known to stand)
                 p8[0] = pos.x; p8[1] = pos.y; p8[2] = pos.z;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_own, nx, p8[k], tagn);
+                for (int k = 0; k < 3; ++k) st_gran2(xch_at(xqn, xpl, xs_own) + (2 * k) * 64, 64, p8[k], tagn);
                 if constexpr (xstrain) {       // ... and the strains this step's bonds left: the next step's mesh is built from them
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) st_gran2(xqn + (size_t)(16 + 2 * k) * nx + xs_own, nx, sl[k * no + tid], tagn);
+                    for (int k = 0; k < 6; ++k) st_gran2(xch_at(xqn, xpl, xs_own) + (16 + 2 * k) * 64, 64, sl[k * no + tid], tagn);
                 }
                 VXH_TV(3)
             }
@@ -886,7 +896,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
                 am_new = amv;
                 p8[3] = scale; p8[4] = ang.w; p8[5] = ang.x; p8[6] = ang.y; p8[7] = ang.z;
 #pragma unroll
-                for (int k = 3; k < 8; ++k) st_gran2(xqn + (size_t)(2 * k) * nx + xs_ang, nx, p8[k], tagn);
+                for (int k = 3; k < 8; ++k) st_gran2(xch_at(xqn, xpl, xs_ang) + (2 * k) * 64, 64, p8[k], tagn);
             }
             if (tid < 64 * nvw) {
                 // the tile's max |v|^2 goes out with the last wavefront to finish its voxels, not behind the workgroup barrier (only the
@@ -977,7 +987,7 @@ __global__ __launch_bounds__(VXH_TILE_THREADS) void k_tile_steps(DBatch B, const
         if (valid) {
             unsigned long long g[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) g[k] = ld_gran(xqp + (size_t)k * nx + xs_own);
+            for (int k = 0; k < 16; ++k) g[k] = ld_gran(xch_at(xqp, xpl, xs_own) + k * 64);
 #pragma unroll
             for (int k = 0; k < 8; ++k) ps[k * np + tid] = gran2_value(g[2 * k], g[2 * k + 1]);
         }
