@@ -15,16 +15,20 @@ of the timed window).  After the timed region the fitness records of all ranks a
 (the path's only collective).
 
 With N > 1 the same line carries `strong`: BASELINE configs[2] as stated -- ONE population of 512, partitioned over the
-N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak run.
+N ranks by cost (64 per GPU at N = 8) -- timed the same way right after the weak run.  At N = 1 the same statement is measured as
+far as one GPU can (round 6): `other_configs` carries shard 0 of the 8 cost-balanced shards -- the 64 robots ONE of eight GPUs would
+step -- with the default kernels and with tile_small, and the projected 8-GPU strong rate; `--shard-of K` times that shard as the
+line's own workload.
 
 READ THIS BEFORE COMPARING TWO LINES: `value` depends on --steps.  The timed region is cut into launches of at most 1024 steps (engine option steps_per_launch), a
 launch of a self-colliding population carries ~0.07 ms of fixed cost (it ends with its slowest workgroup, and in every launch some
 robots run a ~0.04 ms collision broad-phase; 0.27 and 0.17 ms until round 3), and a call ~0.04 ms on the host.  `--steps 20 --warmup 5`
-(what the round-end driver runs) therefore reports ~1.24e10 voxel-steps/s (~28.7 us per step; round 3: 1.03e10, round 2: 7.4e9), the
-default `--steps 2000` ~1.47e10 (~24.2 us; round 3: 1.17e10) -- same kernel, same population; `timed_region` in the line says which case it is.
+(what the round-end driver runs) therefore reports ~1.4e10 voxel-steps/s by the HIP events (~25.5 us per step; ~1.3e10 by the host
+clock, which was the line's `value` until round 4: 1.24e10 then, 1.03e10 in round 3, 7.4e9 in round 2), the default `--steps 2000`
+~1.5e10 (~23.7-24.4 us) -- same kernel, same population; `timed_region` in the line says which case it is.
 
 TIMING (round 5).  `value` / `ms_per_step` are taken from HIP events on the engine's own stream around the K timed steps
-(vxh_counters.kernel_seconds of that one call), max over ranks; the host clock between the two barrier + torch.cuda.synchronize()
+(vxh_counters.kernel_seconds of that one call), max over ranks -- the line says so itself: "clock": "hip_event" --; the host clock between the two barrier + torch.cuda.synchronize()
 pairs the contract names is measured too and printed as `host_clock` (it adds ~0.04 ms of launch and wake-up latency per call, 8 %
 of a 20-step region, none of it GPU work).
 
@@ -37,12 +41,14 @@ The JSON line also carries
                 XCD fits its L2 (hit rate 0.97, profiles/r02_l2_counters.txt), so most algorithmic bytes never leave the chip.
                 `achieved / peak` is therefore not a statement that the kernel is HBM-bound -- it is bound by FP64 issue
                 (DESIGN.md section 4).
-  roofline.binding  the bound that binds, LIVE: FP64 flops per voxel-step of this (population, kernel) -- a property of the two, counted once
+  roofline.binding  the bound that binds: FP64 flops per voxel-step of this (population, kernel) -- a property of the two, counted once (a STORED
+                count: `live` is false for it; the rate it is multiplied by is this run's) --
                 with the SQ_INSTS_VALU_*_F64 counters (profiles/r*_flops_per_unit.json, scripts/flops_per_unit.sh) -- times this run's own
                 voxel-steps/s over its HIP-event time, against the 78.6 TFLOP/s vector-FP64 peak; every other_configs entry carries its own.
   ranks         N > 1: world size, backend, and per rank the device (index, PCI bus id) and its ms per step, gathered over the RCCL group
-  other_configs the other BASELINE configs at their stated sizes (64 x 6^3 walkers, 64 x 8^3 swimmers, one 20^3 lattice),
-                N = 1 only: value, us per step, algorithmic roofline fraction, kernel
+  other_configs the other BASELINE configs at their stated sizes (64 x 6^3 walkers, 64 x 8^3 swimmers, one 20^3 lattice), 512 dense 10^3,
+                a mixed generation run to completion, and configs[2] as stated (one of 8 shards); N = 1 only: value, us per step,
+                algorithmic roofline fraction, binding, kernel
   cpu_baseline  the reference C++ voxelyze (oracle/_ref/voxelyze_ref, built from the reference sources) on this box's host
                 cores: `nproc` concurrent processes on 2 x nproc robots of the bench population (evaluation.py:89 launches
                 one process per robot and lets the OS schedule them), plus the single-process figure, plus the single-process figure of the
