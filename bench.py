@@ -751,26 +751,32 @@ def main():
             # waiting in an RCCL barrier would keep a spinning kernel on the device being measured); same timing protocol.
             barrier()                          # every rank has closed its engines
             if rank == 0:
-                hp = []
-                for k in range(world):
-                    hp += make_population(os.path.join(tmp, "handle%d" % k), n_local, k * n_local, shape, sim_time, INIT_CM_TIME)
-                devices = [0] * world if share_gpu else list(range(world))
-                heng = engine.Engine(engine.VOXCAD, devices)
-                heng.add_vxa_files(hp)
-                hd = [heng.dims(i) for i in range(len(hp))]
-                h_nvox = sum(d["nvox"] for d in hd)
-                heng.step((int(max(INIT_CM_TIME / d["dt"] for d in hd)) + 32) + max(args.warmup, 1))
-                h0 = heng.counters()
-                hw0 = time.time()
-                h_dev, h_elapsed = timed_steps(heng, args.steps)
-                trace_mark("multi_handle_region", hw0, time.time(), rank)
-                h1 = heng.counters()
-                assert abs((h1.voxel_steps - h0.voxel_steps) - float(h_nvox) * args.steps) < 0.5
-                # (host clock: this route's host side -- one thread per device launching and waiting -- is part of it)
-                handle = {"scaling": "weak", "route": "one process, vxh_create_multi over devices %s" % devices, "value": h_nvox * args.steps / h_elapsed,
-                          "unit": "voxel-timesteps/s", "ms_per_step": h_elapsed / args.steps * 1e3, "ms_per_step_device": h_dev / args.steps * 1e3,
-                          "timing": "host clock between the synchronisations", "robots": len(hp)}
-                heng.close()
+                heng = None
+                try:                       # (an extra leg: whatever goes wrong in it, the line above all is still printed)
+                    hp = []
+                    for k in range(world):
+                        hp += make_population(os.path.join(tmp, "handle%d" % k), n_local, k * n_local, shape, sim_time, INIT_CM_TIME)
+                    devices = [0] * world if share_gpu else list(range(world))
+                    heng = engine.Engine(engine.VOXCAD, devices)
+                    heng.add_vxa_files(hp)
+                    hd = [heng.dims(i) for i in range(len(hp))]
+                    h_nvox = sum(d["nvox"] for d in hd)
+                    heng.step((int(max(INIT_CM_TIME / d["dt"] for d in hd)) + 32) + max(args.warmup, 1))
+                    h0 = heng.counters()
+                    hw0 = time.time()
+                    h_dev, h_elapsed = timed_steps(heng, args.steps)
+                    trace_mark("multi_handle_region", hw0, time.time(), rank)
+                    h1 = heng.counters()
+                    assert abs((h1.voxel_steps - h0.voxel_steps) - float(h_nvox) * args.steps) < 0.5
+                    # (host clock: this route's host side -- one thread per device launching and waiting -- is part of it)
+                    handle = {"scaling": "weak", "route": "one process, vxh_create_multi over devices %s" % devices, "value": h_nvox * args.steps / h_elapsed,
+                              "unit": "voxel-timesteps/s", "ms_per_step": h_elapsed / args.steps * 1e3, "ms_per_step_device": h_dev / args.steps * 1e3,
+                              "timing": "host clock between the synchronisations", "robots": len(hp)}
+                except Exception as exc:
+                    handle = {"route": "one process, vxh_create_multi", "error": "%s: %s" % (type(exc).__name__, exc)}
+                finally:
+                    if heng is not None:
+                        heng.close()
             barrier()
 
         if rank == 0:
