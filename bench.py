@@ -814,12 +814,12 @@ def main():
                     "launches": int(c1.dominant_launches),          # (of the timed call: this counter is per call, not cumulative)
                     "mean_steps_per_launch": args.steps / max(1, int(c1.dominant_launches)),
                     "note": "a launch of the resident kernel ends with its slowest workgroup and carries a fixed cost: ~0.02 ms for a "
-                            "population without self-collision, ~0.065 ms for this one (prologue/epilogue of two robots per CU ~0.03 ms; the "
+                            "population without self-collision, ~0.058 ms for this one (prologue/epilogue of two robots per CU ~0.03 ms; the "
                             "rest is waiting for the CUs whose robots ran a collision broad-phase, ~0.04 ms per run, ~50 of 512 robots in "
-                            "any 20-step launch; 0.27 / 0.17 ms until round 3); a call costs ~0.04 ms on the host.  Per step WITHOUT those: "
-                            "~23.5 us.  --steps 20 times ONE 20-step launch (~28.7 us per step, ~1.24e10 voxel-steps/s); the default "
-                            "--steps 2000 times two launches of up to 1024 steps (~24.2 us, ~1.47e10).  "
-                            "DESIGN.md section 4 'The cost of a launch' and 'Measured (MI355X, round 4)'"},
+                            "any 20-step launch; 0.27 / 0.17 ms until round 3, 0.069 until round 5's dispatch order); a call costs ~0.04 ms "
+                            "on the host.  Per step WITHOUT those: ~23.5 us.  --steps 20 times ONE 20-step launch (25.0-26.0 us per step by "
+                            "events, 1.37-1.43e10 voxel-steps/s; host clock 27.1-27.9 us); the default --steps 2000 times two launches of up "
+                            "to 1024 steps (23.7-24.4 us, 1.46-1.51e10).  DESIGN.md section 5 'The cost of a launch'; HISTORY.md"},
                 "kernel_seconds": c1.kernel_seconds - c0.kernel_seconds,
                 "fitness_gather_ms": gather_ms,
                 "control_plane": control_plane,
