@@ -1406,8 +1406,9 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
                     hull_checked += 1
                     hull_worst = max(hull_worst, abs(got_h - want_h) / want_h)
             ta, tb = dict(tag.findall(ref_text)), dict(tag.findall(text))
-            if any(ta[k3] != tb.get(k3) for k3 in ta if not k3.startswith("ConvexHull")) and saved < 4:     # keep a few differing pairs for inspection (hull volumes aside: -1 from a reference without qhull)
-                saved += 1
+            forced = str(i) in os.environ.get("VXH_CAMPAIGN_SAVE", "").split(",")                   # (robots to keep whatever the comparison says)
+            if forced or (any(ta[k3] != tb.get(k3) for k3 in ta if not k3.startswith("ConvexHull")) and saved < 4):     # keep a few differing pairs for inspection (hull volumes aside: -1 from a reference without qhull)
+                saved += 0 if forced else 1
                 out = os.path.join(REPO, "gpurun_out", "refcampaign")
                 os.makedirs(out, exist_ok=True)
                 open(os.path.join(out, "v%d_s%d_r%d_reference.xml" % (variant, seed, i)), "w").write(ref_text)
@@ -1436,6 +1437,19 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
         print("   ConvexHullVolumeStart against scipy's qhull over the filled cells' corners: %d robots, worst relative difference %.3e" % (hull_checked, hull_worst), flush=True)
     print("   ... of those, differences that are neither NaN against NaN nor noise around zero (< 1e-9 on both sides) nor a hull volume: %s in files %s" % (
         significant, sorted(sig_files)), flush=True)
+
+
+if __name__ == "__main__" and "xmlof" in sys.argv[1:]:
+    # the result file of every .vxa given, as this library writes it: xmlof <variant> <path>...   (A/B of two libraries on one robot: scripts/ab_lib.py)
+    variant = int(sys.argv[2])
+    for path in sys.argv[3:]:
+        with engine.Engine(variant, 0) as eng:
+            eng.add_vxa_file(path)
+            eng.run()
+            out = os.path.join(tempfile.mkdtemp(), "r.xml")
+            eng.write_result_xml(0, out)
+            print("== %s: %d steps (%s)" % (os.path.basename(path), eng.result(0).steps, os.path.basename(engine.LIB_PATH)), flush=True)
+            print(open(out).read(), flush=True)
 
 
 if __name__ == "__main__" and "onestepfile" in sys.argv[1:]:
