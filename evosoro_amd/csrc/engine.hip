@@ -110,10 +110,32 @@ struct Engine::Device {
     // measured: "allocations + uploads" of the second chunk 6 ms alone, 38 ms next to a running kernel with the synchronous calls.
     // The host vectors are pageable: hipMemcpyAsync returns once it has staged them; prepare() ends with a wait for this stream.
     bool async_alloc = std::getenv("VXH_SYNC_ALLOC") == nullptr;
+    bool dbg_alloc = std::getenv("VXH_DBG_ALLOC") != nullptr;
+    std::vector<size_t> alloc_bytes;
+    std::vector<std::pair<void*, std::vector<char>>> dbg_uploads;      // (VXH_DBG_ALLOC: what every upload sent, for verify_uploads)
+    void verify_uploads(const char* when)
+    {
+        if (!dbg_alloc) return;
+        int n_bad = 0;
+        for (size_t k = 0; k < dbg_uploads.size(); ++k) {
+            std::vector<char> back(dbg_uploads[k].second.size());
+            if (hipMemcpy(back.data(), dbg_uploads[k].first, back.size(), hipMemcpyDeviceToHost) != hipSuccess) { std::fprintf(stderr, "vxhip: VERIFY %s: read-back of upload #%zu failed\n", when, k); continue; }
+            size_t first = back.size(), count = 0, zeros = 0;
+            for (size_t i = 0; i < back.size(); ++i) if (back[i] != dbg_uploads[k].second[i]) { if (first == back.size()) first = i; ++count; zeros += back[i] == 0; }
+            if (count) { ++n_bad; std::fprintf(stderr, "vxhip: VERIFY %s: upload #%zu at %p (%zu bytes) differs in %zu bytes from offset %zu on (%zu of them read 0)\n", when, k, dbg_uploads[k].first, back.size(), count, first, zeros); }
+        }
+        std::fprintf(stderr, "vxhip: VERIFY %s: %d of %zu uploads differ\n", when, n_bad, dbg_uploads.size());
+    }
     void* raw_alloc(size_t bytes)
     {
         void* p = nullptr;
         if (async_alloc) HIP_OK(hipMallocAsync(&p, bytes, stream)); else HIP_OK(hipMalloc(&p, bytes));
+        if (dbg_alloc) {
+            for (size_t k = 0; k < allocs.size(); ++k)
+                if ((char*)p < (char*)allocs[k] + alloc_bytes[k] && (char*)allocs[k] < (char*)p + bytes)
+                    std::fprintf(stderr, "vxhip: ALLOCATION OVERLAP: new %p + %zu against live #%zu %p + %zu\n", p, bytes, k, allocs[k], alloc_bytes[k]);
+            alloc_bytes.push_back(bytes);
+        }
         allocs.push_back(p);
         return p;
     }
@@ -125,6 +147,7 @@ struct Engine::Device {
         if (!h.empty()) {
             if (async_alloc) HIP_OK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream));
             else HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+            if (dbg_alloc) dbg_uploads.emplace_back(p, std::vector<char>((const char*)h.data(), (const char*)h.data() + h.size() * sizeof(T)));
         }
         return (T*)p;
     }
@@ -150,6 +173,8 @@ struct Engine::Device {
         if (async_alloc && stream) { for (void* p : allocs) hipFreeAsync(p, stream); if (!allocs.empty()) hipStreamSynchronize(stream); }
         else for (void* p : allocs) hipFree(p);
         allocs.clear();
+        alloc_bytes.clear();
+        dbg_uploads.clear();
         results = nullptr;
         B = DBatch{};
     }
@@ -163,6 +188,21 @@ Engine::Engine(int variant, int device_id) : variant_(variant), device_id_(devic
         throw std::runtime_error("no HIP device available (libvxhip has no CPU path)");
     if (device_id < 0 || device_id >= count) throw std::runtime_error("device id out of range");
     HIP_OK(hipSetDevice(device_id));
+    // The stream-ordered pool keeps what the engines free (release threshold: everything) instead of handing it back to the driver at every
+    // synchronisation.  Round 6, found by looping the GPU tests: a call that failed halfway (a refused tile kernel), then reset() -- free,
+    // release, acquire again, upload -- left the FIRST TWO uploads of the new batch (DRobot and DRobotState, the first 0x290 bytes of the
+    // re-acquired chunk) zeroed in 3 % of fresh processes: correct right behind their copies, zero at the end of prepare() (VXH_DBG_ALLOC=1
+    // reads every upload back), i.e. cleared by something that is not the engine's; never with hipMalloc (VXH_SYNC_ALLOC), never with the
+    // memory kept (0 of 250 against 7-8 of 250; gpurun_out/r6/refusedloop*.txt, HISTORY "Round 6").  A population's footprint is what the
+    // process needed at its peak anyway, and re-mapping it every generation costs time.  VXH_POOL_RELEASE=1: the runtime's default back.
+    if (!std::getenv("VXH_POOL_RELEASE")) {
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    }
     HIP_OK(hipStreamCreateWithFlags(&dev_->stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&dev_->ev0));
     HIP_OK(hipEventCreate(&dev_->ev1));
@@ -1377,6 +1417,7 @@ void Engine::prepare()
     B.smallish_angle_w = std::cos(VXH_HYST * VXH_SMALL_ANGLE_RAD * 0.5);
     B.slthresh_acos2sqrt = 1.0 - 0.9988 * 0.9988;
     HIP_OK(hipStreamSynchronize(D.stream));      // every upload has left the host vectors above
+    D.verify_uploads("at the end of prepare()");
     hs.mark("kernel choice, tiling, launch groups");
     hs.print("prepare");
     prepared_ = true;
@@ -1427,7 +1468,23 @@ void Engine::advance(long long max_rounds)
         const long long huge = 0x7fffffffffffffffLL / 4;
         advance_launch(max_rounds >= huge - before ? huge : before + max_rounds);
         advance_finish();
+    } catch (...) {
+        // a launch sequence that ended halfway (a refused kernel, a HIP error): nothing of it may still be queued when the caller goes on
+        quiesce();
+        throw;
     }
+}
+
+// every stream of this engine idle, no launched call pending, no sticky error: the state a failed call leaves behind
+void Engine::quiesce()
+{
+    Device& D = *dev_;
+    (void)hipSetDevice(device_id_);
+    for (hipStream_t st : D.group_streams) (void)hipStreamSynchronize(st);
+    if (D.tile_stream) (void)hipStreamSynchronize(D.tile_stream);
+    if (D.stream) (void)hipStreamSynchronize(D.stream);
+    (void)hipGetLastError();
+    D.pending.active = false;
 }
 
 void Engine::advance_launch(long long max_rounds)

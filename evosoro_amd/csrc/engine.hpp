@@ -80,6 +80,7 @@ private:
     void advance(long long max_rounds);        // launch step rounds and wait
     void advance_launch(long long max_rounds);
     void advance_finish();
+    void quiesce();                            // after a launch sequence that failed halfway: every stream idle, nothing pending
     void download();
     void download_control(bool already_copied = false);
     void download_reduced();                   // k_results + the traces: what results need, without the voxel state

@@ -1439,6 +1439,50 @@ if __name__ == "__main__" and "refcampaign" in sys.argv[1:]:
         significant, sorted(sig_files)), flush=True)
 
 
+if __name__ == "__main__" and "refusedloop" in sys.argv[1:]:
+    # hunt for the flake of tests/test_gpu_tiled.py::test_a_tile_kernel_that_needs_scratch_is_refused...: refusedloop <count> [noprev] [norefuse] [noreset]
+    count = int(sys.argv[2])
+    path = os.path.join(REPO, "tests", "golden", "vxa", "rand6_col.vxa")
+    with engine.Engine(engine.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 0); eng.set_option("wide", 0)
+        eng.add_vxa_file(path)
+        rest = eng.state(0).copy()
+        eng.step(10)
+        want = eng.state(0).copy()
+    bad = 0
+    for k in range(count):
+        if "noprev" not in sys.argv[1:]:
+            with engine.Engine(engine.VOXCAD, 0) as prev:     # (what ran before in the test file: tiles, several launches)
+                prev.set_option("tiled", 2); prev.set_option("tiles_per_robot", 3); prev.set_option("steps_per_launch", 7)
+                prev.add_vxa_file(path)
+                prev.step(40)
+        with engine.Engine(engine.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 2); eng.set_option("tiles_per_robot", 3)
+            eng.add_vxa_file(path)
+            if "norefuse" not in sys.argv[1:]:
+                os.environ["VXH_TILE_SCRATCH_LIMIT"] = "-1"
+                try:
+                    eng.step(10)
+                    print("not refused?!")
+                except engine.VxhError:
+                    pass
+                del os.environ["VXH_TILE_SCRATCH_LIMIT"]
+            if "noreset" not in sys.argv[1:]:
+                eng.reset()
+            eng.step(10)
+            got = eng.state(0)
+            d_want, d_rest = np.abs(got[:, :8] - want[:, :8]).max(), np.abs(got[:, :8] - rest[:, :8]).max()
+            if d_want > 1e-12:
+                bad += 1
+                r, c = eng.result(0), eng.counters()
+                print("iteration %d: |got - want| %.3e, |got - rest| %.3e; result steps %d status %d; counters launches %d max_steps %d dominant_block %d voxel_steps %.0f" % (
+                    k, d_want, d_rest, r.steps, r.status, c.launches, c.max_steps, c.dominant_block, c.voxel_steps), flush=True)
+                eng.step(10)
+                got2 = eng.state(0)
+                print("   ten more steps: result steps %d; |got2 - want| %.3e |got2 - got| %.3e" % (eng.result(0).steps, np.abs(got2[:, :8] - want[:, :8]).max(), np.abs(got2[:, :8] - got[:, :8]).max()), flush=True)
+    print("refusedloop %s: %d of %d wrong" % (" ".join(sys.argv[3:]), bad, count), flush=True)
+
+
 if __name__ == "__main__" and "xmlof" in sys.argv[1:]:
     # the result file of every .vxa given, as this library writes it: xmlof <variant> <path>...   (A/B of two libraries on one robot: scripts/ab_lib.py)
     variant = int(sys.argv[2])
