@@ -46,3 +46,12 @@ def kernel_path(request, monkeypatch):
     else:
         monkeypatch.delenv("VXH_ENGINE_OPTIONS", raising=False)
     yield request.param
+
+
+def free_port():
+    """a rendezvous port nobody listens on right now: a FIXED --master-port made a second launch within the first one's TIME_WAIT retry for
+    half a minute and more (round 6: test_two_ranks_share_the_gpu 34-77 s instead of 7 on one box in six)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

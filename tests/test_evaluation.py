@@ -13,6 +13,7 @@ from evosoro_amd import workloads
 from evosoro_amd.base import Sim, Env, ObjectiveDict
 from evosoro_amd.tools.evaluation import evaluate_all
 from oracle import vxoracle as vo
+from conftest import free_port
 
 
 class Log(object):
@@ -84,7 +85,7 @@ def test_evaluate_all_on_two_ranks(tmp_path, route):
         os.makedirs(os.path.join(run, d))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=repo)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617" if route == "files" else "29619", os.path.join(repo, "tests", "dist_worker_eval.py"), run, route]
+           "--master-port", str(free_port()), os.path.join(repo, "tests", "dist_worker_eval.py"), run, route]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert proc.returncode == 0, proc.stdout.decode()[-3000:]
     r0, r1 = (json.load(open(os.path.join(run, "rank%d.json" % k))) for k in (0, 1))

@@ -20,6 +20,7 @@ import subprocess
 
 import numpy as np
 import pytest
+from conftest import free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -696,7 +697,7 @@ def test_two_ranks_share_the_gpu(eng_mod, golden_dir, tmp_path):
     from evosoro_amd import parallel
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29633", os.path.join(os.path.dirname(__file__), "dist_worker_gpu.py"), str(tmp_path),
+           "--master-port", str(free_port()), os.path.join(os.path.dirname(__file__), "dist_worker_gpu.py"), str(tmp_path),
            os.path.join(golden_dir, "vxa")]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]

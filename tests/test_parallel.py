@@ -6,6 +6,7 @@ import sys
 import numpy as np
 
 from evosoro_amd import parallel
+from conftest import free_port
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -31,7 +32,7 @@ def test_gather_without_process_group():
 def test_two_rank_gloo_run(tmp_path, golden_dir):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=REPO)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29613", os.path.join(REPO, "tests", "dist_worker.py"), str(tmp_path),
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(REPO, "tests", "dist_worker.py"), str(tmp_path),
            os.path.join(golden_dir, "vxa")]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert proc.returncode == 0, proc.stdout.decode()[-3000:]
