@@ -389,3 +389,39 @@ def test_a_tile_kernel_that_needs_scratch_is_refused_before_it_is_launched(golde
         eng.add_vxa_file(path)
         eng.step(10)
         assert np.abs(eng.state(0)[:, :8] - tiled[:, :8]).max() < 1e-12
+
+
+def test_the_engine_keeps_the_pools_memory_between_batches(golden_dir, monkeypatch):
+    """Round 6, found by looping this file on one box: the engine that had refused a launch (the test above), then reset() and stepped, came
+    back with the REST state in 3 % of fresh processes -- the first two uploads of the re-uploaded batch (DRobot, DRobotState: the first
+    0x290 bytes of a chunk the stream-ordered pool had just handed back to the driver and acquired again) read zero at the end of prepare()
+    although they were right behind their copies.  Never with the memory kept: the engine raises the default pool's release threshold
+    (engine.hip, Engine::Engine; VXH_POOL_RELEASE=1 leaves the runtime's default).  A 3-% event cannot be asserted in one run; what can is that
+    the threshold is what the engine says it is, and that the refused-then-reset sequence is right ten times over in this process."""
+    import ctypes
+    from evosoro_amd import engine as eng_mod
+    path = os.path.join(golden_dir, "vxa", "rand6_col.vxa")
+    monkeypatch.delenv("VXH_POOL_RELEASE", raising=False)
+    with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+        eng.set_option("tiled", 0)
+        eng.set_option("wide", 0)
+        eng.add_vxa_file(path)
+        eng.step(10)
+        want = eng.state(0).copy()
+        hip = ctypes.CDLL("libamdhip64.so")
+        pool, keep = ctypes.c_void_p(), ctypes.c_uint64(0)
+        assert hip.hipDeviceGetDefaultMemPool(ctypes.byref(pool), 0) == 0 and pool.value
+        assert hip.hipMemPoolGetAttribute(pool, 4, ctypes.byref(keep)) == 0           # hipMemPoolAttrReleaseThreshold
+        assert keep.value == 2 ** 64 - 1
+    for _ in range(10):
+        with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
+            eng.set_option("tiled", 2)
+            eng.set_option("tiles_per_robot", 3)
+            eng.add_vxa_file(path)
+            monkeypatch.setenv("VXH_TILE_SCRATCH_LIMIT", "-1")
+            with pytest.raises(eng_mod.VxhError):
+                eng.step(10)
+            monkeypatch.delenv("VXH_TILE_SCRATCH_LIMIT")
+            eng.reset()
+            eng.step(10)
+            assert np.abs(eng.state(0)[:, :8] - want[:, :8]).max() < 1e-12
