@@ -408,11 +408,17 @@ def test_the_engine_keeps_the_pools_memory_between_batches(golden_dir, monkeypat
         eng.add_vxa_file(path)
         eng.step(10)
         want = eng.state(0).copy()
-        hip = ctypes.CDLL("libamdhip64.so")
-        pool, keep = ctypes.c_void_p(), ctypes.c_uint64(0)
-        assert hip.hipDeviceGetDefaultMemPool(ctypes.byref(pool), 0) == 0 and pool.value
-        assert hip.hipMemPoolGetAttribute(pool, 4, ctypes.byref(keep)) == 0           # hipMemPoolAttrReleaseThreshold
-        assert keep.value == 2 ** 64 - 1
+        # the HIP runtime the ENGINE is linked against: a process that has imported torch holds two copies of libamdhip64 (torch ships its
+        # own), and the soname alone may resolve to the other one, which has never seen a device (hipErrorNoDevice)
+        copies = sorted({line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line})
+        answers = []
+        for lib_path in copies:
+            hip = ctypes.CDLL(lib_path)
+            pool, keep = ctypes.c_void_p(), ctypes.c_uint64(0)
+            if hip.hipDeviceGetDefaultMemPool(ctypes.byref(pool), 0) == 0 and pool.value \
+                    and hip.hipMemPoolGetAttribute(pool, 4, ctypes.byref(keep)) == 0:           # hipMemPoolAttrReleaseThreshold
+                answers.append(keep.value)
+        assert 2 ** 64 - 1 in answers, (copies, answers)
     for _ in range(10):
         with eng_mod.Engine(eng_mod.VOXCAD, 0) as eng:
             eng.set_option("tiled", 2)
